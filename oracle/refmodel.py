@@ -1,0 +1,398 @@
+"""Plain-torch CPU restatement of the reference GAN hot path (ORACLE, tests only).
+
+Every class cites the reference lines it follows (paths relative to
+/root/reference).  The generator's U-Net restates MONAI 0.4.0
+(`monai.networks.nets.UNet`, `monai.networks.blocks.{Convolution,ResidualUnit,
+ADN}`, `monai.networks.layers.SkipConnection`), which the reference calls at
+code/GAN/GAN_final.py:106-114 but does not vendor -- generator parity is
+therefore UNPINNED (see oracle/__init__.py).
+
+Module / parameter names reproduce the reference's state_dict keys
+ so reference checkpoints would load.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_CONV = {2: nn.Conv2d, 3: nn.Conv3d}
+_CONVT = {2: nn.ConvTranspose2d, 3: nn.ConvTranspose3d}
+_BN = {2: nn.BatchNorm2d, 3: nn.BatchNorm3d}
+_IN = {2: nn.InstanceNorm2d, 3: nn.InstanceNorm3d}
+
+
+def _norm_layer(norm: str, dims: int, ch: int) -> nn.Module:
+    if norm == "batch":
+        return _BN[dims](ch)  # eps 1e-5, momentum .1, affine, track stats
+    if norm == "instance":
+        # north_star asks for InstanceNorm; affine so it has the same
+        # parameters as the batch variant, no running stats (torch default).
+        return _IN[dims](ch, affine=True)
+    raise ValueError(norm)
+
+
+class ADN(nn.Sequential):
+    """MONAI 0.4.0 ADN with ordering "NDA": Norm -> Dropout(p=0) -> PReLU."""
+
+    def __init__(self, dims: int, ch: int, norm: str):
+        super().__init__()
+        self.add_module("N", _norm_layer(norm, dims, ch))
+        self.add_module("D", nn.Dropout(0.0))
+        self.add_module("A", nn.PReLU())  # one shared alpha, init 0.25
+
+
+class Convolution(nn.Sequential):
+    """MONAI 0.4.0 Convolution: conv (k=3, pad=1) [+ ADN unless conv_only]."""
+
+    def __init__(self, dims, cin, cout, strides=1, kernel_size=3,
+                 conv_only=False, is_transposed=False, norm="batch"):
+        super().__init__()
+        pad = (kernel_size - 1) // 2
+        if is_transposed:
+            conv = _CONVT[dims](cin, cout, kernel_size, stride=strides,
+                                padding=pad, output_padding=strides - 1,
+                                bias=True)
+        else:
+            conv = _CONV[dims](cin, cout, kernel_size, stride=strides,
+                               padding=pad, bias=True)
+        self.add_module("conv", conv)
+        if not conv_only:
+            self.add_module("adn", ADN(dims, cout, norm))
+
+
+class ResidualUnit(nn.Module):
+    """MONAI 0.4.0 ResidualUnit: conv(x) + residual(x)."""
+
+    def __init__(self, dims, cin, cout, strides=1, kernel_size=3, subunits=2,
+                 last_conv_only=False, norm="batch"):
+        super().__init__()
+        self.conv = nn.Sequential()
+        self.residual = nn.Identity()
+        sch, sst = cin, strides
+        subunits = max(1, subunits)
+        for su in range(subunits):
+            conv_only = last_conv_only and su == subunits - 1
+            self.conv.add_module(
+                f"unit{su:d}",
+                Convolution(dims, sch, cout, sst, kernel_size,
+                            conv_only=conv_only, norm=norm))
+            sch, sst = cout, 1
+        if strides != 1 or cin != cout:
+            rk, rp = kernel_size, (kernel_size - 1) // 2
+            if strides == 1:
+                rk, rp = 1, 0
+            self.residual = _CONV[dims](cin, cout, rk, strides, rp, bias=True)
+
+    def forward(self, x):
+        return self.conv(x) + self.residual(x)
+
+
+class SkipConnection(nn.Module):
+    def __init__(self, submodule):
+        super().__init__()
+        self.submodule = submodule
+
+    def forward(self, x):
+        return torch.cat([x, self.submodule(x)], dim=1)
+
+
+class UNet(nn.Module):
+    """MONAI 0.4.0 UNet as the reference parametrises it
+    (code/GAN/GAN_final.py:106-114): num_res_units=2, kernel 3, PReLU."""
+
+    def __init__(self, dimensions=3, in_channels=1, out_channels=1,
+                 channels=(16, 32, 64, 128), strides=(2, 2, 2),
+                 num_res_units=2, norm="batch"):
+        super().__init__()
+        self.dimensions = dimensions
+        self.num_res_units = num_res_units
+        self.norm = norm
+        assert num_res_units > 0
+
+        def down(inc, outc, s):
+            return ResidualUnit(dimensions, inc, outc, s, 3,
+                                subunits=num_res_units, norm=norm)
+
+        def up(inc, outc, s, is_top):
+            conv = Convolution(dimensions, inc, outc, s, 3, conv_only=False,
+                               is_transposed=True, norm=norm)
+            ru = ResidualUnit(dimensions, outc, outc, 1, 3, subunits=1,
+                              last_conv_only=is_top, norm=norm)
+            return nn.Sequential(conv, ru)
+
+        def block(inc, outc, chs, sts, is_top):
+            c, s = chs[0], sts[0]
+            if len(chs) > 2:
+                sub = block(c, c, chs[1:], sts[1:], False)
+                upc = c * 2
+            else:
+                sub = down(c, chs[1], 1)
+                upc = c + chs[1]
+            return nn.Sequential(down(inc, c, s), SkipConnection(sub),
+                                 up(upc, outc, s, is_top))
+
+        self.model = block(in_channels, out_channels, tuple(channels),
+                           tuple(strides), True)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class CasNetGenerator(nn.Module):
+    """code/GAN/GAN_final.py:92-122 (variant A: 6 U-Nets, 16..128, strides 2^3)
+    and test_runs/GAN.py:94-129 (variant B: 4 U-Nets, 32..256, strides 2^4)."""
+
+    def __init__(self, img_shape, n_unet_blocks=6, *, dimensions=3,
+                 norm="batch", channels=(16, 32, 64, 128), strides=(2, 2, 2)):
+        super().__init__()
+        self.img_shape = img_shape
+        nets = [UNet(dimensions, 1, 1, channels, strides, 2, norm)
+                for _ in range(n_unet_blocks)]
+        nets.append(nn.Tanh())
+        self.model = nn.Sequential(*nets)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+def disc_feature_sizes(spatial: Sequence[int], variant: str = "A"):
+    """Spatial sizes after each valid conv of the discriminator."""
+    cfg = ([(3, 1), (3, 1), (4, 2), (4, 2)] if variant == "A"
+           else [(3, 1)] * 4)
+    sizes = [tuple(spatial)]
+    for k, s in cfg:
+        sizes.append(tuple((n - k) // s + 1 for n in sizes[-1]))
+    return sizes
+
+
+class Discriminator(nn.Module):
+    """Variant A: code/GAN/GAN_final.py:159-209.  The reference hard-codes
+    Linear(256*29*29*29, 1) (:201), i.e. a 128^3 input; here in_features is
+    computed from `img_shape` (identical for 128^3) so 2-D / small inputs work."""
+
+    def __init__(self, img_shape, use_perceptual=True, *, dimensions=3):
+        super().__init__()
+        self.use_perceptual = use_perceptual
+        C, B = _CONV[dimensions], _BN[dimensions]
+        self.model_conv = nn.Sequential(
+            C(1, 64, 3, 1), B(64), nn.LeakyReLU(0.2, inplace=True),
+            C(64, 128, 3, 1), B(128), nn.LeakyReLU(0.2, inplace=True),
+            C(128, 256, 4, 2), B(256), nn.LeakyReLU(0.2, inplace=True),
+            C(256, 256, 4, 2), B(256), nn.LeakyReLU(0.2, inplace=True),
+        )
+        spatial = tuple(img_shape)[-dimensions:]
+        last = disc_feature_sizes(spatial, "A")[-1]
+        self.model_linear = nn.Sequential(
+            nn.Flatten(), nn.Linear(256 * int(np.prod(last)), 1), nn.Sigmoid())
+
+    def forward(self, img):
+        return self.model_linear(self.model_conv(img))
+
+
+class PatchDiscriminator(nn.Module):
+    """Variant B: test_runs/GAN.py:136-198.  Four valid k3 s1 convs
+    1->64->128->256->512 (+BN+LeakyReLU), Flatten, Linear(512*8^3, 64),
+    Linear(64, 1), Sigmoid on 16^3 patches; returns (validity, taps) where the
+    taps are clones after each of the 12+4 modules (:183-198).  The in-place
+    LeakyReLU runs AFTER the BN-index clone was taken, so tap[1] is post-BN
+    pre-activation and tap[2] post-activation."""
+
+    def __init__(self, img_shape, use_perceptual=True, *, dimensions=3,
+                 patch=16):
+        super().__init__()
+        self.use_perceptual = use_perceptual
+        C, B = _CONV[dimensions], _BN[dimensions]
+        self.model_conv = nn.Sequential(
+            C(1, 64, 3, 1), B(64), nn.LeakyReLU(0.2, inplace=True),
+            C(64, 128, 3, 1), B(128), nn.LeakyReLU(0.2, inplace=True),
+            C(128, 256, 3, 1), B(256), nn.LeakyReLU(0.2, inplace=True),
+            C(256, 512, 3, 1), B(512), nn.LeakyReLU(0.2, inplace=True),
+        )
+        last = disc_feature_sizes((patch,) * dimensions, "B")[-1]
+        self.model_linear = nn.Sequential(
+            nn.Flatten(), nn.Linear(512 * int(np.prod(last)), 64),
+            nn.Linear(64, 1), nn.Sigmoid())
+
+    def forward(self, x):
+        taps: Dict[int, torch.Tensor] = {}
+        idx = 0
+        for module in self.model_conv:
+            x = module(x)
+            if self.use_perceptual:
+                taps[idx] = x.clone()
+                idx += 1
+        for module in self.model_linear:
+            x = module(x)
+            if self.use_perceptual:
+                taps[idx] = x.clone()
+                idx += 1
+        return x, taps
+
+
+# --------------------------------------------------------------------------
+# loss hooks
+# --------------------------------------------------------------------------
+def adversarial_loss(y_hat, y):
+    """code/GAN/GAN_final.py:244-245 (mean BCE, log terms clamped >= -100)."""
+    return F.binary_cross_entropy(y_hat, y)
+
+
+def reconstruction_loss(y_hat, y):
+    """code/GAN/GAN_final.py:247-248."""
+    return F.l1_loss(y_hat, y)
+
+
+def perceptual_loss(y_hat_activations, y_activations):
+    """test_runs/GAN.py:288-298: sum_k L1mean(real_k, fake_k) / numel_k,
+    result shape (1,)."""
+    assert set(y_activations.keys()) == set(y_hat_activations.keys())
+    running = torch.zeros(1, dtype=y_hat_activations[0].dtype)
+    for key in y_activations.keys():
+        running = running + (F.l1_loss(y_activations[key],
+                                       y_hat_activations[key])
+                             / y_activations[key].numel())
+    return running
+
+
+def crop_patches(vols: torch.Tensor, corners: np.ndarray, roi: int):
+    """The gather half of RandSpatialCropSamplesd as the reference uses it
+    (test_runs/GAN.py:263-272,313-337): `corners` is (B, S, dims) int; returns
+    (B*S, 1, roi...) with the samples of volume 0 first."""
+    B, S, dims = corners.shape
+    out = []
+    for b in range(B):
+        for s in range(S):
+            sl = tuple(slice(int(c), int(c) + roi) for c in corners[b, s])
+            out.append(vols[(b, slice(None)) + sl].unsqueeze(0))
+    return torch.cat(out, dim=0)
+
+
+def draw_corners(rs: np.random.RandomState, batch: int, samples: int,
+                 spatial: Sequence[int], roi: int) -> np.ndarray:
+    """Corner stream of MONAI's RandSpatialCropSamplesd(random_size=False):
+    per volume, per sample, per spatial dim one `randint(0, size-roi+1)`.
+    (Restated from MONAI 0.4.0; the RNG stream itself is parity-unpinned.)"""
+    c = np.zeros((batch, samples, len(spatial)), dtype=np.int64)
+    for b in range(batch):
+        for s in range(samples):
+            for d, n in enumerate(spatial):
+                c[b, s, d] = rs.randint(0, n - roi + 1)
+    return c
+
+
+# --------------------------------------------------------------------------
+# the two-optimizer step (Lightning 1.2.1 loop)
+# --------------------------------------------------------------------------
+class GAN(nn.Module):
+    """code/GAN/GAN_final.py:212-317 without Lightning: `training_step` has the
+    reference's body; `step` is the (G then D) optimizer alternation."""
+
+    def __init__(self, img_shape, *, dimensions=3, norm="batch",
+                 n_unet_blocks=6, d_lr=5e-4, g_lr=5e-4, b1=0.5, b2=0.999,
+                 one_sided_label_value=0.9, channels=(16, 32, 64, 128),
+                 strides=(2, 2, 2)):
+        super().__init__()
+        self.hparams = dict(d_lr=d_lr, g_lr=g_lr, b1=b1, b2=b2,
+                            one_sided_label_value=one_sided_label_value)
+        self.generator = CasNetGenerator(img_shape, n_unet_blocks,
+                                         dimensions=dimensions, norm=norm,
+                                         channels=channels, strides=strides)
+        self.discriminator = Discriminator(img_shape, dimensions=dimensions)
+        self.logged: Dict[str, float] = {}
+
+    def forward(self, x):
+        return self.generator(x)
+
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        t1w, t2w = batch["t1w"], batch["t2w"]
+        if optimizer_idx == 0:                       # GAN_final.py:254-273
+            gen = self(t1w)
+            self.generated_imgs = gen
+            valid = torch.ones(t1w.shape[0], 1).type_as(t1w)
+            g_adv = adversarial_loss(self.discriminator(gen), valid)
+            g_rec = reconstruction_loss(gen, t2w)
+            g_loss = g_adv + g_rec
+            self.logged.update(g_adv_loss=float(g_adv), g_recon_loss=float(g_rec),
+                               g_loss=float(g_loss))
+            return g_loss
+        if optimizer_idx == 1:                       # GAN_final.py:276-296
+            valid = (torch.ones(t1w.shape[0], 1)
+                     * self.hparams["one_sided_label_value"]).type_as(t1w)
+            real_loss = adversarial_loss(self.discriminator(t2w), valid)
+            fake = torch.zeros(t1w.shape[0], 1).type_as(t1w)
+            fake_loss = adversarial_loss(
+                self.discriminator(self(t1w).detach()), fake)
+            d_loss = (real_loss + fake_loss) / 2
+            self.logged.update(d_loss=float(d_loss))
+            return d_loss
+
+    def configure_optimizers(self):                  # GAN_final.py:298-308
+        h = self.hparams
+        opt_g = torch.optim.Adam(self.generator.parameters(), lr=h["g_lr"],
+                                 betas=(h["b1"], h["b2"]))
+        opt_d = torch.optim.Adam(self.discriminator.parameters(), lr=h["d_lr"],
+                                 betas=(h["b1"], h["b2"]))
+        return [opt_g, opt_d], []
+
+    def step(self, batch, batch_idx, optimizers):
+        """One Lightning batch: for (idx, opt): toggle -> zero_grad ->
+        training_step -> backward -> opt.step (Appendix B)."""
+        nets = [self.generator, self.discriminator]
+        for idx, opt in enumerate(optimizers):
+            other = nets[1 - idx]
+            for p in other.parameters():
+                p.requires_grad_(False)
+            opt.zero_grad()
+            loss = self.training_step(batch, batch_idx, idx)
+            loss.backward()
+            opt.step()
+            for p in other.parameters():
+                p.requires_grad_(True)
+        return dict(self.logged)
+
+
+# --------------------------------------------------------------------------
+# deterministic closed-form weights (fixtures hold inputs/outputs only)
+# --------------------------------------------------------------------------
+def closed_form_fill_(module: nn.Module, scale: float = 1.0) -> None:
+    """Deterministic weights: the k-th tensor (named_modules order, parameters
+    then buffers) gets t.flat[i] = amp * sin(0.37*i + 1.3*k).  Conv / linear
+    weights use amp = scale/sqrt(fan_in) so activations stay O(1); norm weights
+    are 1 +- 0.1, PReLU alpha 0.25 +- 0.05, biases +-0.1; running stats are
+    reset to (0, 1, 0)."""
+    k = 0
+    with torch.no_grad():
+        for _, m in module.named_modules():
+            tensors = list(m._parameters.items()) + list(m._buffers.items())
+            for name, t in tensors:
+                if t is None:
+                    continue
+                k += 1
+                if name == "num_batches_tracked" or name == "running_mean":
+                    t.zero_()
+                    continue
+                if name == "running_var":
+                    t.fill_(1.0)
+                    continue
+                i = torch.arange(t.numel(), dtype=torch.float64)
+                wave = torch.sin(0.37 * i + 1.3 * k).reshape(t.shape)
+                is_norm = isinstance(m, (nn.modules.batchnorm._BatchNorm,
+                                         nn.modules.instancenorm._InstanceNorm))
+                if isinstance(m, nn.PReLU):
+                    v = 0.25 + 0.05 * wave
+                elif is_norm and name == "weight":
+                    v = 1.0 + 0.1 * wave
+                elif t.dim() >= 2:
+                    v = (scale / math.sqrt(t[0].numel())) * wave
+                else:
+                    v = 0.1 * wave
+                t.copy_(v.float())
+
+
+def param_count(m: nn.Module) -> int:
+    return sum(p.numel() for p in m.parameters())

@@ -1,0 +1,85 @@
+"""ctypes binding of libmpgan_hip.so (the C ABI declared in include/mpgan_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpgan_hip.so")
+_lib = None
+
+
+class ConvGeomC(C.Structure):
+    _fields_ = [("n", C.c_int32), ("in_dhw", C.c_int32 * 3), ("out_dhw", C.c_int32 * 3),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("k", C.c_int32 * 3),
+                ("stride", C.c_int32 * 3), ("pad", C.c_int32 * 3), ("transposed", C.c_int32)]
+
+
+class PrologueC(C.Structure):
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("n_stride", C.c_int32),
+                ("act", C.c_int32), ("slope", C.c_float), ("slope_ptr", C.c_void_p)]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_L = C.c_int64
+_F = C.c_float
+_G = C.POINTER(ConvGeomC)
+_PR = C.POINTER(PrologueC)
+_I3 = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); must list EVERY symbol include/mpgan_hip.h declares
+SIGNATURES = {
+    "mpgan_last_error": (C.c_char_p, []),
+    "mpgan_abi_version": (_I, []),
+    "mpgan_conv_forward": (_I, [_G, _P, _I, _P, _P, _PR, _P, _I, _I, _P, _I, _P]),
+    "mpgan_conv_backward_data": (_I, [_G, _P, _I, _P, _P, _I, _P, _I, _P]),
+    "mpgan_conv_wgrad_workspace": (_L, [_G]),
+    "mpgan_conv_backward_weight": (_I, [_G, _P, _I, _PR, _P, _I, _P, _F, _P, _L, _P]),
+    "mpgan_pack_weights": (_I, [_P, _P, _P, _I, _L, _P]),
+    "mpgan_stats_chunks": (_I, [_L, _I]),
+    "mpgan_channel_stats": (_I, [_P, _I, _I, _L, _I, _P, _P]),
+    "mpgan_norm_finalize": (_I, [_P, _I, _I, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mpgan_norm_act_add": (_I, [_P, _I, _PR, _P, _I, _PR, _I, _L, _I, _I, _P, _I, _P]),
+    "mpgan_norm_bwd_reduce": (_I, [_P, _I, _P, _I, _PR, _P, _P, _I, _L, _I, _P, _P]),
+    "mpgan_norm_bwd_finalize": (_I, [_P, _I, _I, _I, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "mpgan_norm_bwd_apply": (_I, [_P, _I, _P, _I, _PR, _P, _P, _P, _P, _I, _L, _I, _P, _I, _P]),
+    "mpgan_reduce_partials": (_I, [_P, _I, _I, _I, _P, _F, _P]),
+    "mpgan_add_tanh": (_I, [_P, _P, _L, _I, _P, _P]),
+    "mpgan_tanh_backward": (_I, [_P, _P, _L, _P, _P]),
+    "mpgan_axpby": (_I, [_P, _F, _P, _F, _L, _P, _P]),
+    "mpgan_copy_slice": (_I, [_P, _I, _P, _I, _L, _I, _I, _P]),
+    "mpgan_linear1_partials": (_I, [_I]),
+    "mpgan_linear1_forward": (_I, [_P, _PR, _I, _L, _I, _P, _P, _P, _P, _P]),
+    "mpgan_linear1_backward": (_I, [_P, _PR, _I, _L, _I, _P, _P, _P, _P, _P, _F, _P]),
+    "mpgan_sigmoid_bce": (_I, [_P, _I, _F, _F, _P, _P, _P, _P]),
+    "mpgan_l1_partials": (_I, []),
+    "mpgan_l1_loss": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
+    "mpgan_adam_step": (_I, [_P, _P, _P, _P, _L, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, _P]),
+    "mpgan_patch_gather": (_I, [_P, _I, _I3, _P, _I, _I3, _P, _P]),
+    "mpgan_patch_scatter_add": (_I, [_P, _I, _I3, _P, _I, _I3, _P, _P]),
+}
+
+
+def lib():
+    """Return the loaded library; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP hot path has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().mpgan_last_error().decode()
+        raise RuntimeError(f"{what} failed (status {rc}): {msg}")

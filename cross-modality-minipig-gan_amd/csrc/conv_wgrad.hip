@@ -1,0 +1,385 @@
+// Weight gradient of ConvNd / ConvTransposeNd on the fp32 matrix cores.
+//
+// GEMM view: R[cd][t*Cg + cg] = sum_m dense[m][cd] * gathered[pix(m,t)][cg]
+// with m over the COARSE pixel grid and pix(m,t) = m*stride - pad + k_t
+// (forward-type mapping):
+//   ConvNd:           dense = dy (Cout), gathered = x (Cin, optional norm+act prologue)
+//   ConvTransposeNd:  dense = x  (Cin),  gathered = dy (Cout)
+// so R is dW in torch layout [cd][cg][t] up to the (t,cg) order, which the
+// split-K reducer fixes while summing the slabs in a fixed order
+// (deterministic; no atomics).
+//
+// Both operands are "K-major" as stored (one channels-last pixel row per K), so
+// LDS tiles are [pixel][channel] and the 32x32x2 MFMA operand of lane (i,h) is
+// tile[2s+h][i]: consecutive lanes read consecutive floats -- conflict-free
+// ds_read_b32 with no transposition.
+#include "mpgan_common.h"
+
+namespace mpgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradParams {
+  const float* dense;
+  const float* gath;
+  float* partial;  // [split][Cd][T*Cg]
+  Pro pro;         // prologue on the gathered operand
+  int ldd, Cd, ldg, Cg;
+  int N, Mz, My, Mx;  // coarse grid
+  int Gz, Gy, Gx;     // gathered tensor spatial dims
+  int Kz, Ky, Kx;
+  int sz, sy, sx, pz, py, px;
+  int nsplit;
+  long chunk;  // pixels per split (multiple of 32)
+};
+
+constexpr int WBK = 32;
+
+// KW = 1: the 4 waves tile the BD x BG block (WM x WN waves of TM x TN tiles).
+// KW = 4: small block (<= 64x32): every wave owns the whole tile and a quarter
+//         of each K-step; the 4 wave-partials go to 4 slabs of the workspace.
+template <int BD, int BG, int TM, int TN, int WN, int KW, bool SCALAR_D, bool SCALAR_G>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int STAGE = WBK * (BD + BG);
+  constexpr int DCH = BD / 4, GCH = BG / 4;          // float4 chunks per pixel row
+  constexpr int DLOADS = (WBK * DCH) / 256;          // chunks per thread
+  constexpr int GLOADS = (WBK * GCH) / 256 > 0 ? (WBK * GCH) / 256 : 1;
+  constexpr int GTHREADS = WBK * GCH;                // threads that load the gathered tile (<=256)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = KW == 1 ? wid / WN : 0, wn = KW == 1 ? wid % WN : 0;
+  const int T = p.Kz * p.Ky * p.Kx;
+  const int NC = T * p.Cg;  // columns of R
+  const int c0 = blockIdx.x * BG;
+  const int d0 = blockIdx.y * BD;
+  const long M = (long)p.N * p.Mz * p.My * p.Mx;
+  const long mbeg = (long)blockIdx.z * p.chunk;
+  const long mend = mbeg + p.chunk < M ? mbeg + p.chunk : M;
+  const int nk = mbeg < mend ? (int)((mend - mbeg + WBK - 1) / WBK) : 0;
+  const float slope = pro_slope(p.pro);
+
+  // ---- gathered operand: this thread's column chunk is fixed for the block ----
+  const int gcc = tid % GCH, grow0 = tid / GCH;      // rows grow0 + (256/GCH)*i
+  int gtap[4], gci[4], gkz[4], gky[4], gkx[4];
+  bool gvalid[4];
+  {
+    const int nel = SCALAR_G ? 4 : 1;
+    for (int e = 0; e < 4; ++e) {
+      gvalid[e] = false; gtap[e] = gci[e] = gkz[e] = gky[e] = gkx[e] = 0;
+      if (e >= nel) continue;
+      int col = c0 + gcc * 4 + e;
+      if (col < NC) {
+        int t = col / p.Cg;
+        gci[e] = col - t * p.Cg;
+        gtap[e] = t;
+        gkx[e] = t % p.Kx;
+        int q = t / p.Kx;
+        gky[e] = q % p.Ky;
+        gkz[e] = q / p.Ky;
+        gvalid[e] = true;
+      }
+    }
+  }
+  // ---- dense operand chunk ----
+  const int dcc = tid % DCH, drow0 = tid / DCH;      // rows drow0 + (256/DCH)*i
+
+  float4 rd[DLOADS], rg[GLOADS];
+
+  auto global_load = [&](int kt) {
+    const long mb = mbeg + (long)kt * WBK;
+#pragma unroll
+    for (int i = 0; i < DLOADS; ++i) {
+      const long m = mb + drow0 + (256 / DCH) * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < mend) {
+        const int c = d0 + dcc * 4;
+        if constexpr (!SCALAR_D) {
+          if (c < p.Cd) v = *reinterpret_cast<const float4*>(p.dense + m * p.ldd + c);
+        } else {
+          const float* src = p.dense + m * p.ldd;
+          if (c + 0 < p.Cd) v.x = src[c + 0];
+          if (c + 1 < p.Cd) v.y = src[c + 1];
+          if (c + 2 < p.Cd) v.z = src[c + 2];
+          if (c + 3 < p.Cd) v.w = src[c + 3];
+        }
+      }
+      rd[i] = v;
+    }
+    if (GTHREADS >= 256 || tid < GTHREADS) {
+#pragma unroll
+      for (int i = 0; i < GLOADS; ++i) {
+        const long m = mb + grow0 + (256 / GCH) * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < mend) {
+          int mx = (int)(m % p.Mx);
+          long q = m / p.Mx;
+          int my = (int)(q % p.My);
+          q /= p.My;
+          int mz = (int)(q % p.Mz);
+          int n = (int)(q / p.Mz);
+          const int bz = mz * p.sz - p.pz, by = my * p.sy - p.py, bx = mx * p.sx - p.px;
+          if constexpr (!SCALAR_G) {
+            int iz = bz + gkz[0], iy = by + gky[0], ix = bx + gkx[0];
+            if (gvalid[0] && (unsigned)iz < (unsigned)p.Gz && (unsigned)iy < (unsigned)p.Gy &&
+                (unsigned)ix < (unsigned)p.Gx) {
+              long pix = (((long)n * p.Gz + iz) * p.Gy + iy) * p.Gx + ix;
+              v = *reinterpret_cast<const float4*>(p.gath + pix * p.ldg + gci[0]);
+              if (p.pro.scale) {
+                int si = n * p.pro.n_stride + gci[0];
+                float4 sc = *reinterpret_cast<const float4*>(p.pro.scale + si);
+                float4 sh = *reinterpret_cast<const float4*>(p.pro.shift + si);
+                v.x = act_apply(v.x * sc.x + sh.x, p.pro.act, slope);
+                v.y = act_apply(v.y * sc.y + sh.y, p.pro.act, slope);
+                v.z = act_apply(v.z * sc.z + sh.z, p.pro.act, slope);
+                v.w = act_apply(v.w * sc.w + sh.w, p.pro.act, slope);
+              }
+            }
+          } else {
+            float w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              w[e] = 0.f;
+              int iz = bz + gkz[e], iy = by + gky[e], ix = bx + gkx[e];
+              if (gvalid[e] && (unsigned)iz < (unsigned)p.Gz && (unsigned)iy < (unsigned)p.Gy &&
+                  (unsigned)ix < (unsigned)p.Gx) {
+                long pix = (((long)n * p.Gz + iz) * p.Gy + iy) * p.Gx + ix;
+                float x = p.gath[pix * p.ldg + gci[e]];
+                if (p.pro.scale) {
+                  int si = n * p.pro.n_stride + gci[e];
+                  x = act_apply(x * p.pro.scale[si] + p.pro.shift[si], p.pro.act, slope);
+                }
+                w[e] = x;
+              }
+            }
+            v = make_float4(w[0], w[1], w[2], w[3]);
+          }
+        }
+        rg[i] = v;
+      }
+    }
+  };
+
+  auto lds_store = [&](int buf) {
+    float* Ds = lds + buf * STAGE;
+    float* Gs = Ds + WBK * BD;
+#pragma unroll
+    for (int i = 0; i < DLOADS; ++i)
+      *reinterpret_cast<float4*>(Ds + (drow0 + (256 / DCH) * i) * BD + dcc * 4) = rd[i];
+    if (GTHREADS >= 256 || tid < GTHREADS) {
+#pragma unroll
+      for (int i = 0; i < GLOADS; ++i)
+        *reinterpret_cast<float4*>(Gs + (grow0 + (256 / GCH) * i) * BG + gcc * 4) = rg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (nk > 0) {
+    global_load(0);
+    lds_store(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) global_load(kt + 1);
+    const float* Ds = lds + cur * STAGE + wm * TM * 32 + li;
+    const float* Gs = lds + cur * STAGE + WBK * BD + wn * TN * 32 + li;
+#pragma unroll
+    for (int s0 = 0; s0 < 16 / KW; ++s0) {
+      const int s = KW == 1 ? s0 : s0 + (16 / KW) * wid;
+      const int kk = 2 * s + lh;
+      float a[TM], b[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) a[tm] = Ds[kk * BD + tm * 32];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b[tn] = Gs[kk * BG + tn * 32];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lds_store(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* out = p.partial + ((long)blockIdx.z * KW + (KW == 1 ? 0 : wid)) * p.Cd * NC;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = c0 + (wn * TN + tn) * 32 + li;
+      if (col >= NC) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cd = d0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (cd < p.Cd) out[(long)cd * NC + col] = acc[tm][tn][r];
+      }
+    }
+}
+
+// dW[cd][cg][t] = beta*dW + sum_split partial[split][cd][t*Cg+cg]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           int nsplit, int Cd, int Cg, int T, float beta) {
+  const long total = (long)Cd * Cg * T;
+  const long NC = (long)T * Cg;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // i enumerates the partial layout (coalesced reads): cd, t, cg
+    const long cd = i / NC;
+    const long rem = i - cd * NC;
+    const int t = (int)(rem / Cg);
+    const int cg = (int)(rem - (long)t * Cg);
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(long)k * total + i];
+    const long o = (cd * Cg + cg) * T + t;
+    dw[o] = beta != 0.f ? beta * dw[o] + s : s;
+  }
+}
+
+struct WgradPlan {
+  int BD, BG, nsplit, kw;
+  long chunk;
+  int tiles_c, tiles_d;
+};
+
+static WgradPlan plan_wgrad(int Cd, int NC, long M) {
+  WgradPlan pl;
+  pl.BD = Cd > 64 ? 128 : (Cd > 32 ? 64 : 32);
+  pl.BG = NC > 64 ? 128 : (NC > 32 ? 64 : 32);
+  pl.kw = 1;
+  if (pl.BD <= 64 && pl.BG == 32) pl.kw = 4;       // (32|64) x 32: wave-split K
+  else if (pl.BD == 32 && pl.BG == 64) pl.kw = 4;
+  pl.tiles_c = (NC + pl.BG - 1) / pl.BG;
+  pl.tiles_d = (Cd + pl.BD - 1) / pl.BD;
+  long tiles = (long)pl.tiles_c * pl.tiles_d;
+  long want = (1024 + tiles - 1) / tiles;          // ~4 blocks per CU in total
+  long maxsplit = (M + 255) / 256;                 // at least 256 pixels per split
+  if (maxsplit < 1) maxsplit = 1;
+  long ns = want < maxsplit ? want : maxsplit;
+  if (ns < 1) ns = 1;
+  if (ns > 512) ns = 512;
+  long chunk = (M + ns - 1) / ns;
+  chunk = (chunk + WBK - 1) / WBK * WBK;
+  ns = (M + chunk - 1) / chunk;
+  if (ns < 1) ns = 1;
+  pl.nsplit = (int)ns;
+  pl.chunk = chunk;
+  return pl;
+}
+
+template <int BD, int BG, int TM, int TN, int WN, int KW, bool SD, bool SG>
+static int launch_wgrad_variant(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+  auto kern = wgrad_kernel<BD, BG, TM, TN, WN, KW, SD, SG>;
+  constexpr int smem = 2 * WBK * (BD + BG) * (int)sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      set_error("wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid((unsigned)pl.tiles_c, (unsigned)pl.tiles_d, (unsigned)pl.nsplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+  return check_launch("wgrad");
+}
+
+template <bool SD, bool SG>
+static int dispatch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+  if (pl.BD == 128 && pl.BG == 128) return launch_wgrad_variant<128, 128, 2, 2, 2, 1, SD, SG>(p, pl, st);
+  if (pl.BD == 128 && pl.BG == 64) return launch_wgrad_variant<128, 64, 1, 2, 1, 1, SD, SG>(p, pl, st);
+  if (pl.BD == 128 && pl.BG == 32) return launch_wgrad_variant<128, 32, 1, 1, 1, 1, SD, SG>(p, pl, st);
+  if (pl.BD == 64 && pl.BG == 128) return launch_wgrad_variant<64, 128, 2, 1, 4, 1, SD, SG>(p, pl, st);
+  if (pl.BD == 64 && pl.BG == 64) return launch_wgrad_variant<64, 64, 1, 1, 2, 1, SD, SG>(p, pl, st);
+  if (pl.BD == 64 && pl.BG == 32) return launch_wgrad_variant<64, 32, 2, 1, 1, 4, SD, SG>(p, pl, st);
+  if (pl.BD == 32 && pl.BG == 128) return launch_wgrad_variant<32, 128, 1, 1, 4, 1, SD, SG>(p, pl, st);
+  if (pl.BD == 32 && pl.BG == 64) return launch_wgrad_variant<32, 64, 1, 2, 1, 4, SD, SG>(p, pl, st);
+  return launch_wgrad_variant<32, 32, 1, 1, 1, 4, SD, SG>(p, pl, st);
+}
+
+}  // namespace mpgan
+
+using namespace mpgan;
+
+static void wgrad_dims(const mpgan_conv_geom* g, int& Cd, int& Cg, int& T, long& M) {
+  T = g->k[0] * g->k[1] * g->k[2];
+  if (!g->transposed) {
+    Cd = g->cout; Cg = g->cin;
+    M = (long)g->n * g->out_dhw[0] * g->out_dhw[1] * g->out_dhw[2];
+  } else {
+    Cd = g->cin; Cg = g->cout;
+    M = (long)g->n * g->in_dhw[0] * g->in_dhw[1] * g->in_dhw[2];
+  }
+}
+
+extern "C" int64_t mpgan_conv_wgrad_workspace(const mpgan_conv_geom* g) {
+  if (!g) return -1;
+  int Cd, Cg, T;
+  long M;
+  wgrad_dims(g, Cd, Cg, T, M);
+  WgradPlan pl = plan_wgrad(Cd, T * Cg, M);
+  return (int64_t)pl.nsplit * pl.kw * Cd * T * Cg * (int64_t)sizeof(float);
+}
+
+extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float* x, int32_t ldx,
+                                          const mpgan_prologue* pro, const float* dy, int32_t lddy, float* dw,
+                                          float beta, void* workspace, int64_t workspace_bytes, void* stream) {
+  MPGAN_CHECK_ARG(g && x && dy && dw && workspace, "conv_backward_weight: null pointer");
+  MPGAN_CHECK_ARG(ldx >= g->cin && lddy >= g->cout, "conv_backward_weight: bad pitch");
+  int Cd, Cg, T;
+  long M;
+  wgrad_dims(g, Cd, Cg, T, M);
+  WgradPlan pl = plan_wgrad(Cd, T * Cg, M);
+  const int64_t need = (int64_t)pl.nsplit * pl.kw * Cd * T * Cg * (int64_t)sizeof(float);
+  MPGAN_CHECK_ARG(workspace_bytes >= need, "conv_backward_weight: workspace %lld < %lld bytes",
+                  (long long)workspace_bytes, (long long)need);
+  WgradParams p{};
+  p.partial = static_cast<float*>(workspace);
+  p.Kz = g->k[0]; p.Ky = g->k[1]; p.Kx = g->k[2];
+  p.sz = g->stride[0]; p.sy = g->stride[1]; p.sx = g->stride[2];
+  p.pz = g->pad[0]; p.py = g->pad[1]; p.px = g->pad[2];
+  p.N = g->n;
+  p.nsplit = pl.nsplit; p.chunk = pl.chunk;
+  if (!g->transposed) {
+    p.dense = dy; p.ldd = lddy; p.Cd = g->cout;
+    p.gath = x; p.ldg = ldx; p.Cg = g->cin;
+    p.pro = make_pro(pro);
+    p.Mz = g->out_dhw[0]; p.My = g->out_dhw[1]; p.Mx = g->out_dhw[2];
+    p.Gz = g->in_dhw[0]; p.Gy = g->in_dhw[1]; p.Gx = g->in_dhw[2];
+  } else {
+    MPGAN_UNSUPPORTED(pro && pro->scale, "conv_backward_weight: prologue on a transposed conv input");
+    p.dense = x; p.ldd = ldx; p.Cd = g->cin;
+    p.gath = dy; p.ldg = lddy; p.Cg = g->cout;
+    p.pro = make_pro(nullptr);
+    p.Mz = g->in_dhw[0]; p.My = g->in_dhw[1]; p.Mx = g->in_dhw[2];
+    p.Gz = g->out_dhw[0]; p.Gy = g->out_dhw[1]; p.Gx = g->out_dhw[2];
+  }
+  const bool vd = (p.Cd % 4 == 0) && (p.ldd % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.dense) & 15) == 0);
+  const bool vg = (p.Cg % 4 == 0) && (p.ldg % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.gath) & 15) == 0) &&
+                  (!p.pro.scale || (((reinterpret_cast<uintptr_t>(p.pro.scale) |
+                                      reinterpret_cast<uintptr_t>(p.pro.shift)) & 15) == 0 &&
+                                    p.pro.n_stride % 4 == 0));
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (vd && vg) rc = dispatch_wgrad<false, false>(p, pl, st);
+  else if (vd) rc = dispatch_wgrad<false, true>(p, pl, st);
+  else if (vg) rc = dispatch_wgrad<true, false>(p, pl, st);
+  else rc = dispatch_wgrad<true, true>(p, pl, st);
+  if (rc) return rc;
+  const long total = (long)Cd * Cg * T;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, pl.nsplit * pl.kw, Cd, Cg, T, beta);
+  return check_launch("wgrad_reduce");
+}

@@ -1,0 +1,74 @@
+// Shared host/device helpers for libmpgan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "mpgan_hip.h"
+
+namespace mpgan {
+
+void set_error(const char* fmt, ...);
+
+#define MPGAN_CHECK_ARG(cond, ...)                         \
+  do {                                                     \
+    if (!(cond)) {                                         \
+      ::mpgan::set_error(__VA_ARGS__);                     \
+      return MPGAN_ERR_INVALID;                            \
+    }                                                      \
+  } while (0)
+
+#define MPGAN_UNSUPPORTED(cond, ...)                       \
+  do {                                                     \
+    if (cond) {                                            \
+      ::mpgan::set_error(__VA_ARGS__);                     \
+      return MPGAN_ERR_UNSUPPORTED;                        \
+    }                                                      \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return MPGAN_ERR_HIP;
+  }
+  return MPGAN_OK;
+}
+
+// Device view of the optional normalise+activate prologue.
+struct Pro {
+  const float* scale;
+  const float* shift;
+  const float* slope_ptr;
+  float slope;
+  int n_stride;
+  int act;
+};
+
+inline Pro make_pro(const mpgan_prologue* p) {
+  Pro r;
+  if (p == nullptr || p->scale == nullptr) {
+    r.scale = nullptr; r.shift = nullptr; r.slope_ptr = nullptr;
+    r.slope = 1.f; r.n_stride = 0; r.act = MPGAN_ACT_NONE;
+  } else {
+    r.scale = p->scale; r.shift = p->shift; r.slope_ptr = p->slope_ptr;
+    r.slope = p->slope; r.n_stride = p->n_stride; r.act = p->act;
+  }
+  return r;
+}
+
+__device__ __forceinline__ float pro_slope(const Pro& p) {
+  return p.slope_ptr ? __builtin_nontemporal_load(p.slope_ptr) : p.slope;
+}
+
+__device__ __forceinline__ float act_apply(float y, int act, float slope) {
+  return (act == MPGAN_ACT_LEAKY && y < 0.f) ? y * slope : y;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+}  // namespace mpgan

@@ -1,0 +1,450 @@
+// BatchNorm (training mode) / InstanceNorm statistics, fused norm+activation
+// apply and their backward -- the HBM-bound half of the GAN step.
+//
+// All kernels stream channels-last rows (pitch ld) with 16-byte accesses when
+// C % 4 == 0, reduce over pixels per thread, then across the block through LDS
+// in a FIXED order, and leave one partial row per (sample, chunk); a tiny
+// finalize kernel combines partials in double precision.  No atomics anywhere,
+// so statistics (and therefore the whole forward) are bitwise reproducible.
+#include "mpgan_common.h"
+
+namespace mpgan {
+
+static inline int stats_chunks_host(long pixels_per_sample) {
+  long c = pixels_per_sample / 1024;
+  if (c < 1) c = 1;
+  if (c > 256) c = 256;
+  return (int)c;
+}
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+  using T = float4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <>
+struct Vec<1> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = *p; }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+
+// ---------------------------------------------------------------------------
+// Generic per-channel partial reduction over pixel chunks.
+// NQ quantities per element produced by functor F(n, c, pixel-row pointers...).
+// grid = (chunks, n); block = 256 threads laid out as R rows x CG column groups.
+// ---------------------------------------------------------------------------
+struct ReduceGeom {
+  int C, CG, R;           // channels, column groups (C/V), rows per pass
+  long P;                 // pixels per sample
+  int chunks;
+};
+
+template <int V, int NQ, class F>
+__device__ __forceinline__ void chunk_reduce(const ReduceGeom& g, float* partials, F f) {
+  extern __shared__ float red[];  // [R][NQ][C]
+  const int tid = threadIdx.x;
+  const int q = tid % g.CG, r = tid / g.CG;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const long per = (g.P + g.chunks - 1) / g.chunks;
+  const long beg = (long)chunk * per;
+  const long end = beg + per < g.P ? beg + per : g.P;
+  float acc[NQ][V];
+#pragma unroll
+  for (int a = 0; a < NQ; ++a)
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[a][e] = 0.f;
+  if (r < g.R) {
+    for (long pix = beg + r; pix < end; pix += g.R) f(n, q * V, (long)n * g.P + pix, acc);
+#pragma unroll
+    for (int a = 0; a < NQ; ++a)
+#pragma unroll
+      for (int e = 0; e < V; ++e) red[(r * NQ + a) * g.C + q * V + e] = acc[a][e];
+  }
+  __syncthreads();
+  // fixed-order sum over the R rows
+  float* out = partials + ((long)n * g.chunks + chunk) * NQ * g.C;
+  for (int i = tid; i < NQ * g.C; i += blockDim.x) {
+    float s = 0.f;
+    for (int rr = 0; rr < g.R; ++rr) s += red[rr * NQ * g.C + i];
+    out[i] = s;
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ z, int ldz, ReduceGeom g,
+                                                            float* __restrict__ partials) {
+  chunk_reduce<V, 2>(g, partials, [&](int, int c, long row, float (&acc)[2][V]) {
+    float v[V];
+    Vec<V>::load(z + row * ldz + c, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      acc[0][e] += v[e];
+      acc[1][e] += v[e] * v[e];
+    }
+  });
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ gr, int ldg,
+                                                              const float* __restrict__ z, int ldz, Pro p,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, ReduceGeom g,
+                                                              float* __restrict__ partials) {
+  const float slope = pro_slope(p);
+  chunk_reduce<V, 3>(g, partials, [&](int n, int c, long row, float (&acc)[3][V]) {
+    float zv[V], gv[V];
+    Vec<V>::load(z + row * ldz + c, zv);
+    Vec<V>::load(gr + row * ldg + c, gv);
+    const int si = n * p.n_stride + c;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float y = zv[e] * p.scale[si + e] + p.shift[si + e];
+      const float zh = (zv[e] - mean[si + e]) * invstd[si + e];
+      const bool neg = (p.act == MPGAN_ACT_LEAKY) && y < 0.f;
+      const float gy = neg ? gv[e] * slope : gv[e];
+      acc[0][e] += gy;
+      acc[1][e] += gy * zh;
+      acc[2][e] += neg ? gv[e] * y : 0.f;
+    }
+  });
+}
+
+__global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ partials, int N, int chunks,
+                                                            int C, long P, int instance,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, float momentum,
+                                                            float* running_mean, float* running_var,
+                                                            int64_t* nbt, float* __restrict__ scale,
+                                                            float* __restrict__ shift, float* __restrict__ mean,
+                                                            float* __restrict__ invstd) {
+  const int total = instance ? N * C : C;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && nbt) *nbt += 1;
+  if (i >= total) return;
+  const int c = instance ? i % C : i;
+  const int nb = instance ? i / C : 0, ne = instance ? nb + 1 : N;
+  double s = 0.0, ss = 0.0;
+  for (int n = nb; n < ne; ++n)
+    for (int k = 0; k < chunks; ++k) {
+      const float* row = partials + ((long)n * chunks + k) * 2 * C;
+      s += (double)row[c];
+      ss += (double)row[C + c];
+    }
+  const double cnt = (double)P * (ne - nb);
+  const double m = s / cnt;
+  double var = ss / cnt - m * m;
+  if (var < 0.0) var = 0.0;
+  const float istd = (float)(1.0 / sqrt(var + (double)eps));
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const float sc = ga * istd;
+  scale[i] = sc;
+  shift[i] = be - (float)m * sc;
+  mean[i] = (float)m;
+  invstd[i] = istd;
+  if (running_mean && !instance) {
+    const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// one block; thread-strided over channels; deterministic
+__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __restrict__ partials, int N, int chunks,
+                                                                int C, long P, int instance, float* dgamma,
+                                                                float* dbeta, float* dslope, float* __restrict__ c1,
+                                                                float* __restrict__ c2) {
+  __shared__ double sred[256];
+  double slope_acc = 0.0;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    for (int n = 0; n < N; ++n) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < chunks; ++k) {
+        const float* row = partials + ((long)n * chunks + k) * 3 * C;
+        s1 += (double)row[c];
+        s2 += (double)row[C + c];
+        t3 += (double)row[2 * C + c];
+      }
+      t1 += s1;
+      t2 += s2;
+      if (instance) {
+        c1[n * C + c] = (float)(s1 / (double)P);
+        c2[n * C + c] = (float)(s2 / (double)P);
+      }
+    }
+    if (!instance) {
+      const double cnt = (double)P * N;
+      c1[c] = (float)(t1 / cnt);
+      c2[c] = (float)(t2 / cnt);
+    }
+    if (dgamma) dgamma[c] += (float)t2;
+    if (dbeta) dbeta[c] += (float)t1;
+    slope_acc += t3;
+  }
+  sred[threadIdx.x] = slope_acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && dslope) {
+    double s = 0.0;
+    for (int i = 0; i < (int)blockDim.x; ++i) s += sred[i];
+    *dslope += (float)s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// element-wise kernels: grid-stride over (pixel rows x column groups)
+// ---------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void norm_act_add_kernel(const float* __restrict__ z, int ldz, Pro pz,
+                                                           const float* __restrict__ r, int ldr, Pro pr, long rows,
+                                                           long P, int C, int tanh_out, float* __restrict__ out,
+                                                           int ldo) {
+  const int CG = C / V;
+  const long total = rows * CG;
+  const float sz = pro_slope(pz), sr = pro_slope(pr);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / CG;
+    const int c = (int)(i - row * CG) * V;
+    const int n = (int)(row / P);
+    float v[V], o[V];
+    Vec<V>::load(z + row * ldz + c, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float y = v[e];
+      if (pz.scale) {
+        const int si = n * pz.n_stride + c + e;
+        y = act_apply(y * pz.scale[si] + pz.shift[si], pz.act, sz);
+      }
+      o[e] = y;
+    }
+    if (r) {
+      float rv[V];
+      Vec<V>::load(r + row * ldr + c, rv);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        float y = rv[e];
+        if (pr.scale) {
+          const int si = n * pr.n_stride + c + e;
+          y = act_apply(y * pr.scale[si] + pr.shift[si], pr.act, sr);
+        }
+        o[e] += y;
+      }
+    }
+    if (tanh_out) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] = tanhf(o[e]);
+    }
+    Vec<V>::store(out + row * ldo + c, o);
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ gr, int ldg,
+                                                             const float* __restrict__ z, int ldz, Pro p,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ c1,
+                                                             const float* __restrict__ c2, long rows, long P, int C,
+                                                             float* __restrict__ dz, int lddz) {
+  const int CG = C / V;
+  const long total = rows * CG;
+  const float slope = pro_slope(p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / CG;
+    const int c = (int)(i - row * CG) * V;
+    const int n = (int)(row / P);
+    const int si = n * p.n_stride + c;
+    float zv[V], gv[V], o[V];
+    Vec<V>::load(z + row * ldz + c, zv);
+    Vec<V>::load(gr + row * ldg + c, gv);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float y = zv[e] * p.scale[si + e] + p.shift[si + e];
+      const float zh = (zv[e] - mean[si + e]) * invstd[si + e];
+      const float gy = ((p.act == MPGAN_ACT_LEAKY) && y < 0.f) ? gv[e] * slope : gv[e];
+      o[e] = p.scale[si + e] * (gy - c1[si + e] - zh * c2[si + e]);
+    }
+    Vec<V>::store(dz + row * lddz + c, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int rows,
+                                                              int row_stride, int C, float* __restrict__ out,
+                                                              float beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)partials[(long)r * row_stride + c];
+  out[c] = beta != 0.f ? beta * out[c] + (float)s : (float)s;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void copy_slice_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst,
+                                                         int ldd, long rows, int C, int accumulate) {
+  const int CG = C / V;
+  const long total = rows * CG;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / CG;
+    const int c = (int)(i - row * CG) * V;
+    float v[V];
+    Vec<V>::load(src + row * lds_ + c, v);
+    if (accumulate) {
+      float d[V];
+      Vec<V>::load(dst + row * ldd + c, d);
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] += d[e];
+    }
+    Vec<V>::store(dst + row * ldd + c, v);
+  }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int make_reduce_geom(ReduceGeom& g, int C, long P, bool vec, const char* what) {
+  const int V = vec ? 4 : 1;
+  g.C = C;
+  g.CG = C / V;
+  MPGAN_UNSUPPORTED(g.CG > 256, "%s: C=%d too wide", what, C);
+  g.R = 256 / g.CG;
+  g.P = P;
+  g.chunks = stats_chunks_host(P);
+  return MPGAN_OK;
+}
+
+static inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace mpgan
+
+using namespace mpgan;
+
+extern "C" int32_t mpgan_stats_chunks(int64_t pixels_per_sample, int32_t) { return stats_chunks_host(pixels_per_sample); }
+
+extern "C" int mpgan_channel_stats(const float* z, int32_t ldz, int32_t n, int64_t P, int32_t c, float* partials,
+                                   void* stream) {
+  MPGAN_CHECK_ARG(z && partials && n > 0 && P > 0 && c > 0 && ldz >= c, "channel_stats: bad argument");
+  const bool vec = (c % 4 == 0) && (ldz % 4 == 0) && aligned16(z);
+  ReduceGeom g;
+  int rc = make_reduce_geom(g, c, P, vec, "channel_stats");
+  if (rc) return rc;
+  dim3 grid(g.chunks, n);
+  const size_t smem = (size_t)g.R * 2 * c * sizeof(float);
+  if (vec)
+    hipLaunchKernelGGL(channel_stats_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, z, ldz, g, partials);
+  else
+    hipLaunchKernelGGL(channel_stats_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, z, ldz, g, partials);
+  return check_launch("channel_stats");
+}
+
+extern "C" int mpgan_norm_finalize(const float* partials, int32_t n, int32_t chunks, int32_t c, int64_t P,
+                                   int32_t instance, const float* gamma, const float* beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, int64_t* nbt,
+                                   float* scale, float* shift, float* mean, float* invstd, void* stream) {
+  MPGAN_CHECK_ARG(partials && scale && shift && mean && invstd && n > 0 && c > 0 && chunks > 0,
+                  "norm_finalize: bad argument");
+  const int total = instance ? n * c : c;
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, n,
+                     chunks, c, (long)P, instance, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale,
+                     shift, mean, invstd);
+  return check_launch("norm_finalize");
+}
+
+extern "C" int mpgan_norm_act_add(const float* z, int32_t ldz, const mpgan_prologue* pz, const float* r, int32_t ldr,
+                                  const mpgan_prologue* pr, int32_t n, int64_t P, int32_t c, int32_t tanh_out,
+                                  float* out, int32_t ldo, void* stream) {
+  MPGAN_CHECK_ARG(z && out && n > 0 && P > 0 && c > 0 && ldz >= c && ldo >= c && (!r || ldr >= c),
+                  "norm_act_add: bad argument");
+  const bool vec = (c % 4 == 0) && (ldz % 4 == 0) && (ldo % 4 == 0) && aligned16(z) && aligned16(out) &&
+                   (!r || ((ldr % 4 == 0) && aligned16(r)));
+  const long rows = (long)n * P;
+  Pro a = make_pro(pz), b = make_pro(pr);
+  if (vec)
+    hipLaunchKernelGGL(norm_act_add_kernel<4>, dim3(ew_blocks(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream, z,
+                       ldz, a, r, ldr, b, rows, (long)P, c, tanh_out, out, ldo);
+  else
+    hipLaunchKernelGGL(norm_act_add_kernel<1>, dim3(ew_blocks(rows * c)), dim3(256), 0, (hipStream_t)stream, z, ldz, a,
+                       r, ldr, b, rows, (long)P, c, tanh_out, out, ldo);
+  return check_launch("norm_act_add");
+}
+
+extern "C" int mpgan_norm_bwd_reduce(const float* g, int32_t ldg, const float* z, int32_t ldz,
+                                     const mpgan_prologue* p, const float* mean, const float* invstd, int32_t n,
+                                     int64_t P, int32_t c, float* partials, void* stream) {
+  MPGAN_CHECK_ARG(g && z && p && p->scale && mean && invstd && partials && n > 0 && P > 0 && c > 0 && ldg >= c &&
+                      ldz >= c,
+                  "norm_bwd_reduce: bad argument");
+  const bool vec = (c % 4 == 0) && (ldz % 4 == 0) && (ldg % 4 == 0) && aligned16(z) && aligned16(g);
+  ReduceGeom geo;
+  int rc = make_reduce_geom(geo, c, P, vec, "norm_bwd_reduce");
+  if (rc) return rc;
+  dim3 grid(geo.chunks, n);
+  const size_t smem = (size_t)geo.R * 3 * c * sizeof(float);
+  Pro pp = make_pro(p);
+  if (vec)
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, g, ldg, z, ldz, pp, mean,
+                       invstd, geo, partials);
+  else
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, g, ldg, z, ldz, pp, mean,
+                       invstd, geo, partials);
+  return check_launch("norm_bwd_reduce");
+}
+
+extern "C" int mpgan_norm_bwd_finalize(const float* partials, int32_t n, int32_t chunks, int32_t c, int64_t P,
+                                       int32_t instance, float* dgamma, float* dbeta, float* dslope, float* c1,
+                                       float* c2, void* stream) {
+  MPGAN_CHECK_ARG(partials && c1 && c2 && n > 0 && c > 0 && chunks > 0, "norm_bwd_finalize: bad argument");
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n, chunks, c,
+                     (long)P, instance, dgamma, dbeta, dslope, c1, c2);
+  return check_launch("norm_bwd_finalize");
+}
+
+extern "C" int mpgan_norm_bwd_apply(const float* g, int32_t ldg, const float* z, int32_t ldz, const mpgan_prologue* p,
+                                    const float* mean, const float* invstd, const float* c1, const float* c2,
+                                    int32_t n, int64_t P, int32_t c, float* dz, int32_t lddz, void* stream) {
+  MPGAN_CHECK_ARG(g && z && p && p->scale && mean && invstd && c1 && c2 && dz && n > 0 && P > 0 && c > 0 &&
+                      ldg >= c && ldz >= c && lddz >= c,
+                  "norm_bwd_apply: bad argument");
+  const bool vec = (c % 4 == 0) && (ldz % 4 == 0) && (ldg % 4 == 0) && (lddz % 4 == 0) && aligned16(z) &&
+                   aligned16(g) && aligned16(dz);
+  const long rows = (long)n * P;
+  Pro pp = make_pro(p);
+  if (vec)
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<4>, dim3(ew_blocks(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream, g,
+                       ldg, z, ldz, pp, mean, invstd, c1, c2, rows, (long)P, c, dz, lddz);
+  else
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, dim3(ew_blocks(rows * c)), dim3(256), 0, (hipStream_t)stream, g, ldg,
+                       z, ldz, pp, mean, invstd, c1, c2, rows, (long)P, c, dz, lddz);
+  return check_launch("norm_bwd_apply");
+}
+
+extern "C" int mpgan_reduce_partials(const float* partials, int32_t rows, int32_t row_stride, int32_t c, float* out,
+                                     float beta, void* stream) {
+  MPGAN_CHECK_ARG(partials && out && rows > 0 && c > 0 && row_stride >= c, "reduce_partials: bad argument");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, rows,
+                     row_stride, c, out, beta);
+  return check_launch("reduce_partials");
+}
+
+extern "C" int mpgan_copy_slice(const float* src, int32_t lds_, float* dst, int32_t ldd, int64_t pixels, int32_t c,
+                                int32_t accumulate, void* stream) {
+  MPGAN_CHECK_ARG(src && dst && pixels > 0 && c > 0 && lds_ >= c && ldd >= c, "copy_slice: bad argument");
+  const bool vec = (c % 4 == 0) && (lds_ % 4 == 0) && (ldd % 4 == 0) && aligned16(src) && aligned16(dst);
+  if (vec)
+    hipLaunchKernelGGL(copy_slice_kernel<4>, dim3(ew_blocks(pixels * (c / 4))), dim3(256), 0, (hipStream_t)stream, src,
+                       lds_, dst, ldd, (long)pixels, c, accumulate);
+  else
+    hipLaunchKernelGGL(copy_slice_kernel<1>, dim3(ew_blocks(pixels * c)), dim3(256), 0, (hipStream_t)stream, src, lds_,
+                       dst, ldd, (long)pixels, c, accumulate);
+  return check_launch("copy_slice");
+}

@@ -1,0 +1,366 @@
+"""Thin Python wrappers over the C ABI: shape/pitch checks on the host, raw
+device pointers and the current torch stream into the HIP library.
+
+Activations are channels-last tensors of shape (N, D, H, W, C) whose last
+dimension may be a slice of a wider buffer (pitch = stride of W).  Nothing in
+here computes: every function ends in exactly one C call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import ConvGeomC, PrologueC, check, lib
+
+ACT_NONE = 0
+ACT_LEAKY = 1
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _cl(t: torch.Tensor, what: str) -> Tuple[int, int, int]:
+    """Validate a channels-last (N,D,H,W,C) view; return (n, pixels/sample, ld)."""
+    if t.dim() != 5 or t.dtype != torch.float32 or not t.is_cuda:
+        raise ValueError(f"{what}: need a CUDA float32 (N,D,H,W,C) tensor, got {tuple(t.shape)} {t.dtype} {t.device}")
+    n, d, h, w, c = t.shape
+    st = t.stride()
+    # pitch from the innermost dimension that actually has extent (size-1 dims carry arbitrary strides)
+    if w > 1:
+        ld = st[3]
+    elif h > 1:
+        ld = st[2]
+    elif d > 1:
+        ld = st[1]
+    elif n > 1:
+        ld = st[0]
+    else:
+        ld = c
+    want = (d * h * w * ld, h * w * ld, w * ld, ld, 1)
+    ok = ld >= c and all(sz == 1 or a == b for sz, a, b in zip(t.shape, st, want))
+    if not ok:
+        raise ValueError(f"{what}: not a pixel-contiguous channels-last view: shape {tuple(t.shape)} strides {st}")
+    return n, d * h * w, ld
+
+
+@dataclass(frozen=True)
+class ConvGeom:
+    """Geometry of one nn.ConvNd / nn.ConvTransposeNd (depth dim unused in 2-D)."""
+    n: int
+    in_dhw: Tuple[int, int, int]
+    cin: int
+    cout: int
+    k: Tuple[int, int, int]
+    stride: Tuple[int, int, int]
+    pad: Tuple[int, int, int]
+    transposed: bool = False
+    out_pad: Tuple[int, int, int] = (0, 0, 0)
+
+    @property
+    def out_dhw(self) -> Tuple[int, int, int]:
+        if not self.transposed:
+            return tuple((i + 2 * p - k) // s + 1 for i, p, k, s in zip(self.in_dhw, self.pad, self.k, self.stride))
+        return tuple((i - 1) * s - 2 * p + k + op
+                     for i, p, k, s, op in zip(self.in_dhw, self.pad, self.k, self.stride, self.out_pad))
+
+    @property
+    def taps(self) -> int:
+        return self.k[0] * self.k[1] * self.k[2]
+
+    def c(self) -> ConvGeomC:
+        g = ConvGeomC()
+        g.n = self.n
+        g.in_dhw[:] = self.in_dhw
+        g.out_dhw[:] = self.out_dhw
+        g.cin, g.cout = self.cin, self.cout
+        g.k[:] = self.k
+        g.stride[:] = self.stride
+        g.pad[:] = self.pad
+        g.transposed = 1 if self.transposed else 0
+        return g
+
+    def with_n(self, n: int) -> "ConvGeom":
+        return ConvGeom(n, self.in_dhw, self.cin, self.cout, self.k, self.stride, self.pad, self.transposed,
+                        self.out_pad)
+
+
+@dataclass
+class Prologue:
+    """a = act(z*scale + shift) applied on load (norm + PReLU/LeakyReLU of the producer)."""
+    scale: torch.Tensor
+    shift: torch.Tensor
+    n_stride: int = 0
+    act: int = ACT_NONE
+    slope: float = 1.0
+    slope_t: Optional[torch.Tensor] = None  # device scalar (PReLU alpha)
+
+    def c(self) -> PrologueC:
+        p = PrologueC()
+        p.scale = self.scale.data_ptr()
+        p.shift = self.shift.data_ptr()
+        p.n_stride = self.n_stride
+        p.act = self.act
+        p.slope = self.slope
+        p.slope_ptr = None if self.slope_t is None else self.slope_t.data_ptr()
+        return p
+
+
+def _pro(p: Optional[Prologue]):
+    return None if p is None else C.byref(p.c())
+
+
+def _check_in_out(g: ConvGeom, x: torch.Tensor, y: torch.Tensor, what: str):
+    if tuple(x.shape) != (g.n, *g.in_dhw, g.cin):
+        raise ValueError(f"{what}: input shape {tuple(x.shape)} != {(g.n, *g.in_dhw, g.cin)}")
+    if tuple(y.shape) != (g.n, *g.out_dhw, g.cout):
+        raise ValueError(f"{what}: output shape {tuple(y.shape)} != {(g.n, *g.out_dhw, g.cout)}")
+
+
+def conv_forward(g: ConvGeom, x, w_packed, bias, y, *, pro: Optional[Prologue] = None, resid=None,
+                 tanh_out: bool = False):
+    _check_in_out(g, x, y, "conv_forward")
+    _, _, ldx = _cl(x, "conv_forward x")
+    _, _, ldy = _cl(y, "conv_forward y")
+    ldr = 0
+    if resid is not None:
+        if resid.shape != y.shape:
+            raise ValueError("conv_forward: resid shape mismatch")
+        _, _, ldr = _cl(resid, "conv_forward resid")
+    if w_packed.numel() < g.cout * g.cin * g.taps:
+        raise ValueError("conv_forward: packed weight too small")
+    gc = g.c()
+    check(lib().mpgan_conv_forward(C.byref(gc), x.data_ptr(), ldx, w_packed.data_ptr(), _ptr(bias), _pro(pro),
+                                   _ptr(resid), ldr, int(tanh_out), y.data_ptr(), ldy, _stream()), "conv_forward")
+    return y
+
+
+def conv_backward_data(g: ConvGeom, dy, w_packed_bwd, dx, *, resid=None):
+    _check_in_out(g, dx, dy, "conv_backward_data")
+    _, _, lddy = _cl(dy, "conv_backward_data dy")
+    _, _, lddx = _cl(dx, "conv_backward_data dx")
+    ldr = 0
+    if resid is not None:
+        if resid.shape != dx.shape:
+            raise ValueError("conv_backward_data: resid shape mismatch")
+        _, _, ldr = _cl(resid, "conv_backward_data resid")
+    gc = g.c()
+    check(lib().mpgan_conv_backward_data(C.byref(gc), dy.data_ptr(), lddy, w_packed_bwd.data_ptr(), _ptr(resid), ldr,
+                                         dx.data_ptr(), lddx, _stream()), "conv_backward_data")
+    return dx
+
+
+def conv_wgrad_workspace(g: ConvGeom) -> int:
+    gc = g.c()
+    return int(lib().mpgan_conv_wgrad_workspace(C.byref(gc)))
+
+
+def conv_backward_weight(g: ConvGeom, x, dy, dw, workspace, *, pro: Optional[Prologue] = None, beta: float = 0.0):
+    _check_in_out(g, x, dy, "conv_backward_weight")
+    _, _, ldx = _cl(x, "conv_backward_weight x")
+    _, _, lddy = _cl(dy, "conv_backward_weight dy")
+    if dw.numel() != g.cout * g.cin * g.taps or not dw.is_contiguous():
+        raise ValueError("conv_backward_weight: dw must be the contiguous torch-layout weight gradient")
+    gc = g.c()
+    check(lib().mpgan_conv_backward_weight(C.byref(gc), x.data_ptr(), ldx, _pro(pro), dy.data_ptr(), lddy,
+                                           dw.data_ptr(), float(beta), workspace.data_ptr(),
+                                           workspace.numel() * workspace.element_size(), _stream()),
+          "conv_backward_weight")
+    return dw
+
+
+def pack_weights(flat_params, packed, table, n_entries: int, max_elems: int):
+    check(lib().mpgan_pack_weights(flat_params.data_ptr(), packed.data_ptr(), table.data_ptr(), n_entries, max_elems,
+                                   _stream()), "pack_weights")
+
+
+def stats_chunks(pixels_per_sample: int, c: int) -> int:
+    return int(lib().mpgan_stats_chunks(pixels_per_sample, c))
+
+
+def channel_stats(z, partials):
+    n, P, ld = _cl(z, "channel_stats")
+    c = z.shape[-1]
+    if partials.numel() < n * stats_chunks(P, c) * 2 * c:
+        raise ValueError("channel_stats: partials too small")
+    check(lib().mpgan_channel_stats(z.data_ptr(), ld, n, P, c, partials.data_ptr(), _stream()), "channel_stats")
+
+
+def norm_finalize(partials, n, chunks, c, P, instance, gamma, beta, eps, momentum, running_mean, running_var, nbt,
+                  scale, shift, mean, invstd):
+    check(lib().mpgan_norm_finalize(partials.data_ptr(), n, chunks, c, P, int(instance), _ptr(gamma), _ptr(beta),
+                                    float(eps), float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                    scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                    _stream()), "norm_finalize")
+
+
+def norm_act_add(z, pz: Optional[Prologue], r, pr: Optional[Prologue], out, *, tanh_out=False):
+    n, P, ldz = _cl(z, "norm_act_add z")
+    _, _, ldo = _cl(out, "norm_act_add out")
+    ldr = 0
+    if r is not None:
+        _, _, ldr = _cl(r, "norm_act_add r")
+        if r.shape != z.shape:
+            raise ValueError("norm_act_add: r shape mismatch")
+    if out.shape != z.shape:
+        raise ValueError("norm_act_add: out shape mismatch")
+    check(lib().mpgan_norm_act_add(z.data_ptr(), ldz, _pro(pz), _ptr(r), ldr, _pro(pr), n, P, z.shape[-1],
+                                   int(tanh_out), out.data_ptr(), ldo, _stream()), "norm_act_add")
+    return out
+
+
+def norm_bwd_reduce(g, z, p: Prologue, mean, invstd, partials):
+    n, P, ldz = _cl(z, "norm_bwd_reduce z")
+    _, _, ldg = _cl(g, "norm_bwd_reduce g")
+    if g.shape != z.shape:
+        raise ValueError("norm_bwd_reduce: shape mismatch")
+    c = z.shape[-1]
+    if partials.numel() < n * stats_chunks(P, c) * 3 * c:
+        raise ValueError("norm_bwd_reduce: partials too small")
+    check(lib().mpgan_norm_bwd_reduce(g.data_ptr(), ldg, z.data_ptr(), ldz, _pro(p), mean.data_ptr(),
+                                      invstd.data_ptr(), n, P, c, partials.data_ptr(), _stream()), "norm_bwd_reduce")
+
+
+def norm_bwd_finalize(partials, n, chunks, c, P, instance, dgamma, dbeta, dslope, c1, c2):
+    check(lib().mpgan_norm_bwd_finalize(partials.data_ptr(), n, chunks, c, P, int(instance), _ptr(dgamma), _ptr(dbeta),
+                                        _ptr(dslope), c1.data_ptr(), c2.data_ptr(), _stream()), "norm_bwd_finalize")
+
+
+def norm_bwd_apply(g, z, p: Prologue, mean, invstd, c1, c2, dz):
+    n, P, ldz = _cl(z, "norm_bwd_apply z")
+    _, _, ldg = _cl(g, "norm_bwd_apply g")
+    _, _, lddz = _cl(dz, "norm_bwd_apply dz")
+    if g.shape != z.shape or dz.shape != z.shape:
+        raise ValueError("norm_bwd_apply: shape mismatch")
+    check(lib().mpgan_norm_bwd_apply(g.data_ptr(), ldg, z.data_ptr(), ldz, _pro(p), mean.data_ptr(),
+                                     invstd.data_ptr(), c1.data_ptr(), c2.data_ptr(), n, P, z.shape[-1],
+                                     dz.data_ptr(), lddz, _stream()), "norm_bwd_apply")
+    return dz
+
+
+def reduce_partials(partials, rows, row_stride, c, out, beta=0.0):
+    check(lib().mpgan_reduce_partials(partials.data_ptr(), rows, row_stride, c, out.data_ptr(), float(beta),
+                                      _stream()), "reduce_partials")
+
+
+def add_tanh(a, b, y, apply_tanh: bool):
+    check(lib().mpgan_add_tanh(a.data_ptr(), _ptr(b), a.numel(), int(apply_tanh), y.data_ptr(), _stream()),
+          "add_tanh")
+    return y
+
+
+def tanh_backward(g, y, dx):
+    check(lib().mpgan_tanh_backward(g.data_ptr(), y.data_ptr(), y.numel(), dx.data_ptr(), _stream()),
+          "tanh_backward")
+    return dx
+
+
+def axpby(a, alpha, b, beta, y):
+    check(lib().mpgan_axpby(a.data_ptr(), float(alpha), _ptr(b), float(beta), a.numel(), y.data_ptr(), _stream()),
+          "axpby")
+    return y
+
+
+def copy_slice(src, dst, accumulate=False):
+    n, P, lds = _cl(src, "copy_slice src")
+    _, _, ldd = _cl(dst, "copy_slice dst")
+    if src.shape != dst.shape:
+        raise ValueError("copy_slice: shape mismatch")
+    check(lib().mpgan_copy_slice(src.data_ptr(), lds, dst.data_ptr(), ldd, n * P, src.shape[-1], int(accumulate),
+                                 _stream()), "copy_slice")
+    return dst
+
+
+def linear1_partials(n: int) -> int:
+    return int(lib().mpgan_linear1_partials(n))
+
+
+def linear1_forward(z, p: Optional[Prologue], w_perm, bias, partials, logit):
+    n, P, ld = _cl(z, "linear1_forward z")
+    c = z.shape[-1]
+    if ld != c:
+        raise ValueError("linear1_forward: z must be dense")
+    check(lib().mpgan_linear1_forward(z.data_ptr(), _pro(p), n, P, c, w_perm.data_ptr(), _ptr(bias),
+                                      partials.data_ptr(), logit.data_ptr(), _stream()), "linear1_forward")
+    return logit
+
+
+def linear1_backward(z, p: Optional[Prologue], w_perm, dlogit, g_a, dw, dbias, beta=0.0):
+    n, P, ld = _cl(z, "linear1_backward z")
+    c = z.shape[-1]
+    if ld != c or (g_a is not None and (g_a.shape != z.shape or not g_a.is_contiguous())):
+        raise ValueError("linear1_backward: z / g_a must be dense and same shape")
+    check(lib().mpgan_linear1_backward(z.data_ptr(), _pro(p), n, P, c, w_perm.data_ptr(), dlogit.data_ptr(),
+                                       _ptr(g_a), _ptr(dw), _ptr(dbias), float(beta), _stream()), "linear1_backward")
+
+
+def sigmoid_bce(logit, target: float, loss_scale: float, prob, loss, dlogit):
+    check(lib().mpgan_sigmoid_bce(logit.data_ptr(), logit.numel(), float(target), float(loss_scale), _ptr(prob),
+                                  _ptr(loss), _ptr(dlogit), _stream()), "sigmoid_bce")
+
+
+def l1_partials() -> int:
+    return int(lib().mpgan_l1_partials())
+
+
+def l1_loss(a, b, partials, loss, grad_a=None, grad_scale: float = 1.0):
+    if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError("l1_loss: a and b must be contiguous and same shape")
+    check(lib().mpgan_l1_loss(a.data_ptr(), b.data_ptr(), a.numel(), float(grad_scale), partials.data_ptr(),
+                              loss.data_ptr(), _ptr(grad_a), _stream()), "l1_loss")
+
+
+def adam_step(p, g, m, v, lr, b1, b2, eps, step: int, grad_scale: float = 1.0):
+    if not (p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()):
+        raise ValueError("adam_step: flat buffers must be contiguous")
+    if not (p.numel() == g.numel() == m.numel() == v.numel()):
+        raise ValueError("adam_step: size mismatch")
+    check(lib().mpgan_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr),
+                                float(b1), float(b2), float(eps), int(step), float(grad_scale), _stream()),
+          "adam_step")
+
+
+def _i3(v: Sequence[int]):
+    return (C.c_int32 * 3)(*[int(x) for x in v])
+
+
+def patch_gather(vol, corners, samples: int, roi, patches):
+    """vol (B,1,D,H,W) or (B,D,H,W,1); corners int32 (B*S,3)."""
+    b = vol.shape[0]
+    dhw = vol.shape[2:] if vol.shape[1] == 1 and vol.dim() == 5 and vol.shape[-1] != 1 else vol.shape[1:4]
+    if corners.dtype != torch.int32 or corners.numel() != b * samples * 3:
+        raise ValueError("patch_gather: corners must be int32 (B*S,3)")
+    check(lib().mpgan_patch_gather(vol.data_ptr(), b, _i3(dhw), corners.data_ptr(), samples, _i3(roi),
+                                   patches.data_ptr(), _stream()), "patch_gather")
+    return patches
+
+
+def patch_scatter_add(dpatches, corners, samples: int, roi, dvol):
+    b = dvol.shape[0]
+    dhw = dvol.shape[2:] if dvol.shape[1] == 1 and dvol.dim() == 5 and dvol.shape[-1] != 1 else dvol.shape[1:4]
+    check(lib().mpgan_patch_scatter_add(dpatches.data_ptr(), b, _i3(dhw), corners.data_ptr(), samples, _i3(roi),
+                                        dvol.data_ptr(), _stream()), "patch_scatter_add")
+    return dvol
+
+
+def pack_weight(w: torch.Tensor, *, transposed: bool = False, for_dgrad: bool = False) -> torch.Tensor:
+    """Pack ONE torch-layout conv / convT / linear weight (convenience for tests
+    and small callers; networks pack all their weights with one table launch)."""
+    w = w.contiguous()
+    if transposed:
+        cin, cout = w.shape[0], w.shape[1]
+    else:
+        cout, cin = w.shape[0], w.shape[1]
+    taps = w.numel() // (cin * cout)
+    table = torch.tensor([[0, 0, cout, cin, taps, int(transposed), int(for_dgrad), 0]], dtype=torch.int64,
+                         device=w.device)
+    packed = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    pack_weights(w, packed, table, 1, w.numel())
+    return packed

@@ -1,0 +1,230 @@
+/*
+ * mpgan_hip.h -- C ABI of libmpgan_hip.so, the MI355X (gfx950) hot path of the
+ * T1->T2 GAN training step.
+ *
+ * The reference (mbrzus/Cross-Modality-Minipig-Gan) has no FFI of its own: the
+ * hot path is reached through torch.nn modules.  Each entry point below names
+ * the reference call site whose ATen/cuDNN work it replaces
+ * (paths relative to the reference repo; "MONAI" = monai==0.4.0, un-vendored,
+ * called from code/GAN/GAN_final.py:106-114).
+ *
+ * Conventions
+ *   - Activations are channels-last (N, D, H, W, C) fp32 with an explicit
+ *     channel pitch `ld*` (elements between consecutive pixels), so a tensor
+ *     may be a channel slice of a wider buffer (concat elision).  2-D tensors
+ *     use D = 1 and kernel/stride/pad 1/1/0 in the depth dimension.
+ *   - Conv weights are consumed in packed "OTI" order [Cout][tap][Cin]
+ *     (tap = (kz*Ky+ky)*Kx+kx), produced by mpgan_pack_weights from the
+ *     torch-layout parameters.
+ *   - The caller (PyTorch) owns every buffer.  The library never allocates or
+ *     frees device memory and keeps no pointer after return.  All calls are
+ *     asynchronous on `stream` (a hipStream_t passed as void*).
+ *   - Return value: 0 on success, negative on error; mpgan_last_error() returns
+ *     a thread-local message.  Unsupported shapes are errors, never fallbacks.
+ */
+#ifndef MPGAN_HIP_H
+#define MPGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPGAN_OK 0
+#define MPGAN_ERR_INVALID -1
+#define MPGAN_ERR_UNSUPPORTED -2
+#define MPGAN_ERR_HIP -3
+
+#define MPGAN_ACT_NONE 0
+#define MPGAN_ACT_LEAKY 1 /* x>0 ? x : slope*x ; PReLU (one shared alpha) and LeakyReLU(0.2) */
+
+const char* mpgan_last_error(void);
+int mpgan_abi_version(void);
+
+/* Geometry of one convolution as the reference's nn.ConvNd / nn.ConvTransposeNd
+ * describe it.  For a transposed conv, `in` is the (small) input and `out` the
+ * up-sampled output: out = (in-1)*stride - 2*pad + k + out_pad. */
+typedef struct {
+  int32_t n;                 /* batch */
+  int32_t in_dhw[3];         /* input  spatial (D,H,W) */
+  int32_t out_dhw[3];        /* output spatial (D,H,W) */
+  int32_t cin, cout;
+  int32_t k[3];              /* kernel (kz,ky,kx) */
+  int32_t stride[3];         /* per-dimension stride (1 in an unused depth dim) */
+  int32_t pad[3];
+  int32_t transposed;        /* 0: ConvNd, 1: ConvTransposeNd */
+} mpgan_conv_geom;
+
+/* Optional "normalise + activate on load" prologue applied to the operand that
+ * is a raw (pre-norm) conv output: a = act(z*scale[c] + shift[c]).
+ * scale/shift may be per channel (n_stride = 0, BatchNorm) or per (n, c)
+ * (n_stride = C, InstanceNorm).  slope_ptr (device, 1 float) overrides slope
+ * when non-null (PReLU's learnable alpha). */
+typedef struct {
+  const float* scale;        /* null => no prologue */
+  const float* shift;
+  int32_t n_stride;
+  int32_t act;
+  float slope;
+  const float* slope_ptr;
+} mpgan_prologue;
+
+/* ---- convolution blocks ------------------------------------------------- */
+
+/* y = conv(prologue(x)) [+ bias] [+ resid] [tanh]   (forward of ConvNd, or of
+ * ConvTransposeNd when g->transposed).
+ * Replaces: conv3d/conv_transpose3d dispatched by MONAI Convolution /
+ * ResidualUnit (GAN_final.py:106-114) and by Discriminator.model_conv
+ * (GAN_final.py:167-189, test_runs/GAN.py:142-173). */
+int mpgan_conv_forward(const mpgan_conv_geom* g, const float* x, int32_t ldx,
+                       const float* w_packed, const float* bias,
+                       const mpgan_prologue* pro,
+                       const float* resid, int32_t ldr, int32_t tanh_out,
+                       float* y, int32_t ldy, void* stream);
+
+/* dx = conv_backward_data(dy) [+ resid]: gradient w.r.t. the conv input
+ * (for g->transposed: gradient w.r.t. the transposed conv's input).
+ * `w_packed_bwd` is the packed weight for the backward direction
+ * (mpgan_pack_weights with for_dgrad=1).
+ * Replaces: the autograd conv backward-data kernels behind loss.backward()
+ * (GAN_final.py:273,296 via Lightning's loop). */
+int mpgan_conv_backward_data(const mpgan_conv_geom* g, const float* dy, int32_t lddy,
+                             const float* w_packed_bwd,
+                             const float* resid, int32_t ldr,
+                             float* dx, int32_t lddx, void* stream);
+
+/* Weight gradient: dW (torch layout, (Cout,Cin,k..) or (Cin,Cout,k..) for a
+ * transposed conv) = beta*dW + sum over pixels.  x is the conv's input (with
+ * optional prologue), dy the gradient of its raw output.  `workspace` holds
+ * the split-K partial slabs (size from mpgan_conv_wgrad_workspace). */
+int64_t mpgan_conv_wgrad_workspace(const mpgan_conv_geom* g);
+int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float* x, int32_t ldx,
+                               const mpgan_prologue* pro,
+                               const float* dy, int32_t lddy,
+                               float* dw, float beta,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Repack every conv / linear weight of a network in ONE launch.
+ * table: device int64 [n_entries][8] = {src_off, dst_off, cout, cin, taps,
+ * transposed, for_dgrad, k_spatial_code}; offsets in floats into `flat_params` / `packed`. */
+int mpgan_pack_weights(const float* flat_params, float* packed, const int64_t* table,
+                       int32_t n_entries, int64_t max_elems, void* stream);
+
+/* ---- normalisation (BatchNorm training mode / InstanceNorm) -------------- */
+
+/* Per-channel partial sums of z and z^2 over pixel chunks.
+ * partials: [n][chunks][2][C]; returns chunks via mpgan_stats_chunks().
+ * Replaces: the statistics half of batch_norm (every adn.N in MONAI UNet;
+ * GAN_final.py:170,176,182,188). */
+int32_t mpgan_stats_chunks(int64_t pixels_per_sample, int32_t c);
+int mpgan_channel_stats(const float* z, int32_t ldz, int32_t n, int64_t pixels_per_sample,
+                        int32_t c, float* partials, void* stream);
+
+/* Finalise statistics: mean / biased var -> scale = gamma*invstd,
+ * shift = beta - mean*scale; saves mean and invstd; updates running stats
+ * (momentum, UNBIASED variance) when running_mean != null.
+ * instance = 0: one set per channel (stats over n and pixels);
+ * instance = 1: one set per (n, c). */
+int mpgan_norm_finalize(const float* partials, int32_t n, int32_t chunks, int32_t c,
+                        int64_t pixels_per_sample, int32_t instance,
+                        const float* gamma, const float* beta, float eps, float momentum,
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                        float* scale, float* shift, float* mean, float* invstd, void* stream);
+
+/* out = act(z*scale+shift) [+ r]   where r is either a plain tensor or itself
+ * act(zr*scale_r+shift_r); optional tanh on the sum.  (ResidualUnit.forward's
+ * "cx + res" and the generator's final Tanh, GAN_final.py:117.) */
+int mpgan_norm_act_add(const float* z, int32_t ldz, const mpgan_prologue* pz,
+                       const float* r, int32_t ldr, const mpgan_prologue* pr,
+                       int32_t n, int64_t pixels_per_sample, int32_t c, int32_t tanh_out,
+                       float* out, int32_t ldo, void* stream);
+
+/* Backward of a = act(z*scale+shift), given g = dL/da:
+ *   reduce  : partials [n][chunks][3][C] of (sum gy, sum gy*zhat, sum g*min(y,0))
+ *   finalize: dgamma += , dbeta += , dslope += ; coef c1 = sum gy / M, c2 = sum gy*zhat / M
+ *   apply   : dz = scale*(gy - c1 - zhat*c2)
+ * g may carry a fused pointwise factor: g_eff = g * (1 - t^2) (tanh backward)
+ * when tanh_y != null. */
+int mpgan_norm_bwd_reduce(const float* g, int32_t ldg, const float* z, int32_t ldz,
+                          const mpgan_prologue* p, const float* mean, const float* invstd,
+                          int32_t n, int64_t pixels_per_sample, int32_t c,
+                          float* partials, void* stream);
+int mpgan_norm_bwd_finalize(const float* partials, int32_t n, int32_t chunks, int32_t c,
+                            int64_t pixels_per_sample, int32_t instance,
+                            float* dgamma, float* dbeta, float* dslope,
+                            float* c1, float* c2, void* stream);
+int mpgan_norm_bwd_apply(const float* g, int32_t ldg, const float* z, int32_t ldz,
+                         const mpgan_prologue* p, const float* mean, const float* invstd,
+                         const float* c1, const float* c2,
+                         int32_t n, int64_t pixels_per_sample, int32_t c,
+                         float* dz, int32_t lddz, void* stream);
+
+/* out[c] = beta*out[c] + sum_p partials[p][c]  (deterministic order). */
+int mpgan_reduce_partials(const float* partials, int32_t rows, int32_t row_stride, int32_t c,
+                          float* out, float beta, void* stream);
+
+/* ---- pointwise helpers --------------------------------------------------- */
+/* y = a + b (optionally y = tanh(a+b));  dx = g*(1-y^2). */
+int mpgan_add_tanh(const float* a, const float* b, int64_t numel, int32_t apply_tanh,
+                   float* y, void* stream);
+int mpgan_tanh_backward(const float* g, const float* y, int64_t numel, float* dx, void* stream);
+int mpgan_axpby(const float* a, float alpha, const float* b, float beta, int64_t numel,
+                float* y, void* stream);
+/* strided channel-slice copy: dst[p*ldd + c] = src[p*lds + c] (accumulate: +=) */
+int mpgan_copy_slice(const float* src, int32_t lds, float* dst, int32_t ldd, int64_t pixels,
+                     int32_t c, int32_t accumulate, void* stream);
+
+/* ---- discriminator head: Flatten + Linear(F,1) + Sigmoid + BCE ------------ */
+/* logit[n] = bias + sum_k act(z[n][k]*scale+shift) * w_perm[k]  where z is the
+ * last conv's raw output in channels-last order and w_perm the Linear weight
+ * permuted to that order by mpgan_pack_weights.  (GAN_final.py:198-204.) */
+int32_t mpgan_linear1_partials(int32_t n); /* floats of `partials` scratch */
+int mpgan_linear1_forward(const float* z, const mpgan_prologue* p, int32_t n,
+                          int64_t pixels_per_sample, int32_t c, const float* w_perm,
+                          const float* bias, float* partials, float* logit, void* stream);
+/* g_a[n][k] = dlogit[n]*w_perm[k];  dW (torch order, C-major) += sum_n dlogit[n]*a[n][k];
+ * dbias += sum_n dlogit[n]. */
+int mpgan_linear1_backward(const float* z, const mpgan_prologue* p, int32_t n,
+                           int64_t pixels_per_sample, int32_t c, const float* w_perm,
+                           const float* dlogit, float* g_a, float* dw, float* dbias,
+                           float beta, void* stream);
+
+/* prob = sigmoid(logit); loss = mean BCE(prob, target) with log clamped at
+ * -100 (F.binary_cross_entropy, GAN_final.py:244-245); dlogit = loss_scale *
+ * dL/dlogit computed THROUGH the clamped log and the sigmoid exactly as
+ * autograd does (BCE backward: (p-t)/max((1-p)p, 1e-12)/n, then p(1-p)). */
+int mpgan_sigmoid_bce(const float* logit, int32_t n, float target, float loss_scale,
+                      float* prob, float* loss, float* dlogit, void* stream);
+
+/* loss = mean |a-b| (F.l1_loss, GAN_final.py:247-248); grad_a = scale*sign(a-b)/numel
+ * (written when grad_a != null).  partials: >= mpgan_l1_partials() floats. */
+int32_t mpgan_l1_partials(void);
+int mpgan_l1_loss(const float* a, const float* b, int64_t numel, float grad_scale,
+                  float* partials, float* loss, float* grad_a, void* stream);
+
+/* ---- optimiser ------------------------------------------------------------ */
+/* torch.optim.Adam.step over one flat buffer (GAN_final.py:306-307):
+ * m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t)+eps).
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce).  Hyper-parameters are
+ * doubles (python floats), rounded to fp32 where torch rounds them. */
+int mpgan_adam_step(float* p, const float* g, float* m, float* v, int64_t numel,
+                    double lr, double b1, double b2, double eps, int32_t step, float grad_scale,
+                    void* stream);
+
+/* ---- patch gather / scatter (variant B, test_runs/GAN.py:263-272,313-337) -- */
+/* patches[(b*S+s)][roi^dims] = vol[b][corner+...]; bit-exact copy.
+ * corners: device int32 [B*S][3] (z,y,x). */
+int mpgan_patch_gather(const float* vol, int32_t b, const int32_t dhw[3],
+                       const int32_t* corners, int32_t samples, const int32_t roi[3],
+                       float* patches, void* stream);
+/* dvol[b][corner+...] += dpatches (atomic-free: one thread per volume voxel
+ * walks the corners that cover it, in sample order => deterministic). */
+int mpgan_patch_scatter_add(const float* dpatches, int32_t b, const int32_t dhw[3],
+                            const int32_t* corners, int32_t samples, const int32_t roi[3],
+                            float* dvol, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPGAN_HIP_H */

@@ -1,0 +1,196 @@
+"""HIP conv kernels (through the C ABI) vs the CPU oracle ops on identical inputs.
+
+fp32 tolerance: rtol 2e-4, atol 2e-5 * max|ref| (summation order differs; the
+MFMA path is an exact fp32 fma chain)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_helpers import assert_close, from_cl, t3, to_cl
+
+pytestmark = pytest.mark.gpu
+
+# (dims, cin, cout, k, stride, pad, spatial, batch)  -- every layer type of G and D
+CONV_CASES = [
+    (2, 1, 16, 3, 2, 1, (20, 24), 2),      # G down0.unit0 / residual (Cin = 1, scalar gather)
+    (2, 16, 16, 3, 1, 1, (20, 24), 3),     # G down0.unit1
+    (2, 16, 32, 3, 2, 1, (20, 24), 2),     # G down1.unit0
+    (2, 32, 64, 3, 2, 1, (12, 16), 2),
+    (2, 64, 128, 3, 1, 1, (9, 7), 2),      # G bottom.unit0
+    (2, 128, 128, 3, 1, 1, (8, 8), 2),     # G bottom.unit1
+    (2, 64, 128, 1, 1, 0, (8, 8), 2),      # G bottom.residual (1x1)
+    (2, 1, 1, 3, 1, 1, (16, 20), 2),       # G up0.ru.unit0 (1 -> 1)
+    (2, 1, 64, 3, 1, 0, (20, 18), 2),      # D conv1
+    (2, 64, 128, 3, 1, 0, (20, 18), 2),    # D conv2
+    (2, 128, 256, 4, 2, 0, (18, 16), 2),   # D conv3
+    (2, 256, 256, 4, 2, 0, (15, 13), 2),   # D conv4 (odd input: uneven phases in dgrad)
+    (3, 1, 16, 3, 2, 1, (8, 10, 12), 2),   # 3-D variants (reference's true shape)
+    (3, 16, 32, 3, 2, 1, (8, 10, 12), 1),
+    (3, 32, 32, 3, 1, 1, (6, 5, 7), 2),
+    (3, 64, 128, 3, 1, 0, (6, 6, 6), 1),
+    (3, 128, 256, 4, 2, 0, (8, 8, 10), 1),
+    (3, 256, 512, 3, 1, 0, (5, 5, 5), 2),  # variant-B D conv4
+]
+
+CONVT_CASES = [
+    (2, 192, 32, (6, 5), 2),
+    (2, 64, 16, (10, 12), 2),
+    (2, 32, 1, (12, 10), 3),
+    (3, 192, 32, (3, 4, 5), 1),
+    (3, 32, 1, (5, 4, 6), 2),
+]
+
+
+def _geom(dims, n, cin, cout, k, s, p, spatial, transposed=False):
+    from mpgan_amd.ops import ConvGeom
+    return ConvGeom(n, t3(spatial, dims, 1), cin, cout, t3(k, dims, 1), t3(s, dims, 1), t3(p, dims, 0),
+                    transposed, t3(s - 1, dims, 0) if transposed else (0, 0, 0))
+
+
+def _conv(dims):
+    return F.conv2d if dims == 2 else F.conv3d
+
+
+def _convt(dims):
+    return F.conv_transpose2d if dims == 2 else F.conv_transpose3d
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "d{}_{}to{}_k{}s{}p{}".format(*c[:6]))
+def test_conv_forward_dgrad_wgrad(case):
+    from mpgan_amd import ops
+    dims, cin, cout, k, s, p, spatial, n = case
+    gen = torch.Generator().manual_seed(1000 + cin * 7 + cout)
+    x = (torch.rand(n, cin, *spatial, generator=gen) * 2 - 1).requires_grad_(True)
+    w = ((torch.rand(cout, cin, *([k] * dims), generator=gen) * 2 - 1) / (cin * k ** dims) ** 0.5).requires_grad_(True)
+    b = (torch.rand(cout, generator=gen) - 0.5).requires_grad_(True)
+    y_ref = _conv(dims)(x, w, b, stride=s, padding=p)
+    gy = torch.rand(y_ref.shape, generator=gen) * 2 - 1
+    y_ref.backward(gy)
+
+    g = _geom(dims, n, cin, cout, k, s, p, spatial)
+    assert g.out_dhw[3 - dims:] == tuple(y_ref.shape[2:])
+    xc, wc = to_cl(x.detach()), w.detach().cuda()
+    y = torch.empty(n, *g.out_dhw, cout, device="cuda")
+    ops.conv_forward(g, xc, ops.pack_weight(wc), b.detach().cuda(), y)
+    assert_close(from_cl(y, dims), y_ref, what="forward")
+
+    dx = torch.full((n, *g.in_dhw, cin), float("nan"), device="cuda")
+    ops.conv_backward_data(g, to_cl(gy), ops.pack_weight(wc, for_dgrad=True), dx)
+    assert_close(from_cl(dx, dims), x.grad, what="dgrad")
+
+    ws = torch.empty(ops.conv_wgrad_workspace(g) // 4, device="cuda")
+    dw = torch.full_like(wc, float("nan"))
+    ops.conv_backward_weight(g, xc, to_cl(gy), dw, ws)
+    assert_close(dw.cpu(), w.grad, what="wgrad")
+    # accumulate (beta = 1) doubles it
+    ops.conv_backward_weight(g, xc, to_cl(gy), dw, ws, beta=1.0)
+    assert_close(dw.cpu(), 2 * w.grad, what="wgrad beta=1")
+
+
+@pytest.mark.parametrize("case", CONVT_CASES, ids=lambda c: "d{}_{}to{}".format(*c[:3]))
+def test_conv_transpose_forward_dgrad_wgrad(case):
+    from mpgan_amd import ops
+    dims, cin, cout, spatial, n = case
+    k, s, p = 3, 2, 1
+    gen = torch.Generator().manual_seed(2000 + cin + cout)
+    x = (torch.rand(n, cin, *spatial, generator=gen) * 2 - 1).requires_grad_(True)
+    w = ((torch.rand(cin, cout, *([k] * dims), generator=gen) * 2 - 1) / (cin * k ** dims) ** 0.5).requires_grad_(True)
+    b = (torch.rand(cout, generator=gen) - 0.5).requires_grad_(True)
+    y_ref = _convt(dims)(x, w, b, stride=s, padding=p, output_padding=s - 1)
+    gy = torch.rand(y_ref.shape, generator=gen) * 2 - 1
+    y_ref.backward(gy)
+
+    g = _geom(dims, n, cin, cout, k, s, p, spatial, transposed=True)
+    assert g.out_dhw[3 - dims:] == tuple(y_ref.shape[2:])
+    xc, wc = to_cl(x.detach()), w.detach().cuda()
+    y = torch.full((n, *g.out_dhw, cout), float("nan"), device="cuda")
+    ops.conv_forward(g, xc, ops.pack_weight(wc, transposed=True), b.detach().cuda(), y)
+    assert_close(from_cl(y, dims), y_ref, what="convT forward")
+
+    dx = torch.full((n, *g.in_dhw, cin), float("nan"), device="cuda")
+    ops.conv_backward_data(g, to_cl(gy), ops.pack_weight(wc, transposed=True, for_dgrad=True), dx)
+    assert_close(from_cl(dx, dims), x.grad, what="convT dgrad")
+
+    ws = torch.empty(ops.conv_wgrad_workspace(g) // 4, device="cuda")
+    dw = torch.full_like(wc, float("nan"))
+    ops.conv_backward_weight(g, xc, to_cl(gy), dw, ws)
+    assert_close(dw.cpu(), w.grad, what="convT wgrad")
+
+
+@pytest.mark.parametrize("instance", [False, True])
+@pytest.mark.parametrize("cin,cout,k,s,p", [(16, 32, 3, 2, 1), (64, 128, 3, 1, 0), (1, 16, 3, 1, 1)])
+def test_conv_prologue_bias_resid_tanh_and_channel_slices(cin, cout, k, s, p, instance):
+    """Producer norm + PReLU applied on load; input and output are channel slices
+    of wider buffers (concat elision); residual add and tanh in the epilogue."""
+    from mpgan_amd import ops
+    n, spatial = 3, (14, 10)
+    gen = torch.Generator().manual_seed(77 + cin)
+    z = torch.rand(n, cin, *spatial, generator=gen) * 2 - 1
+    sc = torch.rand(n if instance else 1, cin, generator=gen) + 0.5
+    sh = torch.rand(n if instance else 1, cin, generator=gen) - 0.5
+    alpha = 0.3
+    a = z * sc[:, :, None, None] + sh[:, :, None, None]
+    a = torch.where(a > 0, a, alpha * a)
+    w = (torch.rand(cout, cin, k, k, generator=gen) * 2 - 1) / (cin * k * k) ** 0.5
+    b = torch.rand(cout, generator=gen) - 0.5
+    y0 = F.conv2d(a, w, b, stride=s, padding=p)
+    r = torch.rand(y0.shape, generator=gen) * 2 - 1
+    y_ref = torch.tanh(y0 + r)
+
+    g = _geom(2, n, cin, cout, k, s, p, spatial)
+    pad_in = 4 if cin % 4 == 0 else 3
+    xbuf = torch.zeros(n, 1, *spatial, cin + 2 * pad_in, device="cuda")
+    xbuf[..., pad_in:pad_in + cin] = to_cl(z)
+    ybuf = torch.full((n, *g.out_dhw, cout + 8), float("nan"), device="cuda")
+    rbuf = torch.zeros(n, *g.out_dhw, cout + 4, device="cuda")
+    rbuf[..., 4:] = to_cl(r)
+    pro = ops.Prologue(sc.flatten().cuda(), sh.flatten().cuda(), cin if instance else 0, ops.ACT_LEAKY, 1.0,
+                       torch.tensor([alpha], device="cuda"))
+    ops.conv_forward(g, xbuf[..., pad_in:pad_in + cin], ops.pack_weight(w.cuda()), b.cuda(), ybuf[..., 8:],
+                     pro=pro, resid=rbuf[..., 4:], tanh_out=True)
+    assert_close(from_cl(ybuf[..., 8:], 2), y_ref, what="fused forward")
+    assert torch.isnan(ybuf[..., :8]).all(), "wrote outside its channel slice"
+
+    # weight gradient sees the same prologue on its gathered operand
+    gy = torch.rand(y0.shape, generator=gen) * 2 - 1
+    a_ = a.clone().requires_grad_(True)
+    w_ = w.clone().requires_grad_(True)
+    F.conv2d(a_, w_, None, stride=s, padding=p).backward(gy)
+    ws = torch.empty(ops.conv_wgrad_workspace(g) // 4, device="cuda")
+    dw = torch.empty_like(w, device="cuda")
+    ops.conv_backward_weight(g, xbuf[..., pad_in:pad_in + cin], to_cl(gy), dw, ws, pro=pro)
+    assert_close(dw.cpu(), w_.grad, what="wgrad with prologue")
+    # dgrad with residual accumulate into a slice
+    dxbuf = torch.full((n, 1, *spatial, cin + 4), float("nan"), device="cuda")
+    res = torch.rand(n, cin, *spatial, generator=gen)
+    ops.conv_backward_data(g, to_cl(gy), ops.pack_weight(w.cuda(), for_dgrad=True), dxbuf[..., :cin],
+                           resid=to_cl(res))
+    assert_close(from_cl(dxbuf[..., :cin], 2), a_.grad + res, what="dgrad + resid")
+
+
+def test_linear_as_conv_matches_flatten_linear():
+    """Variant-B head Linear(512*8^3 -> 64) is a conv whose kernel spans the whole
+    (8,8,8) grid; the packed weight realises the NCDHW-flatten permutation."""
+    from mpgan_amd import ops
+    n, c, sp, o = 5, 32, (4, 4, 4), 64
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(n, c, *sp, generator=gen) * 2 - 1
+    lin = torch.nn.Linear(c * 64, o)
+    y_ref = lin(x.flatten(1))
+    g = ops.ConvGeom(n, sp, c, o, sp, (1, 1, 1), (0, 0, 0))
+    y = torch.empty(n, 1, 1, 1, o, device="cuda")
+    wconv = lin.weight.detach().reshape(o, c, *sp).cuda()
+    ops.conv_forward(g, to_cl(x), ops.pack_weight(wconv), lin.bias.detach().cuda(), y)
+    assert_close(y.reshape(n, o).cpu(), y_ref, what="linear as conv")
+
+
+def test_unsupported_and_invalid_arguments_raise():
+    from mpgan_amd import ops
+    g = ops.ConvGeom(1, (1, 8, 8), 4, 4, (1, 3, 3), (1, 3, 3), (0, 1, 1))
+    x = torch.zeros(1, 1, 8, 8, 4, device="cuda")
+    y = torch.zeros(1, *g.out_dhw, 4, device="cuda")
+    with pytest.raises(RuntimeError, match="stride"):
+        ops.conv_forward(g, x, torch.zeros(4 * 4 * 9, device="cuda"), None, y)
+    g2 = ops.ConvGeom(1, (1, 8, 8), 4, 4, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    with pytest.raises(ValueError):
+        ops.conv_forward(g2, x.cpu(), torch.zeros(144, device="cuda"), None, y)

@@ -1,0 +1,201 @@
+"""Norm / activation / loss / optimiser kernels vs the CPU oracle ops."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_helpers import assert_close, from_cl, to_cl
+
+pytestmark = pytest.mark.gpu
+
+
+def _norm_forward(z_cl, gamma, beta, instance, running=None, eps=1e-5, momentum=0.1):
+    from mpgan_amd import ops
+    n, d, h, w, c = z_cl.shape
+    P = d * h * w
+    chunks = ops.stats_chunks(P, c)
+    partials = torch.empty(n * chunks * 2 * c, device="cuda")
+    ops.channel_stats(z_cl, partials)
+    m = n * c if instance else c
+    scale, shift, mean, invstd = (torch.empty(m, device="cuda") for _ in range(4))
+    rm, rv, nbt = running if running is not None else (None, None, None)
+    ops.norm_finalize(partials, n, chunks, c, P, instance, gamma, beta, eps, momentum, rm, rv, nbt, scale, shift,
+                      mean, invstd)
+    return scale, shift, mean, invstd
+
+
+@pytest.mark.parametrize("c,spatial,n", [(16, (1, 40, 36), 3), (1, (1, 64, 64), 2), (128, (1, 9, 7), 2),
+                                         (192, (1, 8, 8), 2), (32, (6, 10, 12), 2), (512, (2, 2, 2), 4)])
+@pytest.mark.parametrize("instance", [False, True])
+def test_norm_prelu_forward_backward(c, spatial, n, instance):
+    """stats -> finalize -> apply, and the three-kernel backward, against
+    F.batch_norm / F.instance_norm + PReLU autograd (train mode, running stats)."""
+    from mpgan_amd import ops
+    gen = torch.Generator().manual_seed(31 + c)
+    d, h, w = spatial
+    z = (torch.rand(n, c, d, h, w, generator=gen) * 3 - 1).requires_grad_(True)
+    gamma = (torch.rand(c, generator=gen) + 0.5).requires_grad_(True)
+    beta = (torch.rand(c, generator=gen) - 0.5).requires_grad_(True)
+    alpha = torch.tensor([0.25]).requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    if instance:
+        y = F.instance_norm(z, None, None, gamma, beta, True, 0.1, 1e-5)
+    else:
+        y = F.batch_norm(z, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    a = F.prelu(y, alpha)
+    g = torch.rand(a.shape, generator=gen) * 2 - 1
+    a.backward(g)
+
+    z_cl = to_cl(z.detach())
+    run = None
+    if not instance:
+        run = (torch.zeros(c, device="cuda"), torch.ones(c, device="cuda"),
+               torch.zeros((), dtype=torch.int64, device="cuda"))
+    scale, shift, mean, invstd = _norm_forward(z_cl, gamma.detach().cuda(), beta.detach().cuda(), instance, run)
+    alpha_d = alpha.detach().cuda()
+    pro = ops.Prologue(scale, shift, c if instance else 0, ops.ACT_LEAKY, 1.0, alpha_d)
+    out = torch.empty_like(z_cl)
+    ops.norm_act_add(z_cl, pro, None, None, out)
+    assert_close(from_cl(out, 3), a, what="norm+prelu forward")
+    if not instance:
+        assert_close(run[0].cpu(), rm, what="running_mean")
+        assert_close(run[1].cpu(), rv, what="running_var (unbiased)")
+        assert int(run[2].item()) == 1
+
+    P = d * h * w
+    chunks = ops.stats_chunks(P, c)
+    partials = torch.empty(n * chunks * 3 * c, device="cuda")
+    g_cl = to_cl(g)
+    ops.norm_bwd_reduce(g_cl, z_cl, pro, mean, invstd, partials)
+    dgamma, dbeta = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    dslope = torch.zeros(1, device="cuda")
+    m = n * c if instance else c
+    c1, c2 = torch.empty(m, device="cuda"), torch.empty(m, device="cuda")
+    ops.norm_bwd_finalize(partials, n, chunks, c, P, instance, dgamma, dbeta, dslope, c1, c2)
+    dz = torch.empty_like(z_cl)
+    ops.norm_bwd_apply(g_cl, z_cl, pro, mean, invstd, c1, c2, dz)
+    assert_close(from_cl(dz, 3), z.grad, rtol=1e-3, what="dz")
+    assert_close(dgamma.cpu(), gamma.grad, rtol=1e-3, what="dgamma")
+    assert_close(dbeta.cpu(), beta.grad, rtol=1e-3, what="dbeta")
+    assert_close(dslope.cpu(), alpha.grad, rtol=1e-3, what="dalpha")
+
+
+def test_norm_act_add_virtual_residual_and_tanh():
+    from mpgan_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    n, c, h, w = 2, 32, 10, 12
+    z, r = torch.rand(n, c, h, w, generator=gen) - 0.5, torch.rand(n, c, h, w, generator=gen) - 0.5
+    s1, t1, s2, t2 = (torch.rand(c, generator=gen) for _ in range(4))
+    lrelu = lambda x, a: torch.where(x > 0, x, a * x)
+    ref = torch.tanh(lrelu(z * s1[None, :, None, None] + t1[None, :, None, None], 0.25)
+                     + lrelu(r * s2[None, :, None, None] + t2[None, :, None, None], 0.1))
+    buf = torch.full((n, 1, h, w, 2 * c), float("nan"), device="cuda")
+    ops.norm_act_add(to_cl(z), ops.Prologue(s1.cuda(), t1.cuda(), 0, ops.ACT_LEAKY, 0.25), to_cl(r),
+                     ops.Prologue(s2.cuda(), t2.cuda(), 0, ops.ACT_LEAKY, 0.1), buf[..., c:], tanh_out=True)
+    assert_close(from_cl(buf[..., c:], 2), ref, what="virtual residual")
+    assert torch.isnan(buf[..., :c]).all()
+
+
+def test_sigmoid_bce_matches_oracle_incl_clamp(golden_dir):
+    from mpgan_amd import ops
+    from oracle import refmodel as R
+    logits = torch.tensor([-200.0, -20.0, -1.5, 0.0, 0.3, 4.0, 30.0, 200.0])
+    for target in (1.0, 0.9, 0.0):
+        x = logits.clone().requires_grad_(True)
+        p = torch.sigmoid(x).unsqueeze(1)
+        loss_ref = R.adversarial_loss(p, torch.full_like(p, target))
+        (0.5 * loss_ref).backward()
+        prob, loss, dl = torch.empty(8, device="cuda"), torch.empty(1, device="cuda"), torch.empty(8, device="cuda")
+        ops.sigmoid_bce(logits.cuda(), target, 0.5, prob, loss, dl)
+        assert_close(prob.cpu(), p.detach().flatten(), what="prob")
+        assert_close(loss.cpu(), loss_ref.detach().reshape(1), what=f"bce target {target}")
+        assert_close(dl.cpu(), x.grad, rtol=1e-4, atol=1e-9, what="dlogit")
+    # saturated: the reference's checkpoints show g_loss = 100.03 (log clamp at -100)
+    loss = torch.empty(1, device="cuda")
+    ops.sigmoid_bce(torch.full((4,), -500.0, device="cuda"), 1.0, 1.0, None, loss, None)
+    assert loss.item() == 100.0
+
+
+def test_l1_loss_and_grad(golden_dir):
+    import os
+    from mpgan_amd import ops
+    fx = np.load(os.path.join(golden_dir, "losses.npz"))
+    a, b = torch.from_numpy(fx["a"]), torch.from_numpy(fx["b"])
+    part = torch.empty(ops.l1_partials(), device="cuda")
+    loss, grad = torch.empty(1, device="cuda"), torch.empty_like(a, device="cuda")
+    ops.l1_loss(a.cuda(), b.cuda(), part, loss, grad, 1.0)
+    np.testing.assert_allclose(loss.item(), float(fx["l1"]), rtol=1e-6)  # reference's own value
+    a2 = a.clone().requires_grad_(True)
+    F.l1_loss(a2, b).backward()
+    assert torch.equal(grad.cpu(), a2.grad)
+    big_a, big_b = torch.rand(3, 1, 300, 301), torch.rand(3, 1, 300, 301)
+    ops.l1_loss(big_a.cuda(), big_b.cuda(), part, loss)
+    np.testing.assert_allclose(loss.item(), F.l1_loss(big_a, big_b).item(), rtol=1e-5)
+
+
+def test_adam_matches_torch_adam_over_steps():
+    from mpgan_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    p0 = torch.rand(10007, generator=gen) - 0.5
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=5e-4, betas=(0.5, 0.999))
+    p, m, v = p0.cuda(), torch.zeros(10007, device="cuda"), torch.zeros(10007, device="cuda")
+    for step in range(1, 6):
+        g = torch.rand(10007, generator=gen) - 0.5
+        p_ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, g.cuda(), m, v, 5e-4, 0.5, 0.999, 1e-8, step)
+        assert_close(p.cpu(), p_ref.detach(), rtol=1e-6, atol=1e-7, what=f"adam step {step}")
+    st = opt.state[p_ref]
+    assert_close(m.cpu(), st["exp_avg"], rtol=1e-6, atol=1e-9, what="exp_avg")
+    assert_close(v.cpu(), st["exp_avg_sq"], rtol=1e-6, atol=1e-12, what="exp_avg_sq")
+
+
+def test_linear1_head_forward_backward():
+    """Flatten + Linear(F,1) on the last conv's RAW output with BN+LeakyReLU on load."""
+    from mpgan_amd import ops
+    gen = torch.Generator().manual_seed(8)
+    n, c, h, w = 3, 64, 9, 7
+    z = torch.rand(n, c, h, w, generator=gen) - 0.5
+    sc, sh = torch.rand(c, generator=gen) + 0.5, torch.rand(c, generator=gen) - 0.5
+    lin = torch.nn.Linear(c * h * w, 1)
+    a = (z * sc[None, :, None, None] + sh[None, :, None, None])
+    a = F.leaky_relu(a, 0.2).requires_grad_(True)
+    logit_ref = lin(a.flatten(1))
+    dl = torch.rand(n, 1, generator=gen) - 0.5
+    logit_ref.backward(dl)
+
+    wperm = ops.pack_weight(lin.weight.detach().reshape(1, c, 1, h, w).cuda())
+    pro = ops.Prologue(sc.cuda(), sh.cuda(), 0, ops.ACT_LEAKY, 0.2)
+    z_cl = to_cl(z)
+    part = torch.empty(ops.linear1_partials(n), device="cuda")
+    logit = torch.empty(n, device="cuda")
+    ops.linear1_forward(z_cl, pro, wperm, lin.bias.detach().cuda(), part, logit)
+    assert_close(logit.cpu(), logit_ref.detach().flatten(), what="logit")
+    g_a = torch.empty_like(z_cl)
+    dw = torch.zeros(c * h * w, device="cuda")
+    db = torch.zeros(1, device="cuda")
+    ops.linear1_backward(z_cl, pro, wperm, dl.flatten().cuda(), g_a, dw, db, beta=0.0)
+    assert_close(from_cl(g_a, 2), a.grad, what="g_a")
+    assert_close(dw.cpu(), lin.weight.grad.flatten(), what="dW (torch flatten order)")
+    assert_close(db.cpu(), lin.bias.grad, what="dbias")
+
+
+def test_patch_gather_is_bit_exact_and_scatter_is_its_adjoint():
+    from mpgan_amd import ops
+    from oracle import refmodel as R
+    rs = np.random.RandomState(3)
+    B, S, roi = 2, 7, 4
+    vol = torch.rand(B, 1, 10, 12, 14)
+    corners = R.draw_corners(rs, B, S, (10, 12, 14), roi)
+    want = R.crop_patches(vol, corners, roi)
+    c_dev = torch.from_numpy(corners.reshape(-1, 3).astype(np.int32)).cuda()
+    got = torch.empty(B * S, 1, roi, roi, roi, device="cuda")
+    ops.patch_gather(vol.cuda(), c_dev, S, (roi,) * 3, got)
+    assert torch.equal(got.cpu(), want)  # index op: bit-exact
+    v = vol.clone().requires_grad_(True)
+    gp = torch.rand(want.shape)
+    R.crop_patches(v, corners, roi).backward(gp)
+    dvol = torch.zeros_like(vol, device="cuda")
+    ops.patch_scatter_add(gp.cuda(), c_dev, S, (roi,) * 3, dvol)
+    assert_close(dvol.cpu(), v.grad, rtol=1e-6, what="scatter-add")

@@ -50,7 +50,11 @@ SIGNATURES = {
     "mpgan_axpby": (_I, [_P, _F, _P, _F, _L, _P, _P]),
     "mpgan_copy_slice": (_I, [_P, _I, _P, _I, _L, _I, _I, _P]),
     "mpgan_linear1_partials": (_I, [_I]),
-    "mpgan_linear1_forward": (_I, [_P, _PR, _I, _L, _I, _P, _P, _P, _P, _P]),
+    "mpgan_linear1_forward": (_I, [_P, _PR, _I, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "mpgan_bce_forward": (_I, [_P, _P, _I, _P, _P]),
+    "mpgan_bce_backward": (_I, [_P, _P, _I, _P, _P, _P]),
+    "mpgan_sigmoid_backward": (_I, [_P, _P, _I, _P, _P]),
+    "mpgan_scale_by_device_scalar": (_I, [_P, _P, _L, _P, _P]),
     "mpgan_linear1_backward": (_I, [_P, _PR, _I, _L, _I, _P, _P, _P, _P, _P, _F, _P]),
     "mpgan_sigmoid_bce": (_I, [_P, _I, _F, _F, _P, _P, _P, _P]),
     "mpgan_l1_partials": (_I, []),

@@ -56,12 +56,51 @@ __global__ __launch_bounds__(256) void linear1_partial_kernel(const float* __res
 }
 
 __global__ void linear1_final_kernel(const float* __restrict__ partials, const float* bias, int n,
-                                     float* __restrict__ logit) {
+                                     float* __restrict__ logit, float* __restrict__ prob) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
   for (int k = 0; k < LIN_CHUNKS; ++k) s += partials[i * LIN_CHUNKS + k];
-  logit[i] = s + (bias ? bias[0] : 0.f);
+  s += bias ? bias[0] : 0.f;
+  logit[i] = s;
+  if (prob) prob[i] = 1.f / (1.f + expf(-s));
+}
+
+__global__ __launch_bounds__(256) void bce_forward_kernel(const float* __restrict__ prob,
+                                                          const float* __restrict__ target, int n,
+                                                          float* __restrict__ loss) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float pr = prob[i], t = target[i];
+    acc += -(t * fmaxf(logf(pr), -100.f) + (1.f - t) * fmaxf(logf(1.f - pr), -100.f));
+  }
+  acc = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) *loss = acc / (float)n;
+}
+
+__global__ void bce_backward_kernel(const float* __restrict__ prob, const float* __restrict__ target, int n,
+                                    const float* __restrict__ gout, float* __restrict__ dprob) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float pr = prob[i];
+  dprob[i] = (pr - target[i]) / fmaxf((1.f - pr) * pr, 1e-12f) * (gout[0] / (float)n);
+}
+
+__global__ void sigmoid_backward_kernel(const float* __restrict__ dprob, const float* __restrict__ prob, int n,
+                                        float* __restrict__ dlogit) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float pr = prob[i];
+  dlogit[i] = dprob[i] * (1.f - pr) * pr;
+}
+
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ scalar, long numel,
+                                                              float* __restrict__ y) {
+  const float s = scalar[0];
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) y[i] = x[i] * s;
 }
 
 // one thread per 4 consecutive k (channels-last order); loops over the batch
@@ -297,13 +336,13 @@ extern "C" int32_t mpgan_linear1_partials(int32_t n) { return n * LIN_CHUNKS; }
 
 extern "C" int mpgan_linear1_forward(const float* z, const mpgan_prologue* p, int32_t n, int64_t P, int32_t c,
                                      const float* w_perm, const float* bias, float* partials, float* logit,
-                                     void* stream) {
+                                     float* prob, void* stream) {
   MPGAN_CHECK_ARG(z && w_perm && partials && logit && n > 0 && P > 0 && c > 0, "linear1_forward: bad argument");
   MPGAN_UNSUPPORTED(c % 4 != 0 || !al16(z) || !al16(w_perm), "linear1_forward: needs C %% 4 == 0 and 16-B alignment");
   hipLaunchKernelGGL(linear1_partial_kernel, dim3(LIN_CHUNKS, n), dim3(256), 0, (hipStream_t)stream, z, make_pro(p),
                      (long)P, c, w_perm, partials);
   hipLaunchKernelGGL(linear1_final_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, partials, bias, n,
-                     logit);
+                     logit, prob);
   return check_launch("linear1_forward");
 }
 
@@ -326,6 +365,35 @@ extern "C" int mpgan_sigmoid_bce(const float* logit, int32_t n, float target, fl
   hipLaunchKernelGGL(sigmoid_bce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logit, n, target, loss_scale,
                      prob, loss, dlogit);
   return check_launch("sigmoid_bce");
+}
+
+extern "C" int mpgan_bce_forward(const float* prob, const float* target, int32_t n, float* loss, void* stream) {
+  MPGAN_CHECK_ARG(prob && target && loss && n > 0, "bce_forward: bad argument");
+  hipLaunchKernelGGL(bce_forward_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, prob, target, n, loss);
+  return check_launch("bce_forward");
+}
+
+extern "C" int mpgan_bce_backward(const float* prob, const float* target, int32_t n, const float* gout, float* dprob,
+                                  void* stream) {
+  MPGAN_CHECK_ARG(prob && target && gout && dprob && n > 0, "bce_backward: bad argument");
+  hipLaunchKernelGGL(bce_backward_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, prob, target, n,
+                     gout, dprob);
+  return check_launch("bce_backward");
+}
+
+extern "C" int mpgan_sigmoid_backward(const float* dprob, const float* prob, int32_t n, float* dlogit, void* stream) {
+  MPGAN_CHECK_ARG(dprob && prob && dlogit && n > 0, "sigmoid_backward: bad argument");
+  hipLaunchKernelGGL(sigmoid_backward_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dprob, prob, n,
+                     dlogit);
+  return check_launch("sigmoid_backward");
+}
+
+extern "C" int mpgan_scale_by_device_scalar(const float* x, const float* scalar, int64_t numel, float* y,
+                                            void* stream) {
+  MPGAN_CHECK_ARG(x && scalar && y && numel > 0, "scale_by_device_scalar: bad argument");
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(ew_blocks2(numel)), dim3(256), 0, (hipStream_t)stream, x, scalar,
+                     (long)numel, y);
+  return check_launch("scale_by_device_scalar");
 }
 
 extern "C" int32_t mpgan_l1_partials(void) { return L1_PARTIALS; }

@@ -246,13 +246,14 @@ __global__ __launch_bounds__(256) void norm_act_add_kernel(const float* __restri
 }
 
 template <int V>
-__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ gr, int ldg,
+// gr and dz may alias (in-place): every element is read before it is written by the same thread.
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* gr, int ldg,
                                                              const float* __restrict__ z, int ldz, Pro p,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
                                                              const float* __restrict__ c1,
                                                              const float* __restrict__ c2, long rows, long P, int C,
-                                                             float* __restrict__ dz, int lddz) {
+                                                             float* dz, int lddz) {
   const int CG = C / V;
   const long total = rows * CG;
   const float slope = pro_slope(p);

@@ -1,0 +1,741 @@
+"""Execution plans for the GAN hot path: pre-bound sequences of C-ABI calls.
+
+A *plan* owns every activation / gradient buffer one forward (+ backward) of a
+network needs for a fixed (batch, spatial) shape, and two *programs*: lists of
+(C function, argument tuple) built once.  Running a network is a tight loop of
+ctypes calls on the current stream -- no per-op Python logic, no per-op
+allocation, graph-capturable.  Data layout in HBM: channels-last
+(N, D, H, W, C) fp32; concatenations are channel slices of one buffer that the
+producers write directly; only RAW conv outputs + per-channel norm vectors are
+kept (BatchNorm/InstanceNorm + PReLU/LeakyReLU are applied by the consumer's
+load prologue).
+
+Graph of one U-Net follows MONAI 0.4.0 `UNet(num_res_units=2)` as the reference
+instantiates it (code/GAN/GAN_final.py:106-114); the
+discriminator follows code/GAN/GAN_final.py:159-209.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import lib
+from .ops import ACT_LEAKY, ACT_NONE, ConvGeom, Prologue
+
+
+# --------------------------------------------------------------------------
+# programs
+# --------------------------------------------------------------------------
+class Program:
+    """A frozen list of C calls; `run` appends the stream and checks status."""
+    __slots__ = ("calls", "keep", "names")
+
+    def __init__(self):
+        self.calls = []
+        self.keep = []
+        self.names = []
+
+    def add(self, name, fn, *args, keep=()):
+        self.calls.append((fn, args))
+        self.names.append(name)
+        self.keep.append(keep)
+
+    def run(self, stream=None):
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        for i, (fn, args) in enumerate(self.calls):
+            rc = fn(*args, s)
+            if rc:
+                raise RuntimeError(f"{self.names[i]} failed (status {rc}): {lib().mpgan_last_error().decode()}")
+
+    def __len__(self):
+        return len(self.calls)
+
+
+def _ld(t):
+    return 0 if t is None else ops._cl(t, "plan tensor")[2]
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------
+# parameter storage
+# --------------------------------------------------------------------------
+class ConvRec:
+    """One conv / transposed conv / linear-as-conv weight in the flat store."""
+    __slots__ = ("mod", "transposed", "cout", "cin", "taps", "w_off", "fwd_off", "bwd_off")
+
+
+class ParamStore:
+    """All parameters of a network as views of ONE flat fp32 buffer (+ a flat
+    gradient buffer the kernels accumulate into, the buffer RCCL all-reduces and
+    the fused Adam steps over) and the packed [Cout][tap][Cin] conv weights."""
+
+    def __init__(self, module: nn.Module):
+        self.module = module
+        self.convs: List[ConvRec] = []
+        self._by_mod = {}
+        self.flat = None
+        self.flat_grad = None
+        self.packed = None
+        self.table = None
+        self.version = 0
+        self.frozen = False
+        self.flatten()
+        for m in module.modules():
+            if isinstance(m, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d, nn.ConvTranspose3d)):
+                tr = isinstance(m, (nn.ConvTranspose2d, nn.ConvTranspose3d))
+                taps = 1
+                for k in m.kernel_size:
+                    taps *= k
+                self.register_conv(m, cout=m.out_channels, cin=m.in_channels, taps=taps, transposed=tr)
+
+    def flatten(self):
+        params = list(self.module.parameters())
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            total = (total + 3) // 4 * 4  # keep every tensor 16-byte aligned
+            offs.append(total)
+            total += p.numel()
+        total = (total + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._off = {}
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = flat[o:o + p.numel()].view(p.shape)
+                p.grad = grad[o:o + p.numel()].view(p.shape)
+                self._off[id(p)] = o
+        self.flat, self.flat_grad = flat, grad
+        self._params = params
+        self.version += 1
+        self._build_pack_table()
+
+    def attach_grads(self):
+        """Re-point .grad at the flat gradient views (an optimizer's
+        zero_grad(set_to_none=True) detaches them)."""
+        for p in self._params:
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * self._off[id(p)]:
+                o = self._off[id(p)]
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def offset(self, p) -> int:
+        return self._off[id(p)]
+
+    def grad_view(self, p) -> torch.Tensor:
+        o = self._off[id(p)]
+        return self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def register_conv(self, mod, *, cout, cin, taps, transposed=False):
+        """Register a weight for packing.  All weights must be registered before
+        the first plan is built (packed offsets are baked into the programs)."""
+        if id(mod) in self._by_mod:
+            r = self._by_mod[id(mod)]
+            assert (r.cout, r.cin, r.taps, r.transposed) == (cout, cin, taps, transposed)
+            return r
+        if self.frozen:
+            raise RuntimeError("ParamStore: conv registered after plans were built")
+        r = ConvRec()
+        r.mod, r.transposed, r.cout, r.cin, r.taps = mod, transposed, cout, cin, taps
+        self.convs.append(r)
+        self._by_mod[id(mod)] = r
+        if self.flat is not None:
+            self._build_pack_table()
+        return r
+
+    def _build_pack_table(self):
+        if not self.convs:
+            return
+        rows, off = [], 0
+        for r in self.convs:
+            n = r.cout * r.cin * r.taps
+            assert r.mod.weight.numel() == n, (r.mod, n)
+            r.w_off = self.offset(r.mod.weight)
+            r.fwd_off = off
+            off += (n + 3) // 4 * 4
+            r.bwd_off = off
+            off += (n + 3) // 4 * 4
+            rows.append([r.w_off, r.fwd_off, r.cout, r.cin, r.taps, int(r.transposed), 0, 0])
+            rows.append([r.w_off, r.bwd_off, r.cout, r.cin, r.taps, int(r.transposed), 1, 0])
+        dev = self.flat.device
+        self.packed = torch.empty(off, dtype=torch.float32, device=dev)
+        self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self._max_elems = max(r.cout * r.cin * r.taps for r in self.convs)
+
+    def emit_pack(self, prog: Program):
+        self.frozen = True
+        prog.add("pack_weights", lib().mpgan_pack_weights, self.flat.data_ptr(), self.packed.data_ptr(),
+                 self.table.data_ptr(), self.table.shape[0], self._max_elems, keep=(self.flat, self.packed, self.table))
+
+    def wp(self, rec: ConvRec) -> torch.Tensor:
+        return self.packed[rec.fwd_off:rec.fwd_off + rec.cout * rec.cin * rec.taps]
+
+    def wp_bwd(self, rec: ConvRec) -> torch.Tensor:
+        return self.packed[rec.bwd_off:rec.bwd_off + rec.cout * rec.cin * rec.taps]
+
+
+# --------------------------------------------------------------------------
+# emit helpers
+# --------------------------------------------------------------------------
+class NormBuf:
+    """Device vectors of one norm layer in one plan."""
+
+    def __init__(self, n, c, instance, dev):
+        m = n * c if instance else c
+        mm = (m + 3) // 4 * 4
+        buf = torch.zeros(6, mm, device=dev)
+        self.scale, self.shift, self.mean, self.invstd, self.c1, self.c2 = (buf[i, :m] for i in range(6))
+        self.n, self.c, self.instance = n, c, instance
+
+    def prologue(self, act, slope=1.0, slope_t=None) -> Prologue:
+        return Prologue(self.scale, self.shift, self.c if self.instance else 0, act, slope, slope_t)
+
+
+def emit_conv_fwd(prog, g: ConvGeom, x, wp, bias, y, pro=None, resid=None, tanh=False):
+    ops._check_in_out(g, x, y, "plan conv_forward")
+    gc = g.c()
+    pc = pro.c() if pro is not None else None
+    prog.add("conv_forward", lib().mpgan_conv_forward, C.byref(gc), x.data_ptr(), _ld(x), wp.data_ptr(), _p(bias),
+             C.byref(pc) if pc is not None else None, _p(resid), _ld(resid), int(tanh), y.data_ptr(), _ld(y),
+             keep=(gc, pc, x, wp, bias, y, resid, pro))
+
+
+def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):
+    ops._check_in_out(g, dx, dy, "plan conv_backward_data")
+    gc = g.c()
+    prog.add("conv_backward_data", lib().mpgan_conv_backward_data, C.byref(gc), dy.data_ptr(), _ld(dy),
+             wp_bwd.data_ptr(), _p(resid), _ld(resid), dx.data_ptr(), _ld(dx), keep=(gc, dy, wp_bwd, dx, resid))
+
+
+def emit_conv_wgrad(prog, g: ConvGeom, x, dy, dw, ws, pro=None):
+    ops._check_in_out(g, x, dy, "plan conv_backward_weight")
+    gc = g.c()
+    pc = pro.c() if pro is not None else None
+    need = ops.conv_wgrad_workspace(g)
+    assert ws.numel() * 4 >= need, "wgrad workspace too small"
+    prog.add("conv_backward_weight", lib().mpgan_conv_backward_weight, C.byref(gc), x.data_ptr(), _ld(x),
+             C.byref(pc) if pc is not None else None, dy.data_ptr(), _ld(dy), dw.data_ptr(), 1.0, ws.data_ptr(),
+             ws.numel() * 4, keep=(gc, pc, x, dy, dw, ws, pro))
+
+
+def emit_bias_grad(prog, dy, db, partials):
+    """db += column sums of dy (two-stage, deterministic)."""
+    n, P, ld = ops._cl(dy, "bias grad")
+    c = dy.shape[-1]
+    chunks = ops.stats_chunks(P, c)
+    assert partials.numel() >= n * chunks * 2 * c
+    L = lib()
+    prog.add("channel_stats", L.mpgan_channel_stats, dy.data_ptr(), ld, n, P, c, partials.data_ptr(),
+             keep=(dy, partials))
+    prog.add("reduce_partials", L.mpgan_reduce_partials, partials.data_ptr(), n * chunks, 2 * c, c, db.data_ptr(), 1.0,
+             keep=(db,))
+
+
+def emit_norm_stats(prog, z, nb: NormBuf, norm_mod, partials, eps=1e-5, momentum=0.1):
+    """channel_stats + finalize: scale/shift for the consumer's prologue; running
+    stats updated in place (BatchNorm, train mode)."""
+    n, P, ld = ops._cl(z, "norm stats")
+    c = z.shape[-1]
+    chunks = ops.stats_chunks(P, c)
+    assert partials.numel() >= n * chunks * 2 * c
+    L = lib()
+    rm = getattr(norm_mod, "running_mean", None)
+    rv = getattr(norm_mod, "running_var", None)
+    nbt = getattr(norm_mod, "num_batches_tracked", None)
+    eps = getattr(norm_mod, "eps", eps)
+    momentum = getattr(norm_mod, "momentum", momentum)
+    if nb.instance:
+        rm = rv = nbt = None
+    prog.add("channel_stats", L.mpgan_channel_stats, z.data_ptr(), ld, n, P, c, partials.data_ptr(),
+             keep=(z, partials))
+    prog.add("norm_finalize", L.mpgan_norm_finalize, partials.data_ptr(), n, chunks, c, P, int(nb.instance),
+             _p(norm_mod.weight), _p(norm_mod.bias), float(eps), float(momentum), _p(rm), _p(rv), _p(nbt),
+             nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
+             keep=(norm_mod.weight, norm_mod.bias, rm, rv, nbt, nb))
+
+
+def emit_norm_act_add(prog, z, pz, r, pr, out, tanh=False):
+    n, P, ldz = ops._cl(z, "norm_act_add z")
+    assert out.shape == z.shape and (r is None or r.shape == z.shape)
+    pzc = pz.c() if pz is not None else None
+    prc = pr.c() if pr is not None else None
+    prog.add("norm_act_add", lib().mpgan_norm_act_add, z.data_ptr(), ldz, C.byref(pzc) if pzc else None, _p(r), _ld(r),
+             C.byref(prc) if prc else None, n, P, z.shape[-1], int(tanh), out.data_ptr(), _ld(out),
+             keep=(z, pzc, pz, r, prc, pr, out))
+
+
+def emit_norm_bwd(prog, g, z, nb: NormBuf, pro: Prologue, dz, partials, dgamma, dbeta, dslope):
+    """reduce -> finalize -> apply.  dgamma/dbeta/dslope are gradient views
+    (accumulated into) or None when the owner's parameters are frozen."""
+    n, P, ldz = ops._cl(z, "norm_bwd z")
+    assert g.shape == z.shape and dz.shape == z.shape
+    c = z.shape[-1]
+    chunks = ops.stats_chunks(P, c)
+    assert partials.numel() >= n * chunks * 3 * c
+    L = lib()
+    pc = pro.c()
+    prog.add("norm_bwd_reduce", L.mpgan_norm_bwd_reduce, g.data_ptr(), _ld(g), z.data_ptr(), ldz, C.byref(pc),
+             nb.mean.data_ptr(), nb.invstd.data_ptr(), n, P, c, partials.data_ptr(), keep=(g, z, pc, pro, nb, partials))
+    prog.add("norm_bwd_finalize", L.mpgan_norm_bwd_finalize, partials.data_ptr(), n, chunks, c, P, int(nb.instance),
+             _p(dgamma), _p(dbeta), _p(dslope), nb.c1.data_ptr(), nb.c2.data_ptr(), keep=(dgamma, dbeta, dslope))
+    prog.add("norm_bwd_apply", L.mpgan_norm_bwd_apply, g.data_ptr(), _ld(g), z.data_ptr(), ldz, C.byref(pc),
+             nb.mean.data_ptr(), nb.invstd.data_ptr(), nb.c1.data_ptr(), nb.c2.data_ptr(), n, P, c, dz.data_ptr(),
+             _ld(dz), keep=(dz,))
+
+
+def _t3(v, dims, fill):
+    v = (v,) * dims if isinstance(v, int) else tuple(v)
+    return (fill,) * (3 - dims) + tuple(v)
+
+
+def conv_geom_of(mod, n, in_dhw, dims) -> ConvGeom:
+    """Geometry of an nn.ConvNd / nn.ConvTransposeNd module at a given input size."""
+    tr = isinstance(mod, (nn.ConvTranspose2d, nn.ConvTranspose3d))
+    k, s, p = _t3(mod.kernel_size, dims, 1), _t3(mod.stride, dims, 1), _t3(mod.padding, dims, 0)
+    op = _t3(mod.output_padding, dims, 0) if tr else (0, 0, 0)
+    return ConvGeom(n, tuple(in_dhw), mod.in_channels, mod.out_channels, k, s, p, tr, op)
+
+
+class Scratch:
+    """Grow-only scratch shared by the plans of one network (partials, wgrad slabs)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.partials_need = 0
+        self.ws_need = 0
+        self.partials = None
+        self.ws = None
+
+    def want_partials(self, n, P, c):
+        self.partials_need = max(self.partials_need, n * ops.stats_chunks(P, c) * 3 * c)
+
+    def want_ws(self, g: ConvGeom):
+        self.ws_need = max(self.ws_need, ops.conv_wgrad_workspace(g) // 4)
+
+    def alloc(self):
+        self.partials = torch.empty(max(self.partials_need, 4), device=self.dev)
+        self.ws = torch.empty(max(self.ws_need, 4), device=self.dev)
+
+
+# --------------------------------------------------------------------------
+# residual U-Net
+# --------------------------------------------------------------------------
+class _RU:
+    """Handles into one ResidualUnit's parameter modules."""
+
+    def __init__(self, ru):
+        self.units = []
+        for unit in ru.conv:
+            adn = getattr(unit, "adn", None)
+            self.units.append((unit.conv, adn.N if adn is not None else None, adn.A if adn is not None else None))
+        self.res = ru.residual if not isinstance(ru.residual, nn.Identity) else None
+
+
+class UNetPlan:
+    """Forward/backward programs of one residual U-Net for a fixed input shape."""
+
+    def __init__(self, unet, store: ParamStore, n: int, spatial: Sequence[int], x_in, y_out, *, tanh_out: bool,
+                 instance: bool, want_backward: bool, gbufs: Optional[dict], scratch: Scratch):
+        self.unet, self.store, self.n = unet, store, n
+        dims = unet.dimensions
+        self.dims = dims
+        dev = x_in.device
+        chans = list(unet.channels)
+        L = len(chans)                      # levels incl. bottom
+        strides = list(unet.strides)[:L - 1]
+        dhw0 = _t3(spatial, dims, 1)
+        for d in range(3 - dims, 3):
+            if dhw0[d] % (2 ** (L - 1)) != 0:
+                raise ValueError(f"U-Net input extent {dhw0[d]} is not divisible by {2 ** (L - 1)}")
+        # walk the module tree: level l = (down RU, up Sequential); last = bottom RU
+        downs, ups = [], []
+        blk = unet.model
+        while True:
+            downs.append(_RU(blk[0]))
+            ups.append(blk[2])
+            sub = blk[1].submodule
+            if isinstance(sub, nn.Sequential):
+                blk = sub
+            else:
+                bottom = _RU(sub)
+                break
+        assert len(downs) == L - 1
+        self.fwd, self.bwd = Program(), Program()
+        f = self.fwd
+        E = lambda *shape: torch.empty(*shape, device=dev)
+
+        def reg(conv):
+            tr = isinstance(conv, (nn.ConvTranspose2d, nn.ConvTranspose3d))
+            taps = 1
+            for k in conv.kernel_size:
+                taps *= k
+            return store.register_conv(conv, cout=conv.out_channels, cin=conv.in_channels, taps=taps, transposed=tr)
+
+        def prelu_pro(nb, A):
+            return nb.prologue(ACT_LEAKY, 1.0, A.weight)
+
+        # ---- shapes ----
+        sizes = [dhw0]
+        in_ch = [1] + chans[:L - 2]          # input channels of down level l
+        geoms_down = []
+        for l in range(L - 1):
+            g0 = conv_geom_of(downs[l].units[0][0], n, sizes[l], dims)
+            geoms_down.append(g0)
+            sizes.append(g0.out_dhw)
+        sub_out = [chans[l] for l in range(L - 2)] + [chans[L - 1]]  # channels appended to cat_l
+        self.saved = []
+        cats = [E(n, *sizes[l + 1], chans[l] + sub_out[l]) for l in range(L - 1)]
+        self.cats = cats
+        recs = {}
+
+        def R(conv):
+            if id(conv) not in recs:
+                recs[id(conv)] = reg(conv)
+            return recs[id(conv)]
+
+        # ================= forward =================
+        down_state = []
+        for l in range(L - 1):
+            ru = downs[l]
+            xin = x_in if l == 0 else cats[l - 1][..., :chans[l - 1]]
+            c = chans[l]
+            (cv0, N0, A0), (cv1, N1, A1) = ru.units
+            g0 = geoms_down[l]
+            g1 = conv_geom_of(cv1, n, sizes[l + 1], dims)
+            gr = conv_geom_of(ru.res, n, sizes[l], dims)
+            z0, z1, r = E(n, *sizes[l + 1], c), E(n, *sizes[l + 1], c), E(n, *sizes[l + 1], c)
+            nb0, nb1 = NormBuf(n, c, instance, dev), NormBuf(n, c, instance, dev)
+            P = sizes[l + 1][0] * sizes[l + 1][1] * sizes[l + 1][2]
+            scratch.want_partials(n, P, c)
+            for g in (g0, g1, gr):
+                scratch.want_ws(g)
+            down_state.append(dict(xin=xin, z0=z0, z1=z1, r=r, nb0=nb0, nb1=nb1, g0=g0, g1=g1, gr=gr, ru=ru, c=c))
+        # bottom
+        cb_in, cb = chans[L - 2], chans[L - 1]
+        (bc0, BN0, BA0), (bc1, BN1, BA1) = bottom.units
+        sb = sizes[L - 1]
+        gb0 = conv_geom_of(bc0, n, sb, dims)
+        gb1 = conv_geom_of(bc1, n, sb, dims)
+        gbr = conv_geom_of(bottom.res, n, sb, dims)
+        zb0, zb1, rb = E(n, *sb, cb), E(n, *sb, cb), E(n, *sb, cb)
+        nbb0, nbb1 = NormBuf(n, cb, instance, dev), NormBuf(n, cb, instance, dev)
+        scratch.want_partials(n, sb[0] * sb[1] * sb[2], cb)
+        for g in (gb0, gb1, gbr):
+            scratch.want_ws(g)
+        # up
+        up_state = []
+        out_ch = in_ch                        # output channels of up level l == input channels of down level l
+        for l in range(L - 1):
+            convT_blk, ru_mod = ups[l][0], _RU(ups[l][1])
+            ct, NT, AT = convT_blk.conv, convT_blk.adn.N, convT_blk.adn.A
+            co = out_ch[l]
+            gt = conv_geom_of(ct, n, sizes[l + 1], dims)
+            assert gt.out_dhw == tuple(sizes[l]), (gt.out_dhw, sizes[l])
+            cu, NU, AU = ru_mod.units[0]
+            gu = conv_geom_of(cu, n, sizes[l], dims)
+            zt = E(n, *sizes[l], co)
+            nbt = NormBuf(n, co, instance, dev)
+            P = sizes[l][0] * sizes[l][1] * sizes[l][2]
+            scratch.want_partials(n, P, co)
+            scratch.want_ws(gt)
+            scratch.want_ws(gu)
+            st = dict(ct=ct, NT=NT, AT=AT, cu=cu, NU=NU, AU=AU, gt=gt, gu=gu, zt=zt, nbt=nbt, co=co)
+            if NU is not None:
+                st["zu"] = E(n, *sizes[l], co)
+                st["nbu"] = NormBuf(n, co, instance, dev)
+            else:
+                st["ua"] = E(n, *sizes[l], co)
+            up_state.append(st)
+        self._late = (down_state, up_state)
+        self.scratch = scratch
+        self._build_args = dict(x_in=x_in, y_out=y_out, tanh_out=tanh_out, want_backward=want_backward, gbufs=gbufs,
+                                chans=chans, L=L, sizes=sizes, in_ch=in_ch, sub_out=sub_out, cats=cats, R=R,
+                                bottom=dict(bc0=bc0, BN0=BN0, BA0=BA0, bc1=bc1, BN1=BN1, BA1=BA1, res=bottom.res,
+                                            gb0=gb0, gb1=gb1, gbr=gbr, zb0=zb0, zb1=zb1, rb=rb, nbb0=nbb0, nbb1=nbb1,
+                                            cb=cb, cb_in=cb_in),
+                                prelu_pro=prelu_pro, instance=instance)
+
+    # programs are emitted after the shared scratch has been sized and allocated
+    def emit(self):
+        a = self._build_args
+        down_state, up_state = self._late
+        store, scratch = self.store, self.scratch
+        part, ws = scratch.partials, scratch.ws
+        f, b = self.fwd, self.bwd
+        R, prelu_pro = a["R"], a["prelu_pro"]
+        chans, L, sizes, cats = a["chans"], a["L"], a["sizes"], a["cats"]
+        x_in, y_out = a["x_in"], a["y_out"]
+        bt = a["bottom"]
+        wp, wpb = store.wp, store.wp_bwd
+
+        # ================= forward =================
+        for l in range(L - 1):
+            s = down_state[l]
+            (cv0, N0, A0), (cv1, N1, A1) = s["ru"].units
+            emit_conv_fwd(f, s["g0"], s["xin"], wp(R(cv0)), cv0.bias, s["z0"])
+            emit_conv_fwd(f, s["gr"], s["xin"], wp(R(s["ru"].res)), s["ru"].res.bias, s["r"])
+            emit_norm_stats(f, s["z0"], s["nb0"], N0, part)
+            emit_conv_fwd(f, s["g1"], s["z0"], wp(R(cv1)), cv1.bias, s["z1"], pro=prelu_pro(s["nb0"], A0))
+            emit_norm_stats(f, s["z1"], s["nb1"], N1, part)
+            emit_norm_act_add(f, s["z1"], prelu_pro(s["nb1"], A1), s["r"], None, cats[l][..., :s["c"]])
+        d_last = cats[L - 2][..., :bt["cb_in"]]
+        emit_conv_fwd(f, bt["gb0"], d_last, wp(R(bt["bc0"])), bt["bc0"].bias, bt["zb0"])
+        emit_conv_fwd(f, bt["gbr"], d_last, wp(R(bt["res"])), bt["res"].bias, bt["rb"])
+        emit_norm_stats(f, bt["zb0"], bt["nbb0"], bt["BN0"], part)
+        emit_conv_fwd(f, bt["gb1"], bt["zb0"], wp(R(bt["bc1"])), bt["bc1"].bias, bt["zb1"],
+                      pro=prelu_pro(bt["nbb0"], bt["BA0"]))
+        emit_norm_stats(f, bt["zb1"], bt["nbb1"], bt["BN1"], part)
+        emit_norm_act_add(f, bt["zb1"], prelu_pro(bt["nbb1"], bt["BA1"]), bt["rb"], None,
+                          cats[L - 2][..., bt["cb_in"]:])
+        for l in range(L - 2, -1, -1):
+            u = up_state[l]
+            emit_conv_fwd(f, u["gt"], cats[l], wp(R(u["ct"])), u["ct"].bias, u["zt"])
+            emit_norm_stats(f, u["zt"], u["nbt"], u["NT"], part)
+            pt = prelu_pro(u["nbt"], u["AT"])
+            if "zu" in u:
+                emit_conv_fwd(f, u["gu"], u["zt"], wp(R(u["cu"])), u["cu"].bias, u["zu"], pro=pt)
+                emit_norm_stats(f, u["zu"], u["nbu"], u["NU"], part)
+                dst = cats[l - 1][..., chans[l - 1]:] if l > 0 else y_out
+                emit_norm_act_add(f, u["zu"], prelu_pro(u["nbu"], u["AU"]), u["zt"], pt, dst,
+                                  tanh=(a["tanh_out"] and l == 0))
+            else:
+                # top level: conv-only residual unit on the materialised act(bn(zt))
+                emit_norm_act_add(f, u["zt"], pt, None, None, u["ua"])
+                emit_conv_fwd(f, u["gu"], u["ua"], wp(R(u["cu"])), u["cu"].bias, y_out, resid=u["ua"],
+                              tanh=a["tanh_out"])
+        if not a["want_backward"]:
+            return
+
+        # ================= backward =================
+        G = a["gbufs"]                       # shared gradient scratch (see GeneratorPlan)
+        gv = store.grad_view
+        g_out, g_x = G["g_out"], G["g_x"]
+        # ---- up path, top to bottom of the U ----
+        for l in range(0, L - 1):
+            u = up_state[l]
+            pt = prelu_pro(u["nbt"], u["AT"])
+            g_u = g_out if l == 0 else G["gcat"][l - 1][..., chans[l - 1]:]
+            if "zu" in u:
+                dzu, gta = G["dzu"][l], G["gta"][l]
+                emit_norm_bwd(b, g_u, u["zu"], u["nbu"], prelu_pro(u["nbu"], u["AU"]), dzu, part,
+                              gv(u["NU"].weight), gv(u["NU"].bias), gv(u["AU"].weight))
+                emit_bias_grad(b, dzu, gv(u["cu"].bias), part)
+                emit_conv_wgrad(b, u["gu"], u["zt"], dzu, gv(u["cu"].weight), ws, pro=pt)
+                emit_conv_dgrad(b, u["gu"], dzu, wpb(R(u["cu"])), gta, resid=g_u)
+            else:
+                gta = G["gta"][l]
+                emit_bias_grad(b, g_u, gv(u["cu"].bias), part)
+                emit_conv_wgrad(b, u["gu"], u["ua"], g_u, gv(u["cu"].weight), ws)
+                emit_conv_dgrad(b, u["gu"], g_u, wpb(R(u["cu"])), gta, resid=g_u)
+            emit_norm_bwd(b, gta, u["zt"], u["nbt"], pt, gta, part, gv(u["NT"].weight), gv(u["NT"].bias),
+                          gv(u["AT"].weight))
+            emit_bias_grad(b, gta, gv(u["ct"].bias), part)
+            emit_conv_wgrad(b, u["gt"], cats[l], gta, gv(u["ct"].weight), ws)
+            emit_conv_dgrad(b, u["gt"], gta, wpb(R(u["ct"])), G["gcat"][l])
+        # ---- bottom ----
+        gcat_last = G["gcat"][L - 2]
+        g_b = gcat_last[..., bt["cb_in"]:]
+        gd_last = gcat_last[..., :bt["cb_in"]]
+        d_last = cats[L - 2][..., :bt["cb_in"]]
+        dzb1, gab0 = G["dzb1"], G["gab0"]
+        emit_norm_bwd(b, g_b, bt["zb1"], bt["nbb1"], prelu_pro(bt["nbb1"], bt["BA1"]), dzb1, part,
+                      gv(bt["BN1"].weight), gv(bt["BN1"].bias), gv(bt["BA1"].weight))
+        emit_bias_grad(b, dzb1, gv(bt["bc1"].bias), part)
+        emit_conv_wgrad(b, bt["gb1"], bt["zb0"], dzb1, gv(bt["bc1"].weight), ws, pro=prelu_pro(bt["nbb0"], bt["BA0"]))
+        emit_conv_dgrad(b, bt["gb1"], dzb1, wpb(R(bt["bc1"])), gab0)
+        emit_norm_bwd(b, gab0, bt["zb0"], bt["nbb0"], prelu_pro(bt["nbb0"], bt["BA0"]), gab0, part,
+                      gv(bt["BN0"].weight), gv(bt["BN0"].bias), gv(bt["BA0"].weight))
+        emit_bias_grad(b, gab0, gv(bt["bc0"].bias), part)
+        emit_conv_wgrad(b, bt["gb0"], d_last, gab0, gv(bt["bc0"].weight), ws)
+        emit_bias_grad(b, g_b, gv(bt["res"].bias), part)
+        emit_conv_wgrad(b, bt["gbr"], d_last, g_b, gv(bt["res"].weight), ws)
+        emit_conv_dgrad(b, bt["gb0"], gab0, wpb(R(bt["bc0"])), gd_last, resid=gd_last)
+        emit_conv_dgrad(b, bt["gbr"], g_b, wpb(R(bt["res"])), gd_last, resid=gd_last)
+        # ---- down path, bottom to top ----
+        for l in range(L - 2, -1, -1):
+            s = down_state[l]
+            (cv0, N0, A0), (cv1, N1, A1) = s["ru"].units
+            g_d = G["gcat"][l][..., :s["c"]]
+            dz1, ga0 = G["dz1"][l], G["ga0"][l]
+            emit_norm_bwd(b, g_d, s["z1"], s["nb1"], prelu_pro(s["nb1"], A1), dz1, part, gv(N1.weight), gv(N1.bias),
+                          gv(A1.weight))
+            emit_bias_grad(b, dz1, gv(cv1.bias), part)
+            emit_conv_wgrad(b, s["g1"], s["z0"], dz1, gv(cv1.weight), ws, pro=prelu_pro(s["nb0"], A0))
+            emit_conv_dgrad(b, s["g1"], dz1, wpb(R(cv1)), ga0)
+            emit_norm_bwd(b, ga0, s["z0"], s["nb0"], prelu_pro(s["nb0"], A0), ga0, part, gv(N0.weight), gv(N0.bias),
+                          gv(A0.weight))
+            emit_bias_grad(b, ga0, gv(cv0.bias), part)
+            emit_conv_wgrad(b, s["g0"], s["xin"], ga0, gv(cv0.weight), ws)
+            emit_bias_grad(b, g_d, gv(s["ru"].res.bias), part)
+            emit_conv_wgrad(b, s["gr"], s["xin"], g_d, gv(s["ru"].res.weight), ws)
+            if l > 0:
+                tgt = G["gcat"][l - 1][..., :chans[l - 1]]
+                emit_conv_dgrad(b, s["g0"], ga0, wpb(R(cv0)), tgt, resid=tgt)
+                emit_conv_dgrad(b, s["gr"], g_d, wpb(R(s["ru"].res)), tgt, resid=tgt)
+            elif g_x is not None:
+                emit_conv_dgrad(b, s["g0"], ga0, wpb(R(cv0)), g_x)
+                emit_conv_dgrad(b, s["gr"], g_d, wpb(R(s["ru"].res)), g_x, resid=g_x)
+
+
+class GeneratorPlan:
+    """CasNet: chain of U-Nets + Tanh (code/GAN/GAN_final.py:92-122)."""
+
+    def __init__(self, gen, store: ParamStore, n: int, spatial: Sequence[int], *, want_backward: bool,
+                 want_input_grad: bool, instance: bool):
+        unets = [m for m in gen.model if not isinstance(m, nn.Tanh)]
+        dims = unets[0].dimensions
+        dev = store.flat.device
+        dhw = _t3(spatial, dims, 1)
+        self.n, self.dhw, self.dims = n, dhw, dims
+        self.store = store
+        E = lambda *shape: torch.empty(*shape, device=dev)
+        self.acts = [E(n, *dhw, 1) for _ in range(len(unets) + 1)]   # x0 .. y
+        self.x_in, self.y = self.acts[0], self.acts[-1]
+        self.scratch = Scratch(dev)
+        self.want_backward = want_backward
+        chans = list(unets[0].channels)
+        L = len(chans)
+        gb = None
+        if want_backward:
+            # gradient scratch shared by all U-Nets (their backwards run one after another)
+            sizes = [dhw]
+            for l in range(L - 1):
+                sizes.append(tuple((s + 1) // 2 if i >= 3 - dims else s for i, s in enumerate(sizes[-1])))
+            in_ch = [1] + chans[:L - 2]
+            sub_out = [chans[l] for l in range(L - 2)] + [chans[L - 1]]
+            gb = dict(
+                gcat=[E(n, *sizes[l + 1], chans[l] + sub_out[l]) for l in range(L - 1)],
+                dzu=[E(n, *sizes[l], in_ch[l]) for l in range(L - 1)],
+                gta=[E(n, *sizes[l], in_ch[l]) for l in range(L - 1)],
+                dz1=[E(n, *sizes[l + 1], chans[l]) for l in range(L - 1)],
+                ga0=[E(n, *sizes[l + 1], chans[l]) for l in range(L - 1)],
+                dzb1=E(n, *sizes[L - 1], chans[L - 1]), gab0=E(n, *sizes[L - 1], chans[L - 1]))
+            self.g_acts = [E(n, *dhw, 1) for _ in range(2)]
+            self.g_y = E(n, *dhw, 1)          # upstream gradient dL/dy is copied here
+        self.unet_plans: List[UNetPlan] = []
+        nU = len(unets)
+        for u, unet in enumerate(unets):
+            g = None
+            if want_backward:
+                g = dict(gb)
+                # ping-pong: U-Net u reads g_acts[(u+1)%2] (grad of its output), writes g_acts[u%2]
+                g["g_out"] = self.g_acts[(u + 1) % 2]
+                g["g_x"] = self.g_acts[u % 2] if (u > 0 or want_input_grad) else None
+            self.unet_plans.append(UNetPlan(unet, store, n, spatial, self.acts[u], self.acts[u + 1],
+                                            tanh_out=(u == nU - 1), instance=instance, want_backward=want_backward,
+                                            gbufs=g, scratch=self.scratch))
+        self.scratch.alloc()
+        for p in self.unet_plans:
+            p.emit()
+        self.fwd = Program()
+        store.emit_pack(self.fwd)
+        for p in self.unet_plans:
+            self.fwd.calls += p.fwd.calls
+            self.fwd.names += p.fwd.names
+            self.fwd.keep += p.fwd.keep
+        self.bwd = Program()
+        if want_backward:
+            L_ = lib()
+            last = self.g_acts[nU % 2]        # = g_out of the last U-Net
+            self.bwd.add("tanh_backward", L_.mpgan_tanh_backward, self.g_y.data_ptr(), self.y.data_ptr(),
+                         self.y.numel(), last.data_ptr(), keep=(self.g_y, self.y, last))
+            for p in reversed(self.unet_plans):
+                self.bwd.calls += p.bwd.calls
+                self.bwd.names += p.bwd.names
+                self.bwd.keep += p.bwd.keep
+            self.g_x = self.g_acts[0] if want_input_grad else None
+        self.busy = False
+
+
+# --------------------------------------------------------------------------
+# discriminator (variant A)
+# --------------------------------------------------------------------------
+class DiscPlan:
+    """4 x (valid conv -> BN -> LeakyReLU 0.2) -> Flatten -> Linear(F,1) -> Sigmoid
+    (code/GAN/GAN_final.py:159-209)."""
+
+    def __init__(self, disc, store: ParamStore, n: int, spatial: Sequence[int], *, want_backward: bool,
+                 want_input_grad: bool, want_param_grads: bool):
+        dims = disc.dimensions
+        dev = store.flat.device
+        dhw = _t3(spatial, dims, 1)
+        self.n, self.dhw, self.dims, self.store = n, dhw, dims, store
+        E = lambda *shape: torch.empty(*shape, device=dev)
+        convs = [disc.model_conv[i] for i in (0, 3, 6, 9)]
+        bns = [disc.model_conv[i] for i in (1, 4, 7, 10)]
+        lin = disc.model_linear[1]
+        self.x_in = E(n, *dhw, 1)
+        geoms, zs, nbs, recs = [], [], [], []
+        size = dhw
+        scratch = Scratch(dev)
+        for cv in convs:
+            g = conv_geom_of(cv, n, size, dims)
+            geoms.append(g)
+            size = g.out_dhw
+            if min(size) < 1:
+                raise ValueError(f"discriminator input {spatial} too small")
+            zs.append(E(n, *size, cv.out_channels))
+            nbs.append(NormBuf(n, cv.out_channels, False, dev))
+            taps = 1
+            for k in cv.kernel_size:
+                taps *= k
+            recs.append(store.register_conv(cv, cout=cv.out_channels, cin=cv.in_channels, taps=taps))
+            scratch.want_partials(n, size[0] * size[1] * size[2], cv.out_channels)
+            scratch.want_ws(g)
+        P_last = size[0] * size[1] * size[2]
+        c_last = convs[-1].out_channels
+        if lin.in_features != P_last * c_last:
+            raise ValueError(f"Linear.in_features {lin.in_features} != {c_last}*{P_last} for input {spatial}")
+        rlin = store.register_conv(lin, cout=1, cin=c_last, taps=P_last)
+        scratch.alloc()
+        part, ws = scratch.partials, scratch.ws
+        self.logit, self.prob = E(n), E(n)
+        lin_part = E(ops.linear1_partials(n))
+        L = lib()
+        f = self.fwd = Program()
+        store.emit_pack(f)
+        lrelu = lambda nb: nb.prologue(ACT_LEAKY, 0.2, None)
+        src, pro = self.x_in, None
+        for i, cv in enumerate(convs):
+            emit_conv_fwd(f, geoms[i], src, store.wp(recs[i]), cv.bias, zs[i], pro=pro)
+            emit_norm_stats(f, zs[i], nbs[i], bns[i], part)
+            src, pro = zs[i], lrelu(nbs[i])
+        pc = pro.c()
+        f.add("linear1_forward", L.mpgan_linear1_forward, zs[-1].data_ptr(), C.byref(pc), n, P_last, c_last,
+              store.wp(rlin).data_ptr(), lin.bias.data_ptr(), lin_part.data_ptr(), self.logit.data_ptr(),
+              self.prob.data_ptr(), keep=(pc, pro, lin_part))
+        self.busy = False
+        self.bwd = Program()
+        self.g_x = None
+        if not want_backward:
+            return
+        b = self.bwd
+        gv = store.grad_view if want_param_grads else (lambda p: None)
+        self.g_prob = E(n)
+        dlogit = E(n)
+        gas = [E(*z.shape) for z in zs]
+        b.add("sigmoid_backward", L.mpgan_sigmoid_backward, self.g_prob.data_ptr(), self.prob.data_ptr(), n,
+              dlogit.data_ptr(), keep=(dlogit,))
+        b.add("linear1_backward", L.mpgan_linear1_backward, zs[-1].data_ptr(), C.byref(pc), n, P_last, c_last,
+              store.wp(rlin).data_ptr(), dlogit.data_ptr(), gas[-1].data_ptr(), _p(gv(lin.weight)), _p(gv(lin.bias)),
+              1.0, keep=(gas,))
+        for i in range(3, -1, -1):
+            pro_i = lrelu(nbs[i])
+            emit_norm_bwd(b, gas[i], zs[i], nbs[i], pro_i, gas[i], part, gv(bns[i].weight), gv(bns[i].bias), None)
+            src = zs[i - 1] if i > 0 else self.x_in
+            pro_in = lrelu(nbs[i - 1]) if i > 0 else None
+            if want_param_grads:
+                emit_bias_grad(b, gas[i], gv(convs[i].bias), part)
+                emit_conv_wgrad(b, geoms[i], src, gas[i], gv(convs[i].weight), ws, pro=pro_in)
+            if i > 0:
+                emit_conv_dgrad(b, geoms[i], gas[i], store.wp_bwd(recs[i]), gas[i - 1])
+            elif want_input_grad:
+                self.g_x = E(n, *dhw, 1)
+                emit_conv_dgrad(b, geoms[0], gas[0], store.wp_bwd(recs[0]), self.g_x)

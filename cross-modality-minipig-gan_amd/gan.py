@@ -1,0 +1,194 @@
+"""The reference's GAN LightningModule without Lightning: same methods, same
+two-optimizer step (code/GAN/GAN_final.py:212-317; Lightning 1.2.1 loop restated
+in SURVEY.md Appendix B), every FLOP in HIP kernels.
+"""
+from __future__ import annotations
+
+import types
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .networks import CasNetGenerator, Discriminator, _EngineModule
+
+
+# --------------------------------------------------------------------------
+# loss hooks (autograd nodes around the loss kernels)
+# --------------------------------------------------------------------------
+class _BCEFn(torch.autograd.Function):
+    """F.binary_cross_entropy(y_hat, y) (mean), log clamped at -100."""
+
+    @staticmethod
+    def forward(ctx, y_hat, y):
+        p = y_hat.contiguous()
+        t = y.contiguous()
+        loss = torch.empty((), device=p.device)
+        ops.bce_forward(p, t, loss)
+        ctx.save_for_backward(p, t)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, t = ctx.saved_tensors
+        dprob = torch.empty_like(p)
+        ops.bce_backward(p, t, gout.contiguous(), dprob)
+        return dprob, None
+
+
+class _L1Fn(torch.autograd.Function):
+    """F.l1_loss(y_hat, y) (mean); backward = gout * sign(y_hat - y) / numel."""
+
+    @staticmethod
+    def forward(ctx, y_hat, y):
+        a, b = y_hat.contiguous(), y.contiguous()
+        loss = torch.empty((), device=a.device)
+        part = torch.empty(ops.l1_partials(), device=a.device)
+        grad = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        ops.l1_loss(a, b, part, loss, grad, 1.0)
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = ctx.grad
+        ops.scale_by_device_scalar(g, gout.contiguous(), g)
+        return g, None
+
+
+def adversarial_loss(y_hat, y):
+    """code/GAN/GAN_final.py:244-245."""
+    return _BCEFn.apply(y_hat, y)
+
+
+def reconstruction_loss(y_hat, y):
+    """code/GAN/GAN_final.py:247-248."""
+    return _L1Fn.apply(y_hat, y)
+
+
+# --------------------------------------------------------------------------
+# optimiser
+# --------------------------------------------------------------------------
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(lr, betas, eps=1e-8, weight_decay=0) as ONE kernel over
+    the network's flat parameter buffer (code/GAN/GAN_final.py:306-307).
+    `grad_scale` (e.g. 1/world_size after a sum all-reduce) is applied on load."""
+
+    def __init__(self, net: _EngineModule, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.net = net
+        super().__init__(list(net.parameters()), dict(lr=lr, betas=betas, eps=eps))
+        self._version = -1
+        self.step_count = 0
+        self.grad_scale = 1.0
+
+    def _state(self):
+        store = self.net.store
+        if self._version != store.version:
+            self.exp_avg = torch.zeros_like(store.flat)
+            self.exp_avg_sq = torch.zeros_like(store.flat)
+            self._version = store.version
+        return store
+
+    def zero_grad(self, set_to_none: bool = False):
+        store = self._state()
+        store.flat_grad.zero_()
+        store.attach_grads()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        store = self._state()
+        g = self.param_groups[0]
+        self.step_count += 1
+        ops.adam_step(store.flat, store.flat_grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0],
+                      g["betas"][1], g["eps"], self.step_count, self.grad_scale)
+        return loss
+
+
+# --------------------------------------------------------------------------
+# the GAN module
+# --------------------------------------------------------------------------
+class GAN(nn.Module):
+    """code/GAN/GAN_final.py:212-317.  `training_step(batch, batch_idx,
+    optimizer_idx)` has the reference's body; `fit_batch` is Lightning's
+    per-batch loop (toggle_optimizer -> zero_grad -> training_step -> backward
+    -> optimizer.step for optimizer 0 (G) then 1 (D))."""
+
+    def __init__(self, channels, width, height, depth=None, latent_dim: int = 100, d_lr: float = 0.0005,
+                 g_lr: float = 0.0005, b1: float = 0.5, b2: float = 0.999, batch_size: int = 64, example_data=None,
+                 one_sided_label_value=0.9, *, dimensions: Optional[int] = None, norm: str = "batch",
+                 n_unet_blocks: int = 6, unet_channels=(16, 32, 64, 128), unet_strides=(2, 2, 2), device="cuda",
+                 **kwargs):
+        super().__init__()
+        if dimensions is None:
+            dimensions = 3 if depth is not None else 2
+        self.hparams = types.SimpleNamespace(latent_dim=latent_dim, g_lr=g_lr, d_lr=d_lr, b1=b1, b2=b2,
+                                             batch_size=batch_size, one_sided_label_value=one_sided_label_value)
+        data_shape = (channels, width, height) + ((depth,) if dimensions == 3 else ())
+        self.generator = CasNetGenerator(data_shape, n_unet_blocks, dimensions=dimensions, norm=norm,
+                                         channels=unet_channels, strides=unet_strides, device=device)
+        self.discriminator = Discriminator(data_shape, dimensions=dimensions, device=device)
+        self.logged: Dict[str, torch.Tensor] = {}
+        self.ddp = None  # set by parallel.DataParallelGAN
+
+    def forward(self, x):
+        return self.generator(x)
+
+    def adversarial_loss(self, y_hat, y):
+        return adversarial_loss(y_hat, y)
+
+    def reconstruction_loss(self, y_hat, y):
+        return reconstruction_loss(y_hat, y)
+
+    def log(self, name, value, **kw):
+        """Lightning's self.log: scalars stay on the device (no per-step sync)."""
+        self.logged[name] = value.detach()
+
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        t1w_images, t2w_images = batch["t1w"], batch["t2w"]
+        if optimizer_idx == 0:                      # GAN_final.py:254-273
+            generated_imgs = self(t1w_images)
+            self.generated_imgs = generated_imgs
+            valid = torch.ones(t1w_images.shape[0], 1, device=t1w_images.device, dtype=t1w_images.dtype)
+            g_adv_loss = self.adversarial_loss(self.discriminator(generated_imgs), valid)
+            self.log("g_adv_loss", g_adv_loss)
+            g_recon_loss = self.reconstruction_loss(generated_imgs, t2w_images)
+            self.log("g_recon_loss", g_recon_loss)
+            g_loss = g_adv_loss + g_recon_loss
+            self.log("g_loss", g_loss)
+            return g_loss
+        if optimizer_idx == 1:                      # GAN_final.py:276-296
+            valid = torch.full((t1w_images.shape[0], 1), float(self.hparams.one_sided_label_value),
+                               device=t1w_images.device, dtype=t1w_images.dtype)
+            real_loss = self.adversarial_loss(self.discriminator(t2w_images), valid)
+            fake = torch.zeros(t1w_images.shape[0], 1, device=t1w_images.device, dtype=t1w_images.dtype)
+            fake_loss = self.adversarial_loss(self.discriminator(self(t1w_images).detach()), fake)
+            d_loss = (real_loss + fake_loss) / 2
+            self.log("d_loss", d_loss)
+            return d_loss
+
+    def configure_optimizers(self):                 # GAN_final.py:298-308
+        h = self.hparams
+        opt_g = FusedAdam(self.generator, lr=h.g_lr, betas=(h.b1, h.b2))
+        opt_d = FusedAdam(self.discriminator, lr=h.d_lr, betas=(h.b1, h.b2))
+        return [opt_g, opt_d], []
+
+    def fit_batch(self, batch, batch_idx, optimizers) -> Dict[str, torch.Tensor]:
+        nets: List[_EngineModule] = [self.generator, self.discriminator]
+        for idx, opt in enumerate(optimizers):
+            other = nets[1 - idx]
+            for p in other.parameters():            # toggle_optimizer
+                p.requires_grad_(False)
+            opt.zero_grad()
+            loss = self.training_step(batch, batch_idx, idx)
+            loss.backward()
+            if self.ddp is not None:
+                self.ddp.reduce_gradients(nets[idx], opt)
+            opt.step()
+            for p in other.parameters():
+                p.requires_grad_(True)
+        return dict(self.logged)

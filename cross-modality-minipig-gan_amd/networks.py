@@ -1,0 +1,323 @@
+"""The reference's module API on top of the HIP engine.
+
+`CasNetGenerator(img_shape, n_unet_blocks=6)` and
+`Discriminator(img_shape, use_perceptual=True)` keep the constructor / forward
+signatures, attribute names (`.model`, `.model_conv`, `.model_linear`) and
+state_dict keys of code/GAN/GAN_final.py:92-122,159-209 (and the MONAI 0.4.0
+U-Net tree beneath the generator), so a reference
+checkpoint's `generator.*` / `discriminator.*` entries load unchanged.
+Keyword-only additions: `dimensions` (2|3), `norm` ("batch"|"instance"),
+`channels`, `strides`, `device`.
+
+The torch.nn leaf modules below are parameter CONTAINERS only: their own
+forward is never called.  `forward` runs a pre-built plan of HIP kernels
+(engine.py) inside one autograd node; parameter gradients are accumulated by
+the kernels straight into the store's flat gradient buffer (the `.grad` of each
+parameter is a view of it).  Without libmpgan_hip.so or a GPU this raises.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .engine import DiscPlan, GeneratorPlan, ParamStore
+
+_CONV = {2: nn.Conv2d, 3: nn.Conv3d}
+_CONVT = {2: nn.ConvTranspose2d, 3: nn.ConvTranspose3d}
+_BN = {2: nn.BatchNorm2d, 3: nn.BatchNorm3d}
+_IN = {2: nn.InstanceNorm2d, 3: nn.InstanceNorm3d}
+
+
+class _Container(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: executed only by the HIP engine (call the top-level network)")
+
+
+def _norm(norm: str, dims: int, ch: int) -> nn.Module:
+    if norm == "batch":
+        return _BN[dims](ch)
+    if norm == "instance":
+        return _IN[dims](ch, affine=True)
+    raise ValueError(f"norm must be 'batch' or 'instance', got {norm!r}")
+
+
+def _convolution(dims, cin, cout, stride, *, conv_only=False, transposed=False, norm="batch", k=3) -> nn.Sequential:
+    pad = (k - 1) // 2
+    seq = nn.Sequential()
+    if transposed:
+        seq.add_module("conv", _CONVT[dims](cin, cout, k, stride=stride, padding=pad, output_padding=stride - 1))
+    else:
+        seq.add_module("conv", _CONV[dims](cin, cout, k, stride=stride, padding=pad))
+    if not conv_only:
+        adn = nn.Sequential()
+        adn.add_module("N", _norm(norm, dims, cout))
+        adn.add_module("D", nn.Dropout(0.0))
+        adn.add_module("A", nn.PReLU())
+        seq.add_module("adn", adn)
+    return seq
+
+
+class ResidualUnit(_Container):
+    def __init__(self, dims, cin, cout, stride, subunits, last_conv_only=False, norm="batch"):
+        super().__init__()
+        self.conv = nn.Sequential()
+        self.residual = nn.Identity()
+        sch, sst = cin, stride
+        for su in range(max(1, subunits)):
+            self.conv.add_module(f"unit{su:d}", _convolution(dims, sch, cout, sst, norm=norm,
+                                                             conv_only=last_conv_only and su == subunits - 1))
+            sch, sst = cout, 1
+        if stride != 1 or cin != cout:
+            rk, rp = (3, 1) if stride != 1 else (1, 0)
+            self.residual = _CONV[dims](cin, cout, rk, stride, rp)
+
+
+class SkipConnection(_Container):
+    def __init__(self, submodule):
+        super().__init__()
+        self.submodule = submodule
+
+
+class UNet(_Container):
+    """Parameter tree of MONAI 0.4.0 UNet(num_res_units=2, kernel 3, PReLU)."""
+
+    def __init__(self, dimensions=3, in_channels=1, out_channels=1, channels=(16, 32, 64, 128), strides=(2, 2, 2),
+                 num_res_units=2, norm="batch"):
+        super().__init__()
+        if in_channels != 1 or out_channels != 1 or num_res_units != 2:
+            raise ValueError("the HIP engine implements the reference's U-Net: 1->1 channels, 2 residual units")
+        if any(s != 2 for s in list(strides)[:len(channels) - 1]):
+            raise ValueError("the HIP engine implements stride-2 levels only (the reference's setting)")
+        self.dimensions, self.channels, self.strides = dimensions, tuple(channels), tuple(strides)
+        self.norm = norm
+        d = dimensions
+
+        def up(inc, outc, s, is_top):
+            return nn.Sequential(_convolution(d, inc, outc, s, transposed=True, norm=norm),
+                                 ResidualUnit(d, outc, outc, 1, 1, last_conv_only=is_top, norm=norm))
+
+        def block(inc, outc, chs, sts, is_top):
+            c, s = chs[0], sts[0]
+            if len(chs) > 2:
+                sub, upc = block(c, c, chs[1:], sts[1:], False), c * 2
+            else:
+                sub, upc = ResidualUnit(d, c, chs[1], 1, 2, norm=norm), c + chs[1]
+            return nn.Sequential(ResidualUnit(d, inc, c, s, 2, norm=norm), SkipConnection(sub), up(upc, outc, s, is_top))
+
+        self.model = block(1, 1, tuple(channels), tuple(strides), True)
+
+
+class _Lease:
+    """Returns a plan to its pool when the autograd node that borrowed it dies."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        plan.busy = True
+
+    def release(self):
+        if self.plan is not None:
+            self.plan.busy = False
+            self.plan = None
+
+    def __del__(self):
+        self.release()
+
+
+class _EngineModule(nn.Module):
+    """Shared plumbing: flat parameter store, plan pool, grad anchor."""
+
+    def __init__(self):
+        super().__init__()
+        self._store: Optional[ParamStore] = None
+        self._plans: Dict[tuple, list] = {}
+        self._anchor: Optional[torch.Tensor] = None
+
+    # the store is created lazily on first use so construction / load_state_dict / .cuda() work as usual
+    @property
+    def store(self) -> ParamStore:
+        if self._store is None:
+            p = next(self.parameters())
+            if not p.is_cuda:
+                raise RuntimeError(f"{type(self).__name__} runs only on an MI355X: move it to a CUDA/HIP device first "
+                                   "(there is no CPU path)")
+            ops.lib()  # raises if libmpgan_hip.so is missing
+            self._store = ParamStore(self)
+            self._register_extra(self._store)
+            self._anchor = torch.zeros(1, device=p.device, requires_grad=True)
+        return self._store
+
+    def _register_extra(self, store):
+        pass
+
+    def _apply(self, fn, *a, **k):
+        # .to()/.cuda()/.float() re-create parameter storage: drop the flat store and the plans
+        self._store = None
+        self._plans = {}
+        return super()._apply(fn, *a, **k)
+
+    def _acquire(self, key, make):
+        pool = self._plans.setdefault(key, [])
+        for pl in pool:
+            if not pl.busy:
+                return pl
+        pl = make()
+        pool.append(pl)
+        return pl
+
+    def _params_require_grad(self) -> bool:
+        return any(p.requires_grad for p in self.parameters())
+
+    def zero_grad(self, set_to_none: bool = False):  # keep the flat gradient views attached
+        if self._store is not None:
+            self._store.flat_grad.zero_()
+            self._store.attach_grads()
+        else:
+            super().zero_grad(set_to_none=False)
+
+
+def _spatial(x: torch.Tensor, dims: int) -> Tuple[int, ...]:
+    if x.dim() != dims + 2 or x.shape[1] != 1:
+        raise ValueError(f"expected a (B,1,{'D,' if dims == 3 else ''}H,W) tensor, got {tuple(x.shape)}")
+    if x.dtype != torch.float32 or not x.is_cuda:
+        raise ValueError(f"expected a float32 CUDA tensor, got {x.dtype} on {x.device} (no CPU path)")
+    return tuple(x.shape[2:])
+
+
+class _GenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, gen):
+        need_bwd = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        spatial = _spatial(x, gen.dimensions)
+        n = x.shape[0]
+        key = (n, spatial, need_bwd, bool(ctx.needs_input_grad[0]))
+        store = gen.store
+        plan = gen._acquire(key, lambda: GeneratorPlan(gen, store, n, spatial, want_backward=need_bwd,
+                                                      want_input_grad=bool(ctx.needs_input_grad[0]),
+                                                      instance=(gen.norm == "instance")))
+        lease = _Lease(plan)
+        plan.x_in.view(-1).copy_(x.reshape(-1))     # C == 1: NC(D)HW and channels-last coincide
+        plan.fwd.run()
+        y = plan.y.view(x.shape).clone()
+        if need_bwd:
+            ctx.lease = lease
+            ctx.shape = x.shape
+            store.attach_grads()
+        else:
+            lease.release()
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        plan = ctx.lease.plan
+        plan.g_y.view(-1).copy_(gy.reshape(-1))
+        plan.bwd.run()
+        gx = plan.g_x.view(ctx.shape).clone() if ctx.needs_input_grad[0] else None
+        ctx.lease.release()
+        return gx, None, None
+
+
+class CasNetGenerator(_EngineModule):
+    """code/GAN/GAN_final.py:92-122 (variant B: test_runs/GAN.py:94-129 via
+    n_unet_blocks=4, channels=(32,64,128,256), strides=(2,2,2,2))."""
+
+    def __init__(self, img_shape, n_unet_blocks=6, *, dimensions=3, norm="batch", channels=(16, 32, 64, 128),
+                 strides=(2, 2, 2), device=None):
+        super().__init__()
+        self.img_shape = img_shape
+        self.dimensions, self.norm = dimensions, norm
+        nets = [UNet(dimensions, 1, 1, channels, strides, 2, norm) for _ in range(n_unet_blocks)]
+        nets.append(nn.Tanh())
+        self.model = nn.Sequential(*nets)
+        if device is not None:
+            self.to(device)
+
+    def forward(self, x):
+        if not self.training:
+            raise NotImplementedError("eval-mode (running-statistics) inference is not built yet; the reference "
+                                      "trains with modules in train mode throughout (SURVEY.md Appendix B)")
+        store = self.store
+        self._anchor.requires_grad_(torch.is_grad_enabled() and self._params_require_grad())
+        return _GenFn.apply(x.contiguous(), self._anchor, self)
+
+
+class _DiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, disc):
+        want_in, want_par = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1])
+        need_bwd = want_in or want_par
+        spatial = _spatial(x, disc.dimensions)
+        n = x.shape[0]
+        store = disc.store
+        key = (n, spatial, need_bwd, want_in, want_par)
+        plan = disc._acquire(key, lambda: DiscPlan(disc, store, n, spatial, want_backward=need_bwd,
+                                                   want_input_grad=want_in, want_param_grads=want_par))
+        lease = _Lease(plan)
+        plan.x_in.view(-1).copy_(x.reshape(-1))
+        plan.fwd.run()
+        prob = plan.prob.view(n, 1).clone()
+        if need_bwd:
+            ctx.lease = lease
+            ctx.shape = x.shape
+            if want_par:
+                store.attach_grads()
+        else:
+            lease.release()
+        return prob
+
+    @staticmethod
+    def backward(ctx, gprob):
+        plan = ctx.lease.plan
+        plan.g_prob.copy_(gprob.reshape(-1))
+        plan.bwd.run()
+        gx = plan.g_x.view(ctx.shape).clone() if ctx.needs_input_grad[0] else None
+        ctx.lease.release()
+        return gx, None, None
+
+
+def disc_feature_sizes(spatial: Sequence[int]):
+    sizes = [tuple(spatial)]
+    for k, s in ((3, 1), (3, 1), (4, 2), (4, 2)):
+        sizes.append(tuple((n - k) // s + 1 for n in sizes[-1]))
+    return sizes
+
+
+class Discriminator(_EngineModule):
+    """code/GAN/GAN_final.py:159-209.  The reference hard-codes
+    Linear(256*29*29*29, 1) for its 128^3 input (:201); in_features here is
+    computed from img_shape (the same number for 128^3)."""
+
+    def __init__(self, img_shape, use_perceptual=True, *, dimensions=3, device=None):
+        super().__init__()
+        self.use_perceptual = use_perceptual
+        self.img_shape = img_shape
+        self.dimensions = dimensions
+        Cv, Bn = _CONV[dimensions], _BN[dimensions]
+        self.model_conv = nn.Sequential(
+            Cv(1, 64, 3, 1), Bn(64), nn.LeakyReLU(0.2, inplace=True),
+            Cv(64, 128, 3, 1), Bn(128), nn.LeakyReLU(0.2, inplace=True),
+            Cv(128, 256, 4, 2), Bn(256), nn.LeakyReLU(0.2, inplace=True),
+            Cv(256, 256, 4, 2), Bn(256), nn.LeakyReLU(0.2, inplace=True))
+        spatial = tuple(img_shape)[-dimensions:]
+        last = disc_feature_sizes(spatial)[-1]
+        if min(last) < 1:
+            raise ValueError(f"img_shape {img_shape} too small for the discriminator")
+        self._last = last
+        self.model_linear = nn.Sequential(nn.Flatten(), nn.Linear(256 * int(np.prod(last)), 1), nn.Sigmoid())
+        if device is not None:
+            self.to(device)
+
+    def _register_extra(self, store):
+        lin = self.model_linear[1]
+        store.register_conv(lin, cout=1, cin=256, taps=lin.in_features // 256)
+
+    def forward(self, img):
+        if not self.training:
+            raise NotImplementedError("eval-mode discriminator is not built (the reference never evaluates D)")
+        store = self.store
+        self._anchor.requires_grad_(torch.is_grad_enabled() and self._params_require_grad())
+        return _DiscFn.apply(img.contiguous(), self._anchor, self)

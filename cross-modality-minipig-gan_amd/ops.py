@@ -282,13 +282,14 @@ def linear1_partials(n: int) -> int:
     return int(lib().mpgan_linear1_partials(n))
 
 
-def linear1_forward(z, p: Optional[Prologue], w_perm, bias, partials, logit):
+def linear1_forward(z, p: Optional[Prologue], w_perm, bias, partials, logit, prob=None):
     n, P, ld = _cl(z, "linear1_forward z")
     c = z.shape[-1]
     if ld != c:
         raise ValueError("linear1_forward: z must be dense")
     check(lib().mpgan_linear1_forward(z.data_ptr(), _pro(p), n, P, c, w_perm.data_ptr(), _ptr(bias),
-                                      partials.data_ptr(), logit.data_ptr(), _stream()), "linear1_forward")
+                                      partials.data_ptr(), logit.data_ptr(), _ptr(prob), _stream()),
+          "linear1_forward")
     return logit
 
 
@@ -304,6 +305,27 @@ def linear1_backward(z, p: Optional[Prologue], w_perm, dlogit, g_a, dw, dbias, b
 def sigmoid_bce(logit, target: float, loss_scale: float, prob, loss, dlogit):
     check(lib().mpgan_sigmoid_bce(logit.data_ptr(), logit.numel(), float(target), float(loss_scale), _ptr(prob),
                                   _ptr(loss), _ptr(dlogit), _stream()), "sigmoid_bce")
+
+
+def bce_forward(prob, target, loss):
+    check(lib().mpgan_bce_forward(prob.data_ptr(), target.data_ptr(), prob.numel(), loss.data_ptr(), _stream()),
+          "bce_forward")
+
+
+def bce_backward(prob, target, gout, dprob):
+    check(lib().mpgan_bce_backward(prob.data_ptr(), target.data_ptr(), prob.numel(), gout.data_ptr(),
+                                   dprob.data_ptr(), _stream()), "bce_backward")
+
+
+def sigmoid_backward(dprob, prob, dlogit):
+    check(lib().mpgan_sigmoid_backward(dprob.data_ptr(), prob.data_ptr(), prob.numel(), dlogit.data_ptr(), _stream()),
+          "sigmoid_backward")
+
+
+def scale_by_device_scalar(x, scalar, y):
+    check(lib().mpgan_scale_by_device_scalar(x.data_ptr(), scalar.data_ptr(), x.numel(), y.data_ptr(), _stream()),
+          "scale_by_device_scalar")
+    return y
 
 
 def l1_partials() -> int:

@@ -182,7 +182,8 @@ int mpgan_copy_slice(const float* src, int32_t lds, float* dst, int32_t ldd, int
 int32_t mpgan_linear1_partials(int32_t n); /* floats of `partials` scratch */
 int mpgan_linear1_forward(const float* z, const mpgan_prologue* p, int32_t n,
                           int64_t pixels_per_sample, int32_t c, const float* w_perm,
-                          const float* bias, float* partials, float* logit, void* stream);
+                          const float* bias, float* partials, float* logit, float* prob /* sigmoid(logit), nullable */,
+                          void* stream);
 /* g_a[n][k] = dlogit[n]*w_perm[k];  dW (torch order, C-major) += sum_n dlogit[n]*a[n][k];
  * dbias += sum_n dlogit[n]. */
 int mpgan_linear1_backward(const float* z, const mpgan_prologue* p, int32_t n,
@@ -196,6 +197,19 @@ int mpgan_linear1_backward(const float* z, const mpgan_prologue* p, int32_t n,
  * autograd does (BCE backward: (p-t)/max((1-p)p, 1e-12)/n, then p(1-p)). */
 int mpgan_sigmoid_bce(const float* logit, int32_t n, float target, float loss_scale,
                       float* prob, float* loss, float* dlogit, void* stream);
+
+/* The same loss as separate autograd-shaped pieces (the module API returns the
+ * probability, as the reference's Discriminator.forward does, and
+ * GAN.adversarial_loss consumes it):
+ *   bce_forward : loss = mean_i -(t_i*max(log p_i,-100) + (1-t_i)*max(log(1-p_i),-100))
+ *   bce_backward: dprob_i = gout * (p_i - t_i) / max((1-p_i)*p_i, 1e-12) / n   (gout: device scalar)
+ *   sigmoid_backward: dlogit_i = dprob_i * (1-p_i) * p_i */
+int mpgan_bce_forward(const float* prob, const float* target, int32_t n, float* loss, void* stream);
+int mpgan_bce_backward(const float* prob, const float* target, int32_t n, const float* gout,
+                       float* dprob, void* stream);
+int mpgan_sigmoid_backward(const float* dprob, const float* prob, int32_t n, float* dlogit, void* stream);
+/* y = x * (*scalar)  (scalar on the device: an upstream autograd gradient) */
+int mpgan_scale_by_device_scalar(const float* x, const float* scalar, int64_t numel, float* y, void* stream);
 
 /* loss = mean |a-b| (F.l1_loss, GAN_final.py:247-248); grad_a = scale*sign(a-b)/numel
  * (written when grad_a != null).  partials: >= mpgan_l1_partials() floats. */

@@ -317,8 +317,8 @@ class GAN(nn.Module):
             g_adv = adversarial_loss(self.discriminator(gen), valid)
             g_rec = reconstruction_loss(gen, t2w)
             g_loss = g_adv + g_rec
-            self.logged.update(g_adv_loss=float(g_adv), g_recon_loss=float(g_rec),
-                               g_loss=float(g_loss))
+            self.logged.update(g_adv_loss=g_adv.item(), g_recon_loss=g_rec.item(),
+                               g_loss=g_loss.item())
             return g_loss
         if optimizer_idx == 1:                       # GAN_final.py:276-296
             valid = (torch.ones(t1w.shape[0], 1)
@@ -328,7 +328,7 @@ class GAN(nn.Module):
             fake_loss = adversarial_loss(
                 self.discriminator(self(t1w).detach()), fake)
             d_loss = (real_loss + fake_loss) / 2
-            self.logged.update(d_loss=float(d_loss))
+            self.logged.update(d_loss=d_loss.item())
             return d_loss
 
     def configure_optimizers(self):                  # GAN_final.py:298-308

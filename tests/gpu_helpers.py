@@ -21,7 +21,11 @@ def t3(v, dims, fill):
     return (fill,) * (3 - dims) + v
 
 
-def assert_close(got, want, rtol=2e-4, atol=None, what=""):
+def assert_close(got, want, rtol=2e-4, atol=None, what="", outliers=0.0, outlier_cap=0.05):
+    """|got-want| <= atol + rtol*|want| elementwise.  `outliers` > 0 tolerates that
+    fraction of elements (at least one) beyond it, each still within outlier_cap *
+    max|want|: gradients through LeakyReLU/PReLU jump when an activation sits
+    within rounding of the kink and the two implementations land on opposite sides."""
     got = got.detach().double().cpu()
     want = want.detach().double().cpu()
     assert got.shape == want.shape, (what, got.shape, want.shape)
@@ -29,6 +33,10 @@ def assert_close(got, want, rtol=2e-4, atol=None, what=""):
     atol = atol if atol is not None else 2e-5 * scale
     err = (got - want).abs()
     bad = err > (atol + rtol * want.abs())
+    if outliers > 0 and bad.any():
+        allowed = max(1, int(outliers * bad.numel()))
+        if bad.sum().item() <= allowed and err.max().item() <= outlier_cap * scale:
+            return
     if bad.any():
         i = err.argmax()
         raise AssertionError(f"{what}: max abs err {err.max().item():.3e} (scale {scale:.3e}) at flat index {i.item()} "

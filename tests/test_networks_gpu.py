@@ -1,0 +1,193 @@
+"""Whole-network parity: the HIP engine behind the reference's module API vs the
+CPU oracle, same closed-form weights (loaded through state_dict), same inputs.
+
+Tolerances (fp32): forward 1e-4 abs on [-1,1] outputs (north_star: G-output
+L1 < 1e-4); gradients rtol 2e-3 of the tensor's max (six cascaded train-mode
+BatchNorm U-Nets amplify rounding).  Conv biases that feed a norm layer have a
+mathematically ZERO gradient (the norm removes the mean): both sides hold
+rounding noise there, so those are only checked to be tiny.
+"""
+import pytest
+import torch
+
+from gpu_helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import refmodel as R
+    return R
+
+
+def _pre_norm_bias(name, keys):
+    if not name.endswith("bias"):
+        return False
+    if name.startswith("model_conv."):
+        return name in ("model_conv.0.bias", "model_conv.3.bias", "model_conv.6.bias", "model_conv.9.bias")
+    stem = name[:-len("conv.bias")]
+    return name.endswith("conv.bias") and (stem + "adn.N.weight") in keys
+
+
+def _check_param_grads(ours, ref, rtol=2e-3):
+    keys = set(dict(ref.named_parameters()).keys())
+    ref_p = dict(ref.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in ref_p.values() if p.grad is not None)
+    for name, p in ours.named_parameters():
+        r = ref_p[name]
+        assert p.grad is not None, name
+        if _pre_norm_bias(name, keys):
+            assert p.grad.abs().max().item() <= 1e-4 * gmax + 1e-6, (name, p.grad.abs().max().item())
+            continue
+        assert_close(p.grad, r.grad, rtol=rtol, atol=rtol * (r.grad.abs().max().item() + 1e-12), what="grad " + name,
+                     outliers=0.005)
+
+
+@pytest.mark.parametrize("dims,spatial,n,norm,nblocks", [
+    (2, (32, 48), 2, "batch", 2),
+    (2, (64, 64), 3, "batch", 6),       # the reference's 6-U-Net cascade
+    (2, (32, 32), 2, "instance", 2),    # north_star's InstanceNorm variant
+    (3, (16, 16, 24), 2, "batch", 2),   # the reference's real (3-D) graph
+])
+def test_generator_forward_backward_matches_oracle(dims, spatial, n, norm, nblocks):
+    R = _oracle()
+    from mpgan_amd.networks import CasNetGenerator
+    ref = R.CasNetGenerator((1, *spatial), nblocks, dimensions=dims, norm=norm)
+    R.closed_form_fill_(ref)
+    ref.train()
+    ours = CasNetGenerator((1, *spatial), nblocks, dimensions=dims, norm=norm)
+    ours.load_state_dict(ref.state_dict())
+    ours.cuda().train()
+    gen = torch.Generator().manual_seed(7)
+    x = (torch.rand(n, 1, *spatial, generator=gen) * 2 - 1).requires_grad_(True)
+    t = torch.rand(n, 1, *spatial, generator=gen) * 2 - 1
+    y_ref = ref(x)
+    loss_ref = R.reconstruction_loss(y_ref, t) + 0.1 * (y_ref * y_ref).mean()
+    loss_ref.backward()
+
+    xc = x.detach().cuda().requires_grad_(True)
+    y = ours(xc)
+    l1 = (y.cpu() - y_ref.detach()).abs().mean().item()
+    assert l1 < 1e-4, f"G-output L1 vs CPU oracle = {l1:.3e}"
+    assert_close(y, y_ref, rtol=0, atol=5e-4, what="G output")
+    from mpgan_amd.gan import reconstruction_loss
+    loss = reconstruction_loss(y, t.cuda()) + 0.1 * (y * y).mean()
+    assert_close(loss.reshape(1), loss_ref.reshape(1), rtol=1e-4, what="loss")
+    loss.backward()
+    assert_close(xc.grad, x.grad, rtol=2e-3, atol=2e-3 * x.grad.abs().max().item(), what="dL/dx", outliers=0.005)
+    _check_param_grads(ours, ref)
+    if norm == "batch":   # running statistics are part of parity (updated on every train-mode forward)
+        sd, sr = ours.state_dict(), ref.state_dict()
+        for k in sr:
+            if "running_" in k:
+                assert_close(sd[k], sr[k], rtol=1e-4, atol=1e-6, what=k)
+            if k.endswith("num_batches_tracked"):
+                assert int(sd[k]) == int(sr[k]) == 1
+
+
+@pytest.mark.parametrize("dims,spatial,n", [(2, (32, 40), 3), (2, (128, 128), 1), (3, (28, 28, 32), 2)])
+def test_discriminator_forward_backward_matches_oracle(dims, spatial, n):
+    R = _oracle()
+    from mpgan_amd.gan import adversarial_loss
+    from mpgan_amd.networks import Discriminator
+    ref = R.Discriminator((1, *spatial), dimensions=dims)
+    R.closed_form_fill_(ref)
+    ref.train()
+    ours = Discriminator((1, *spatial), dimensions=dims)
+    ours.load_state_dict(ref.state_dict())
+    ours.cuda().train()
+    gen = torch.Generator().manual_seed(17)
+    x = (torch.rand(n, 1, *spatial, generator=gen) * 2 - 1).requires_grad_(True)
+    p_ref = ref(x)
+    loss_ref = R.adversarial_loss(p_ref, torch.full_like(p_ref, 0.9))
+    loss_ref.backward()
+    xc = x.detach().cuda().requires_grad_(True)
+    p = ours(xc)
+    assert p.shape == (n, 1)
+    assert_close(p, p_ref, rtol=1e-4, atol=1e-6, what="validity")
+    loss = adversarial_loss(p, torch.full_like(p, 0.9))
+    assert_close(loss.reshape(1), loss_ref.reshape(1), rtol=1e-5, what="bce")
+    loss.backward()
+    # four train-mode BatchNorms over few pixels amplify fp32 rounding: 5e-3 of the gradient's max
+    assert_close(xc.grad, x.grad, rtol=5e-3, atol=5e-3 * x.grad.abs().max().item(), what="dL/dx", outliers=0.005)
+    _check_param_grads(ours, ref, rtol=5e-3)
+    sd, sr = ours.state_dict(), ref.state_dict()
+    for k in sr:
+        if "running_" in k:
+            assert_close(sd[k], sr[k], rtol=1e-4, atol=1e-6, what=k)
+
+
+def test_discriminator_frozen_params_only_input_grad():
+    """G-step: D's parameters are toggled off; only dL/d(input) flows."""
+    from mpgan_amd.networks import Discriminator
+    d = Discriminator((1, 32, 32), dimensions=2, device="cuda")
+    for p in d.parameters():
+        p.requires_grad_(False)
+    x = torch.rand(2, 1, 32, 32, device="cuda", requires_grad=True)
+    d(x).sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and x.grad.abs().sum() > 0
+    assert all(p.grad is None or p.grad.abs().sum() == 0 for p in d.parameters())
+
+
+def test_two_optimizer_step_matches_oracle_c1():
+    """BASELINE config C1: one 128x128 slice pair, bs 1, full G+D steps vs the
+    CPU oracle.
+
+    What can and cannot match: Adam's first steps move EVERY parameter by ~lr in
+    the direction of sign(grad), so parameters whose gradient is rounding noise
+    (pre-norm conv biases: exactly zero in exact arithmetic) or merely tiny take
+    unrelated +-lr steps in two fp32 implementations, and that perturbation feeds
+    the next forward.  The test therefore pins, per iteration, (a) the generator
+    losses, computed BEFORE any update of that iteration, tightly; (b) d_loss,
+    computed after that iteration's G update, to 5 %; (c) the updated parameters
+    elementwise to 2*lr with >= 98 % of all of them within 2e-4; (d) BatchNorm
+    bookkeeping (G: 2 forwards/step, D: 3).  The oracle is re-synchronised to
+    our parameters after each iteration so that iteration 2 starts level."""
+    R = _oracle()
+    from mpgan_amd.gan import GAN
+    ref = R.GAN((1, 128, 128), dimensions=2)
+    R.closed_form_fill_(ref.generator)
+    R.closed_form_fill_(ref.discriminator)
+    ref.train()
+    ours = GAN(1, 128, 128, dimensions=2)
+    ours.generator.load_state_dict(ref.generator.state_dict())
+    ours.discriminator.load_state_dict(ref.discriminator.state_dict())
+    ours.train()
+    opts_ref, _ = ref.configure_optimizers()
+    opts, _ = ours.configure_optimizers()
+    gen = torch.Generator().manual_seed(1234)
+    for it in range(2):
+        t1 = torch.rand(1, 1, 128, 128, generator=gen) * 2 - 1
+        t2 = torch.rand(1, 1, 128, 128, generator=gen) * 2 - 1
+        log_ref = ref.step({"t1w": t1, "t2w": t2}, it, opts_ref)
+        log = ours.fit_batch({"t1w": t1.cuda(), "t2w": t2.cuda()}, it, opts)
+        for k, tol in (("g_adv_loss", 2e-3), ("g_recon_loss", 2e-3), ("g_loss", 2e-3), ("d_loss", 5e-2)):
+            got, want = float(log[k]), log_ref[k]
+            assert abs(got - want) <= tol * abs(want) + 1e-5, (it, k, got, want)
+        for net, rnet in ((ours.generator, ref.generator), (ours.discriminator, ref.discriminator)):
+            keys = set(dict(rnet.named_parameters()).keys())
+            rp = dict(rnet.named_parameters())
+            n_bad = n_all = 0
+            for name, p in net.named_parameters():
+                diff = (p.detach().cpu() - rp[name].detach()).abs()
+                assert diff.max().item() <= 2 * 5e-4 + 1e-6, (it, name, diff.max().item())
+                if not _pre_norm_bias(name, keys):
+                    n_bad += int((diff > 2e-4).sum())
+                    n_all += diff.numel()
+            assert n_bad / n_all < 0.02, (it, n_bad, n_all)
+            sd = net.state_dict()
+            for k, v in rnet.state_dict().items():
+                if k.endswith("num_batches_tracked"):
+                    expect = (2 if net is ours.generator else 3) * (it + 1)
+                    assert int(sd[k]) == expect, (k, int(sd[k]), expect)
+            rnet.load_state_dict({k: v.cpu() for k, v in sd.items()})   # level the field for the next iteration
+            for k, v in rnet.state_dict().items():
+                if k.endswith("num_batches_tracked"):
+                    v.fill_((2 if net is ours.generator else 3) * (it + 1))
+
+
+def test_missing_library_or_cpu_tensor_fails_loudly():
+    from mpgan_amd.networks import CasNetGenerator
+    g = CasNetGenerator((1, 32, 32), 1, dimensions=2)     # parameters on the CPU
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        g(torch.zeros(1, 1, 32, 32))

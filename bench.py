@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: T1->T2 256x256 slices/sec of the full G+D adversarial
+training step (BASELINE.json config C3: bs 16 per GPU, fp32), weak-scaled over
+N GPUs with one RCCL all-reduce per optimiser.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = Lightning's per-batch loop of the reference (G step then D step:
+G fwd x2, G bwd, D fwd x3, D bwd x3, two fused Adam steps) on one synthetic
+batch already resident in HBM.  Rank 0 prints ONE JSON line.
+
+  roofline     : the dominant kernel (the BN=128 fp32-MFMA implicit-GEMM conv,
+                 all of D's dense layers forward + backward-data) timed live with
+                 HIP events on the launch stream during the timed steps;
+                 achieved = algorithmic FLOPs of those launches / their time,
+                 against the 157.3 TFLOP/s fp32 matrix peak.
+  cpu_baseline : the CPU oracle (plain torch restatement, oracle/) timed on this
+                 host on a bounded sample (2 slices per step), plus the
+                 G-output L1 between the HIP path and that oracle.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
+DOMINANT = "gather_conv_kernel<BN=128,vec4>"
+
+
+def synthetic_batch(bs, spatial, rank, device):
+    g = torch.Generator().manual_seed(1234 + rank)
+    t1 = torch.rand(bs, 1, *spatial, generator=g) * 2 - 1
+    t2 = torch.rand(bs, 1, *spatial, generator=g) * 2 - 1
+    return {"t1w": t1.to(device), "t2w": t2.to(device)}
+
+
+def cpu_baseline_leg(gan, spatial, sample_bs=2, timed_steps=2):
+    """Oracle on the host cores: bounded sample of the same workload + the
+    G-output L1 of the HIP path against it (same weights, same input)."""
+    from oracle import refmodel as R
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))                # the GPU box's CPU share for one GPU
+    torch.set_num_threads(cores)
+    ref = R.GAN((1, *spatial), dimensions=2)
+    ref.generator.load_state_dict({k: v.cpu() for k, v in gan.generator.state_dict().items()})
+    ref.discriminator.load_state_dict({k: v.cpu() for k, v in gan.discriminator.state_dict().items()})
+    ref.train()
+    g = torch.Generator().manual_seed(99)
+    batch = {"t1w": torch.rand(sample_bs, 1, *spatial, generator=g) * 2 - 1,
+             "t2w": torch.rand(sample_bs, 1, *spatial, generator=g) * 2 - 1}
+    with torch.no_grad():
+        y_ref = ref.generator(batch["t1w"])
+        y = gan.generator(batch["t1w"].cuda()).cpu()
+    l1 = (y - y_ref).abs().mean().item()
+    mse = ((y - y_ref) ** 2).mean().item()
+    psnr = float("inf") if mse == 0 else 10.0 * torch.log10(torch.tensor(4.0 / mse)).item()  # data range 2
+    opts, _ = ref.configure_optimizers()
+    ref.step(batch, 0, opts)                      # warm-up
+    t0 = time.perf_counter()
+    for i in range(timed_steps):
+        ref.step(batch, i + 1, opts)
+    dt = time.perf_counter() - t0
+    return {"value": sample_bs * timed_steps / dt, "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"{timed_steps} G+D steps of the torch-CPU oracle at 256x256, bs {sample_bs} (1 warm-up)",
+            "g_output_l1_vs_cpu": l1, "g_output_psnr_vs_cpu_db": psnr}
+
+
+def note(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="slices per GPU (C3/C4: 16)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lr", type=float, default=1e-6,
+                    help="Adam lr for both nets.  The reference's 5e-4 drives the 952,576-input Linear head into "
+                         "sigmoid saturation within ONE step (its own checkpoints show g_loss=100.03, d_loss=45.00), "
+                         "after which every D gradient is exactly zero; all-zero MFMA operands let the chip clock up, "
+                         "so the default keeps the same work on non-degenerate data.")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mpgan_amd import engine
+    from mpgan_amd.gan import GAN
+    from mpgan_amd.parallel import DataParallelGAN
+
+    spatial = (args.size, args.size)
+    torch.manual_seed(0)                           # torch default init, identical on every rank
+    gan = GAN(1, args.size, args.size, dimensions=2, device=dev, g_lr=args.lr, d_lr=args.lr)
+    # With torch-default init the 952,576-input Linear saturates the sigmoid (BCE sits on its
+    # -100 clamp, as in the reference's own checkpoints: g_loss=100.03, d_loss=45.00), which
+    # makes every discriminator gradient exactly zero.  All-zero MFMA operands let the chip
+    # clock up and would flatter the timing, so the head's weight is scaled to keep logits O(1).
+    with torch.no_grad():
+        gan.discriminator.model_linear[1].weight.mul_(0.02)
+    gan.train()
+    ddp = DataParallelGAN(gan)
+    opts, _ = gan.configure_optimizers()
+    batch = synthetic_batch(args.batch, spatial, rank, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    note(f"rank {rank}/{world}: model built, warming up")
+    for i in range(args.warmup):
+        gan.fit_batch(batch, i, opts)
+        torch.cuda.synchronize()
+        note(f"warm-up step {i} done")
+    probe = engine.KernelProbe(want={DOMINANT})
+    engine.set_probe(probe)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        gan.fit_batch(batch, args.warmup + i, opts)
+    barrier()
+    dt = time.perf_counter() - t0
+    engine.set_probe(None)
+    note(f"timed region: {dt / args.steps * 1e3:.1f} ms/step")
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    losses = {k: float(v) for k, v in gan.logged.items()}
+
+    if rank == 0:
+        summ = probe.summary().get(DOMINANT, dict(calls=0, ms=0.0, flops=0.0))
+        achieved = summ["flops"] / (summ["ms"] * 1e-3) / 1e12 if summ["ms"] > 0 else 0.0
+        roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None, "kernel": DOMINANT,
+                    "launches_per_step": summ["calls"] / max(args.steps, 1),
+                    "avg_launch_ms": summ["ms"] / max(summ["calls"], 1),
+                    "avg_launch_gflop": summ["flops"] / max(summ["calls"], 1) / 1e9}
+        # G-forward-only (config C2) on the side: not part of `value`
+        with torch.no_grad():
+            for _ in range(2):
+                gan.generator(batch["t1w"])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 10
+            for _ in range(reps):
+                gan.generator(batch["t1w"])
+            torch.cuda.synchronize()
+            g_fwd_ms = (time.perf_counter() - t1) / reps * 1e3
+        g_fwd_flops = 7.2423e9 * args.batch * (args.size / 256.0) ** 2
+        out = {
+            "metric": "T1->T2 256x256 slices/sec (G+D step)", "value": world * args.batch * args.steps / dt,
+            "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3: {args.size}x{args.size} bs{args.batch}/GPU full G+D adversarial step "
+                                   "(6-UNet CasNet G + conv D, BatchNorm, Adam x2)",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "adam_lr": args.lr},
+            "roofline": roofline,
+            "step_mfma_frac": (298.0e9 * args.batch * (args.size / 256.0) ** 2) / (dt / args.steps) / 1e12
+                              / PEAK_FP32_TFLOPS,
+            "g_forward": {"ms": g_fwd_ms, "slices_per_s": args.batch / (g_fwd_ms * 1e-3),
+                          "mfma_frac": g_fwd_flops / (g_fwd_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
+            "losses": losses,
+        }
+        note(f"G forward {g_fwd_ms:.2f} ms")
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg(gan, spatial)
+            note("cpu baseline done")
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -32,10 +32,12 @@ _I3 = C.POINTER(C.c_int32)
 SIGNATURES = {
     "mpgan_last_error": (C.c_char_p, []),
     "mpgan_abi_version": (_I, []),
-    "mpgan_conv_forward": (_I, [_G, _P, _I, _P, _P, _PR, _P, _I, _I, _P, _I, _P]),
+    "mpgan_conv_stats_rows": (_I, [_G, _I]),
+    "mpgan_conv_forward": (_I, [_G, _P, _I, _P, _P, _PR, _P, _I, _I, _P, _P, _I, _P]),
     "mpgan_conv_backward_data": (_I, [_G, _P, _I, _P, _P, _I, _P, _I, _P]),
+    "mpgan_conv_variant": (_I, [_G, _I, _I]),
     "mpgan_conv_wgrad_workspace": (_L, [_G]),
-    "mpgan_conv_backward_weight": (_I, [_G, _P, _I, _PR, _P, _I, _P, _F, _P, _L, _P]),
+    "mpgan_conv_backward_weight": (_I, [_G, _P, _I, _PR, _P, _I, _P, _P, _F, _P, _L, _P]),
     "mpgan_pack_weights": (_I, [_P, _P, _P, _I, _L, _P]),
     "mpgan_stats_chunks": (_I, [_L, _I]),
     "mpgan_channel_stats": (_I, [_P, _I, _I, _L, _I, _P, _P]),

@@ -37,6 +37,7 @@ struct GatherConv {
   float* out;
   const float* bias;
   const float* resid;
+  float* stats;   // optional [nphase*gridDim.x][2][Cout] partial sums of the output (fused BatchNorm statistics)
   Pro pro;
   int N, Di, Hi, Wi, Cin, ldi;
   int Do, Ho, Wo, Cout, ldo, ldr;
@@ -50,27 +51,15 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int PITCH = BK + 4;
 
-struct TapInfo {
-  int tapflat, dz, dy, dx, ci;
-  bool valid;
+// Per-thread cursor over the flattened K = (tap, ci) axis.  It is decoded with
+// integer divisions ONCE; each K-step then advances it by 32 with compares only.
+struct KCursor {
+  int ci, jz, jy, jx;   // position
+  int delta;            // pixel offset of the tap relative to the row's base pixel
+  int dz, dy, dx;       // per-dimension input offsets of the tap
+  int woff;             // tapflat * Cin
+  bool valid;           // tap index still inside this phase's tap list
 };
-
-__device__ __forceinline__ TapInfo decode_k(const GatherConv& p, const Phase& ph, int kidx, int Kp) {
-  TapInfo t;
-  t.valid = kidx < Kp;
-  int tap = kidx / p.Cin;
-  t.ci = kidx - tap * p.Cin;
-  int jx = tap % ph.nx;
-  int tq = tap / ph.nx;
-  int jy = tq % ph.ny;
-  int jz = tq / ph.ny;
-  int kz = ph.kz0 + p.kstep[0] * jz, ky = ph.ky0 + p.kstep[1] * jy, kx = ph.kx0 + p.kstep[2] * jx;
-  t.tapflat = (kz * p.Ky + ky) * p.Kx + kx;
-  t.dz = ph.dz0 + p.dstep[0] * jz;
-  t.dy = ph.dy0 + p.dstep[1] * jy;
-  t.dx = ph.dx0 + p.dstep[2] * jx;
-  return t;
-}
 
 template <int BN, int TM, int TN, int WN, bool SCALAR>
 __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
@@ -82,30 +71,44 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
   const int lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
-  const Phase& ph = p.ph[blockIdx.z];
+  const Phase ph = p.ph[blockIdx.z];
   const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
   const long m0 = (long)blockIdx.x * BM;
-  if (m0 >= Mtot) return;
   const int n0 = blockIdx.y * BN;
+  if (m0 >= Mtot) {
+    if (p.stats && tid < BN && n0 + tid < p.Cout) {   // an empty tile of a short phase still owns a partial row
+      float* row = p.stats + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * p.Cout;
+      row[n0 + tid] = 0.f;
+      row[p.Cout + n0 + tid] = 0.f;
+    }
+    return;
+  }
+  const int Cin = p.Cin, Cout = p.Cout, Di = p.Di, Hi = p.Hi, Wi = p.Wi, ldi = p.ldi;
   const int ntaps = ph.nz * ph.ny * ph.nx;
-  const int Kp = ntaps * p.Cin;
+  const int Kp = ntaps * Cin;
   const int nk = (Kp + BK - 1) / BK;
-  const long Ktot = (long)p.Kz * p.Ky * p.Kx * p.Cin;
+  const long Ktot = (long)p.Kz * p.Ky * p.Kx * Cin;
+  const float* __restrict__ gin = p.in;
+  const float* __restrict__ gw = p.wp;
+  const float* __restrict__ gscale = p.pro.scale;
+  const float* __restrict__ gshift = p.pro.shift;
+  const int nstride = p.pro.n_stride, act = p.pro.act;
   const float slope = pro_slope(p.pro);
 
   // ---- per-thread load assignment: K-chunk column cc, rows r0 + 32*i ----
   const int cc = tid & 7, r0 = tid >> 3;
-  int rn[4], rz[4], ry[4], rx[4];
+  int rn[4], rz[4], ry[4], rx[4], rbase[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    long m = m0 + r0 + 32 * i;
-    if (m < Mtot) {
-      int mx = (int)(m % ph.Mx);
-      long q = m / ph.Mx;
-      int my = (int)(q % ph.My);
-      q /= ph.My;
-      int mz = (int)(q % ph.Mz);
-      rn[i] = (int)(q / ph.Mz);
+    const unsigned m = (unsigned)m0 + r0 + 32 * i;   // host guarantees Mtot < 2^31
+    if (m < (unsigned)Mtot) {
+      const unsigned uMx = ph.Mx, uMy = ph.My, uMz = ph.Mz;
+      int mx = (int)(m % uMx);
+      unsigned q = m / uMx;
+      int my = (int)(q % uMy);
+      q /= uMy;
+      int mz = (int)(q % uMz);
+      rn[i] = (int)(q / uMz);
       rz[i] = mz * p.istride[0];
       ry[i] = my * p.istride[1];
       rx[i] = mx * p.istride[2];
@@ -113,91 +116,150 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
       rn[i] = 0;
       rz[i] = ry[i] = rx[i] = -(1 << 28);
     }
+    rbase[i] = ((rn[i] * Di + rz[i]) * Hi + ry[i]) * Wi + rx[i];
   }
+  const int ksz = p.kstep[0], ksy = p.kstep[1], ksx = p.kstep[2];
+  const int dsz = p.dstep[0], dsy = p.dstep[1], dsx = p.dstep[2];
+  const int Ky = p.Ky, Kx = p.Kx;
 
-  float4 ra[4], rb[BROWS];
-
-  auto load_a_elem = [&](int i, const TapInfo& t) -> float {
-    int iz = rz[i] + t.dz, iy = ry[i] + t.dy, ix = rx[i] + t.dx;
-    bool ok = t.valid && (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi &&
-              (unsigned)ix < (unsigned)p.Wi;
-    if (!ok) return 0.f;
-    long pix = (((long)rn[i] * p.Di + iz) * p.Hi + iy) * p.Wi + ix;
-    float v = p.in[pix * p.ldi + t.ci];
-    if (p.pro.scale) {
-      int si = rn[i] * p.pro.n_stride + t.ci;
-      v = act_apply(v * p.pro.scale[si] + p.pro.shift[si], p.pro.act, slope);
+  auto place = [&](KCursor& c) {
+    c.valid = c.jz < ph.nz;
+    const int kz = ph.kz0 + ksz * c.jz, ky = ph.ky0 + ksy * c.jy, kx = ph.kx0 + ksx * c.jx;
+    c.woff = ((kz * Ky + ky) * Kx + kx) * Cin;
+    c.dz = ph.dz0 + dsz * c.jz;
+    c.dy = ph.dy0 + dsy * c.jy;
+    c.dx = ph.dx0 + dsx * c.jx;
+    c.delta = (c.dz * Hi + c.dy) * Wi + c.dx;
+  };
+  auto seek = [&](KCursor& c, int kidx) {   // divisions: once per thread
+    int tap = kidx / Cin;
+    c.ci = kidx - tap * Cin;
+    c.jx = tap % ph.nx;
+    int tq = tap / ph.nx;
+    c.jy = tq % ph.ny;
+    c.jz = tq / ph.ny;
+    place(c);
+  };
+  auto advance = [&](KCursor& c, int by) {
+    c.ci += by;
+    if (c.ci >= Cin) {
+      do {
+        c.ci -= Cin;
+        if (++c.jx == ph.nx) {
+          c.jx = 0;
+          if (++c.jy == ph.ny) { c.jy = 0; ++c.jz; }
+        }
+      } while (c.ci >= Cin);
+      place(c);
     }
-    return v;
   };
 
-  auto global_load = [&](int kt) {
-    const int kidx = kt * BK + cc * 4;
+  constexpr int NCUR = SCALAR ? 4 : 1;
+  KCursor cur[NCUR];
+  if (ntaps > 0) {
+#pragma unroll
+    for (int e = 0; e < NCUR; ++e) seek(cur[e], cc * 4 + e);
+  } else {
+#pragma unroll
+    for (int e = 0; e < NCUR; ++e) { cur[e] = KCursor{}; cur[e].valid = false; }
+  }
+
+  float4 ra[4], rb[BROWS], rsc[4], rsh[4];
+  unsigned amask = 0, bmask = 0;     // validity bits of the staged registers
+
+  // Issue every global load of the next K-tile back to back, branch-free: invalid
+  // (padding / tail) elements read a clamped in-range address and are zeroed when
+  // the tile is written to LDS, after the MFMA phase has hidden the latency.
+  auto global_load = [&]() {
+    amask = 0; bmask = 0;
     if constexpr (!SCALAR) {
-      const TapInfo t = decode_k(p, ph, kidx, Kp);
+      const KCursor& c = cur[0];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        int iz = rz[i] + t.dz, iy = ry[i] + t.dy, ix = rx[i] + t.dx;
-        bool ok = t.valid && (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi &&
-                  (unsigned)ix < (unsigned)p.Wi;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
-          long pix = (((long)rn[i] * p.Di + iz) * p.Hi + iy) * p.Wi + ix;
-          v = *reinterpret_cast<const float4*>(p.in + pix * p.ldi + t.ci);
-          if (p.pro.scale) {
-            int si = rn[i] * p.pro.n_stride + t.ci;
-            float4 sc = *reinterpret_cast<const float4*>(p.pro.scale + si);
-            float4 sh = *reinterpret_cast<const float4*>(p.pro.shift + si);
-            v.x = act_apply(v.x * sc.x + sh.x, p.pro.act, slope);
-            v.y = act_apply(v.y * sc.y + sh.y, p.pro.act, slope);
-            v.z = act_apply(v.z * sc.z + sh.z, p.pro.act, slope);
-            v.w = act_apply(v.w * sc.w + sh.w, p.pro.act, slope);
-          }
+        const int iz = rz[i] + c.dz, iy = ry[i] + c.dy, ix = rx[i] + c.dx;
+        const bool ok = c.valid && (unsigned)iz < (unsigned)Di && (unsigned)iy < (unsigned)Hi &&
+                        (unsigned)ix < (unsigned)Wi;
+        const long off = ok ? (long)(rbase[i] + c.delta) * ldi + c.ci : 0;
+        ra[i] = *reinterpret_cast<const float4*>(gin + off);
+        amask |= (ok ? 1u : 0u) << i;
+        if (gscale && (nstride != 0 || i == 0)) {
+          const int si = rn[i] * nstride + c.ci;
+          rsc[i] = *reinterpret_cast<const float4*>(gscale + si);
+          rsh[i] = *reinterpret_cast<const float4*>(gshift + si);
         }
-        ra[i] = v;
       }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
-        int co = n0 + r0 + 32 * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t.valid && co < p.Cout)
-          v = *reinterpret_cast<const float4*>(p.wp + (long)co * Ktot + (long)t.tapflat * p.Cin + t.ci);
-        rb[i] = v;
+        const int co = n0 + r0 + 32 * i;
+        const bool ok = c.valid && co < Cout;
+        const long off = ok ? (long)co * Ktot + c.woff + c.ci : 0;
+        rb[i] = *reinterpret_cast<const float4*>(gw + off);
+        bmask |= (ok ? 1u : 0u) << i;
       }
     } else {
-      TapInfo t[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] = decode_k(p, ph, kidx + e, Kp);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ra[i].x = load_a_elem(i, t[0]);
-        ra[i].y = load_a_elem(i, t[1]);
-        ra[i].z = load_a_elem(i, t[2]);
-        ra[i].w = load_a_elem(i, t[3]);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const KCursor& c = cur[e];
+          const int iz = rz[i] + c.dz, iy = ry[i] + c.dy, ix = rx[i] + c.dx;
+          const bool ok = c.valid && (unsigned)iz < (unsigned)Di && (unsigned)iy < (unsigned)Hi &&
+                          (unsigned)ix < (unsigned)Wi;
+          const long off = ok ? (long)(rbase[i] + c.delta) * ldi + c.ci : 0;
+          float x = gin[off];
+          if (gscale) {
+            const int si = ok ? rn[i] * nstride + c.ci : 0;
+            x = act_apply(x * gscale[si] + gshift[si], act, slope);
+          }
+          v[e] = ok ? x : 0.f;
+        }
+        ra[i] = make_float4(v[0], v[1], v[2], v[3]);
       }
+      amask = 0xF;
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
-        int co = n0 + r0 + 32 * i;
+        const int co = n0 + r0 + 32 * i;
         float w[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          w[e] = (t[e].valid && co < p.Cout)
-                     ? p.wp[(long)co * Ktot + (long)t[e].tapflat * p.Cin + t[e].ci]
-                     : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          const KCursor& c = cur[e];
+          const bool ok = c.valid && co < Cout;
+          const float x = gw[ok ? (long)co * Ktot + c.woff + c.ci : 0];
+          w[e] = ok ? x : 0.f;
+        }
         rb[i] = make_float4(w[0], w[1], w[2], w[3]);
       }
+      bmask = 0xFF;
     }
+#pragma unroll
+    for (int e = 0; e < NCUR; ++e) advance(cur[e], BK);
   };
 
   auto lds_store = [&](int buf) {
     float* As = lds + buf * STAGE;
     float* Bs = As + BM * PITCH;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4*>(As + (r0 + 32 * i) * PITCH + cc * 4) = ra[i];
+    for (int i = 0; i < 4; ++i) {
+      float4 v = ra[i];
+      if constexpr (!SCALAR) {
+        if (gscale) {
+          const float4 sc = nstride != 0 ? rsc[i] : rsc[0], sh = nstride != 0 ? rsh[i] : rsh[0];
+          v.x = act_apply(v.x * sc.x + sh.x, act, slope);
+          v.y = act_apply(v.y * sc.y + sh.y, act, slope);
+          v.z = act_apply(v.z * sc.z + sh.z, act, slope);
+          v.w = act_apply(v.w * sc.w + sh.w, act, slope);
+        }
+        if (!((amask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      *reinterpret_cast<float4*>(As + (r0 + 32 * i) * PITCH + cc * 4) = v;
+    }
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i)
-      *reinterpret_cast<float4*>(Bs + (r0 + 32 * i) * PITCH + cc * 4) = rb[i];
+    for (int i = 0; i < BROWS; ++i) {
+      float4 v = rb[i];
+      if (!((bmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(Bs + (r0 + 32 * i) * PITCH + cc * 4) = v;
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -209,63 +271,81 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   if (nk > 0) {
-    global_load(0);
+    global_load();
     lds_store(0);
   }
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) global_load(kt + 1);
-    const float* As = lds + cur * STAGE + (wm * TM * 32 + li) * PITCH + 4 * lh;
-    const float* Bs = lds + cur * STAGE + BM * PITCH + (wn * TN * 32 + li) * PITCH + 4 * lh;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 a[TM], b[TN];
+    const int cb = kt & 1;
+    if (kt + 1 < nk) global_load();
+    const float* As = lds + cb * STAGE + (wm * TM * 32 + li) * PITCH + 4 * lh;
+    const float* Bs = lds + cb * STAGE + BM * PITCH + (wn * TN * 32 + li) * PITCH + 4 * lh;
+    // Fragment reads run one K-group (8 K) ahead of the MFMAs that consume them;
+    // sched_group_barrier pins "reads of group g+1, then MFMAs of group g" so the
+    // LDS latency hides under 16 MFMAs instead of stalling every 8.
+    float4 a[2][TM], b[2][TN];
+    auto read_group = [&](int g, int slot) {
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
-        a[tm] = *reinterpret_cast<const float4*>(As + tm * 32 * PITCH + 8 * g);
+        a[slot][tm] = *reinterpret_cast<const float4*>(As + tm * 32 * PITCH + 8 * g);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
-        b[tn] = *reinterpret_cast<const float4*>(Bs + tn * 32 * PITCH + 8 * g);
+        b[slot][tn] = *reinterpret_cast<const float4*>(Bs + tn * 32 * PITCH + 8 * g);
+    };
+    read_group(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int sl = g & 1;
+      if (g < 3) read_group(g + 1, sl ^ 1);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][tm].x, b[sl][tn].x, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][tm].y, b[sl][tn].y, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][tm].z, b[sl][tn].z, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][tm].w, b[sl][tn].w, acc[tm][tn], 0, 0, 0);
         }
+      if (g < 3) {
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);      // DS reads of the next group first
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);  // then this group's MFMAs
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (kt + 1 < nk) lds_store(cur ^ 1);
+    if (kt + 1 < nk) lds_store(cb ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue: row -> output pixel map through LDS, then bias/resid/tanh ----
   int* rowpix = reinterpret_cast<int*>(lds);
   if (tid < BM) {
-    long m = m0 + tid;
+    const unsigned m = (unsigned)m0 + tid;
     int pix = -1;
-    if (m < Mtot) {
-      int mx = (int)(m % ph.Mx);
-      long q = m / ph.Mx;
-      int my = (int)(q % ph.My);
-      q /= ph.My;
-      int mz = (int)(q % ph.Mz);
-      int n = (int)(q / ph.Mz);
+    if (m < (unsigned)Mtot) {
+      const unsigned uMx = ph.Mx, uMy = ph.My, uMz = ph.Mz;
+      int mx = (int)(m % uMx);
+      unsigned q = m / uMx;
+      int my = (int)(q % uMy);
+      q /= uMy;
+      int mz = (int)(q % uMz);
+      int n = (int)(q / uMz);
       int oz = mz * p.ostride[0] + ph.oz, oy = my * p.ostride[1] + ph.oy, ox = mx * p.ostride[2] + ph.ox;
       if (oz < p.Do && oy < p.Ho && ox < p.Wo) pix = ((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
     }
     rowpix[tid] = pix;
   }
   __syncthreads();
+  const float* gres = p.resid;
+  float* gout = p.out;
+  const int ldo = p.ldo, ldr = p.ldr, tanh_out = p.tanh_out;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int co = n0 + (wn * TN + tn) * 32 + li;
-      if (co >= p.Cout) continue;
+      if (co >= Cout) continue;
       const float bv = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -273,11 +353,222 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
         const int pix = rowpix[row];
         if (pix < 0) continue;
         float v = acc[tm][tn][r] + bv;
-        if (p.resid) v += p.resid[(long)pix * p.ldr + co];
-        if (p.tanh_out) v = tanhf(v);
-        p.out[(long)pix * p.ldo + co] = v;
+        if (gres) v += gres[(long)pix * ldr + co];
+        if (tanh_out) v = tanhf(v);
+        gout[(long)pix * ldo + co] = v;
       }
     }
+  if (p.stats) {
+    // Fused BatchNorm statistics: column sums of z = acc + bias over this tile's valid
+    // rows -- registers, then the two half-waves (shuffle), then the WM waves that share
+    // a column range (LDS, fixed order): deterministic, no atomics.
+    constexpr int WM = 4 / WN;
+    float* st = lds + 1024;                 // [WM][2][BN], clear of rowpix
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = (wn * TN + tn) * 32 + li;
+      const int co = n0 + col;
+      const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (rowpix[row] >= 0) {
+            const float v = acc[tm][tn][r] + bv;
+            sm += v;
+            sq += v * v;
+          }
+        }
+      sm += __shfl_xor(sm, 32, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      if (lh == 0) {
+        st[(wm * 2 + 0) * BN + col] = sm;
+        st[(wm * 2 + 1) * BN + col] = sq;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < Cout) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        sm += st[(w * 2 + 0) * BN + tid];
+        sq += st[(w * 2 + 1) * BN + tid];
+      }
+      float* row = p.stats + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * Cout;
+      row[n0 + tid] = sm;
+      row[Cout + n0 + tid] = sq;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Thin layers (1 input channel, or 1 output channel): HBM-bound stencils.  An
+// MFMA tile would be >= 97 % padding there, so these run on the vector ALUs with
+// the (tiny) weight set staged in LDS.  Same GatherConv geometry / phases.
+// ---------------------------------------------------------------------------
+struct PixDecode {
+  int n, bz, by, bx, opix;   // input base coords (m*istride) and output pixel (-1: none)
+};
+
+__device__ __forceinline__ PixDecode decode_pixel(const GatherConv& p, const Phase& ph, unsigned m) {
+  PixDecode d;
+  const unsigned uMx = ph.Mx, uMy = ph.My, uMz = ph.Mz;
+  const int mx = (int)(m % uMx);
+  unsigned q = m / uMx;
+  const int my = (int)(q % uMy);
+  q /= uMy;
+  const int mz = (int)(q % uMz);
+  d.n = (int)(q / uMz);
+  d.bz = mz * p.istride[0]; d.by = my * p.istride[1]; d.bx = mx * p.istride[2];
+  const int oz = mz * p.ostride[0] + ph.oz, oy = my * p.ostride[1] + ph.oy, ox = mx * p.ostride[2] + ph.ox;
+  d.opix = (oz < p.Do && oy < p.Ho && ox < p.Wo) ? ((d.n * p.Do + oz) * p.Ho + oy) * p.Wo + ox : -1;
+  return d;
+}
+
+// Cin == 1: one thread = one output pixel x V consecutive output channels.
+template <int V>
+__global__ __launch_bounds__(256) void thin_cin1_kernel(const GatherConv p) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [T][CoutPad]
+  const Phase ph = p.ph[blockIdx.z];
+  const int T = p.Kz * p.Ky * p.Kx;
+  const int CQ = (p.Cout + V - 1) / V, CP = CQ * V;
+  for (int i = threadIdx.x; i < T * CP; i += 256) {
+    const int t = i / CP, co = i - t * CP;
+    wl[i] = co < p.Cout ? p.wp[(long)co * T + t] : 0.f;
+  }
+  __syncthreads();
+  const unsigned Mtot = (unsigned)p.N * ph.Mz * ph.My * ph.Mx;
+  const unsigned gi = blockIdx.x * 256u + threadIdx.x;
+  const unsigned m = gi / (unsigned)CQ;
+  if (m >= Mtot) return;
+  const int co = (int)(gi - m * CQ) * V;
+  const PixDecode d = decode_pixel(p, ph, m);
+  if (d.opix < 0) return;
+  float acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = (p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
+  for (int jz = 0; jz < ph.nz; ++jz) {
+    const int iz = d.bz + ph.dz0 + p.dstep[0] * jz, kz = ph.kz0 + p.kstep[0] * jz;
+    if ((unsigned)iz >= (unsigned)p.Di) continue;
+    for (int jy = 0; jy < ph.ny; ++jy) {
+      const int iy = d.by + ph.dy0 + p.dstep[1] * jy, ky = ph.ky0 + p.kstep[1] * jy;
+      if ((unsigned)iy >= (unsigned)p.Hi) continue;
+      const long rowbase = (((long)d.n * p.Di + iz) * p.Hi + iy) * p.Wi;
+      for (int jx = 0; jx < ph.nx; ++jx) {
+        const int ix = d.bx + ph.dx0 + p.dstep[2] * jx, kx = ph.kx0 + p.kstep[2] * jx;
+        if ((unsigned)ix >= (unsigned)p.Wi) continue;
+        const float x = p.in[(rowbase + ix) * p.ldi];
+        const float* w = wl + ((kz * p.Ky + ky) * p.Kx + kx) * CP + co;
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = fmaf(x, w[e], acc[e]);
+      }
+    }
+  }
+  float* o = p.out + (long)d.opix * p.ldo + co;
+  const float* r = p.resid ? p.resid + (long)d.opix * p.ldr + co : nullptr;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    if (co + e >= p.Cout) break;
+    float v = acc[e];
+    if (r) v += r[e];
+    if (p.tanh_out) v = tanhf(v);
+    acc[e] = v;
+  }
+  if (V == 4 && co + 3 < p.Cout)
+    *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  else
+    for (int e = 0; e < V && co + e < p.Cout; ++e) o[e] = acc[e];
+}
+
+// Cout == 1: LANES = Cin/4 lanes share one output pixel (16-byte channel chunks,
+// coalesced rows), then a shuffle reduction.
+template <int LANES>
+__global__ __launch_bounds__(256) void thin_cout1_kernel(const GatherConv p) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [T][Cin]
+  const Phase ph = p.ph[blockIdx.z];
+  const int T = p.Kz * p.Ky * p.Kx;
+  for (int i = threadIdx.x; i < T * p.Cin; i += 256) wl[i] = p.wp[i];
+  __syncthreads();
+  const unsigned Mtot = (unsigned)p.N * ph.Mz * ph.My * ph.Mx;
+  const unsigned gi = blockIdx.x * 256u + threadIdx.x;
+  const unsigned m = gi / LANES;
+  const int l = (int)(gi % LANES);
+  const bool live = m < Mtot;
+  PixDecode d = decode_pixel(p, ph, live ? m : 0u);
+  float acc = 0.f;
+  if (live && d.opix >= 0) {
+    for (int jz = 0; jz < ph.nz; ++jz) {
+      const int iz = d.bz + ph.dz0 + p.dstep[0] * jz, kz = ph.kz0 + p.kstep[0] * jz;
+      if ((unsigned)iz >= (unsigned)p.Di) continue;
+      for (int jy = 0; jy < ph.ny; ++jy) {
+        const int iy = d.by + ph.dy0 + p.dstep[1] * jy, ky = ph.ky0 + p.kstep[1] * jy;
+        if ((unsigned)iy >= (unsigned)p.Hi) continue;
+        const long rowbase = (((long)d.n * p.Di + iz) * p.Hi + iy) * p.Wi;
+        for (int jx = 0; jx < ph.nx; ++jx) {
+          const int ix = d.bx + ph.dx0 + p.dstep[2] * jx, kx = ph.kx0 + p.kstep[2] * jx;
+          if ((unsigned)ix >= (unsigned)p.Wi) continue;
+          const float4 v = *reinterpret_cast<const float4*>(p.in + (rowbase + ix) * p.ldi + 4 * l);
+          const float4 w = *reinterpret_cast<const float4*>(wl + ((kz * p.Ky + ky) * p.Kx + kx) * p.Cin + 4 * l);
+          acc = fmaf(v.x, w.x, acc);
+          acc = fmaf(v.y, w.y, acc);
+          acc = fmaf(v.z, w.z, acc);
+          acc = fmaf(v.w, w.w, acc);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = LANES / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (live && d.opix >= 0 && l == 0) {
+    float v = acc + (p.bias ? p.bias[0] : 0.f);
+    if (p.resid) v += p.resid[(long)d.opix * p.ldr];
+    if (p.tanh_out) v = tanhf(v);
+    p.out[(long)d.opix * p.ldo] = v;
+  }
+}
+
+static bool thin_cin1_ok(const GatherConv& p) {
+  const int T = p.Kz * p.Ky * p.Kx;
+  return p.Cin == 1 && !p.pro.scale && (long)T * ((p.Cout + 3) / 4 * 4) * 4 <= 48 * 1024;
+}
+
+static bool thin_cout1_ok(const GatherConv& p) {
+  const int T = p.Kz * p.Ky * p.Kx;
+  const int lanes = p.Cin / 4;
+  return p.Cout == 1 && !p.pro.scale && p.Cin % 4 == 0 && p.ldi % 4 == 0 && lanes >= 1 && lanes <= 64 &&
+         (lanes & (lanes - 1)) == 0 && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0) &&
+         (long)T * p.Cin * 4 <= 48 * 1024;
+}
+
+static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
+  const int T = p.Kz * p.Ky * p.Kx;
+  if (thin_cin1_ok(p)) {
+    const bool v4 = (p.Cout % 4 == 0) && (p.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+    const int V = v4 ? 4 : 1;
+    const int CQ = (p.Cout + V - 1) / V;
+    const long threads = maxM * CQ;
+    dim3 grid((unsigned)((threads + 255) / 256), 1, (unsigned)p.nphase);
+    const size_t smem = (size_t)T * CQ * V * sizeof(float);
+    if (v4) hipLaunchKernelGGL(thin_cin1_kernel<4>, grid, dim3(256), smem, st, p);
+    else hipLaunchKernelGGL(thin_cin1_kernel<1>, grid, dim3(256), smem, st, p);
+    return check_launch("thin_cin1");
+  }
+  const int lanes = p.Cin / 4;
+  const long threads = maxM * lanes;
+  dim3 grid((unsigned)((threads + 255) / 256), 1, (unsigned)p.nphase);
+  const size_t smem = (size_t)T * p.Cin * sizeof(float);
+  switch (lanes) {
+    case 1: hipLaunchKernelGGL(thin_cout1_kernel<1>, grid, dim3(256), smem, st, p); break;
+    case 2: hipLaunchKernelGGL(thin_cout1_kernel<2>, grid, dim3(256), smem, st, p); break;
+    case 4: hipLaunchKernelGGL(thin_cout1_kernel<4>, grid, dim3(256), smem, st, p); break;
+    case 8: hipLaunchKernelGGL(thin_cout1_kernel<8>, grid, dim3(256), smem, st, p); break;
+    case 16: hipLaunchKernelGGL(thin_cout1_kernel<16>, grid, dim3(256), smem, st, p); break;
+    case 32: hipLaunchKernelGGL(thin_cout1_kernel<32>, grid, dim3(256), smem, st, p); break;
+    default: hipLaunchKernelGGL(thin_cout1_kernel<64>, grid, dim3(256), smem, st, p); break;
+  }
+  return check_launch("thin_cout1");
 }
 
 template <int BN, int TM, int TN, int WN, bool SCALAR>
@@ -299,26 +590,50 @@ static int launch_variant(const GatherConv& p, long maxM, hipStream_t st) {
   return check_launch("gather_conv");
 }
 
-static int launch_gather(const GatherConv& p, hipStream_t st) {
+// Kernel selection, shared by the launcher and mpgan_conv_variant():
+//   1 = thin_cin1, 2 = thin_cout1, 32/64/128 = gather_conv_kernel<BN>.
+static long max_phase_pixels(const GatherConv& p) {
   long maxM = 0;
   for (int i = 0; i < p.nphase; ++i) {
     long m = (long)p.N * p.ph[i].Mz * p.ph[i].My * p.ph[i].Mx;
     if (m > maxM) maxM = m;
   }
+  return maxM;
+}
+
+static int select_variant(const GatherConv& p, long maxM, bool thin1, bool thin2) {
+  if (thin1) return 1;
+  if (thin2) return 2;
+  // Largest channel tile that still yields >= 2 blocks per CU; small-M layers (the
+  // U-Net bottom: 16K pixels) take narrower tiles rather than leave CUs idle.
+  const long mtiles = (maxM + BM - 1) / BM * p.nphase;
+  int bn = 32;
+  if (p.Cout > 64 && mtiles * ((p.Cout + 127) / 128) >= 512) bn = 128;
+  else if (p.Cout > 32 && mtiles * ((p.Cout + 63) / 64) >= 512) bn = 64;
+  else if (p.Cout > 64 && mtiles * ((p.Cout + 31) / 32) < 256) bn = 64;   // tiny problem: fewer, fatter tiles
+  return bn;
+}
+
+static int launch_gather(const GatherConv& p, hipStream_t st) {
+  const long maxM = max_phase_pixels(p);
   if (maxM == 0) return MPGAN_OK;
-  MPGAN_CHECK_ARG((long)p.N * p.Do * p.Ho * p.Wo < (1L << 31), "gather_conv: too many output pixels");
+  MPGAN_CHECK_ARG((long)p.N * p.Do * p.Ho * p.Wo < (1L << 31) && (long)p.N * p.Di * p.Hi * p.Wi < (1L << 31) &&
+                      maxM < (1L << 31) - 256,
+                  "gather_conv: more than 2^31 pixels");
+  const int variant = select_variant(p, maxM, thin_cin1_ok(p), thin_cout1_ok(p));
+  if (variant <= 2) return launch_thin(p, maxM, st);
   const bool vec = (p.Cin % 4 == 0) && (p.ldi % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0) &&
                    (!p.pro.scale || (((reinterpret_cast<uintptr_t>(p.pro.scale) |
                                        reinterpret_cast<uintptr_t>(p.pro.shift)) & 15) == 0 &&
                                      p.pro.n_stride % 4 == 0));
   if (vec) {
-    if (p.Cout > 64) return launch_variant<128, 2, 2, 2, false>(p, maxM, st);
-    if (p.Cout > 32) return launch_variant<64, 1, 2, 1, false>(p, maxM, st);
+    if (variant == 128) return launch_variant<128, 2, 2, 2, false>(p, maxM, st);
+    if (variant == 64) return launch_variant<64, 1, 2, 1, false>(p, maxM, st);
     return launch_variant<32, 1, 1, 1, false>(p, maxM, st);
   }
-  if (p.Cout > 64) return launch_variant<128, 2, 2, 2, true>(p, maxM, st);
-  if (p.Cout > 32) return launch_variant<64, 1, 2, 1, true>(p, maxM, st);
+  if (variant == 128) return launch_variant<128, 2, 2, 2, true>(p, maxM, st);
+  if (variant == 64) return launch_variant<64, 1, 2, 1, true>(p, maxM, st);
   return launch_variant<32, 1, 1, 1, true>(p, maxM, st);
 }
 
@@ -393,9 +708,26 @@ static void build_transposed(GatherConv& p, int n, const int32_t* gath_dhw, int 
 
 using namespace mpgan;
 
+extern "C" int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward_data, int32_t has_prologue);
+
+static void build_for_forward(GatherConv& p, const mpgan_conv_geom* g) {
+  if (!g->transposed)
+    build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+  else
+    build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+}
+
+extern "C" int32_t mpgan_conv_stats_rows(const mpgan_conv_geom* g, int32_t has_prologue) {
+  const int v = mpgan_conv_variant(g, 0, has_prologue);
+  if (v < 32) return 0;   // thin VALU kernels (or invalid geometry): no fused statistics
+  GatherConv p{};
+  build_for_forward(p, g);
+  return (int32_t)((max_phase_pixels(p) + BM - 1) / BM) * p.nphase;
+}
+
 extern "C" int mpgan_conv_forward(const mpgan_conv_geom* g, const float* x, int32_t ldx, const float* w_packed,
                                   const float* bias, const mpgan_prologue* pro, const float* resid, int32_t ldr,
-                                  int32_t tanh_out, float* y, int32_t ldy, void* stream) {
+                                  int32_t tanh_out, float* stats_partials, float* y, int32_t ldy, void* stream) {
   int rc = check_geom(g);
   if (rc) return rc;
   MPGAN_CHECK_ARG(x && w_packed && y, "conv_forward: null pointer");
@@ -404,10 +736,14 @@ extern "C" int mpgan_conv_forward(const mpgan_conv_geom* g, const float* x, int3
   p.in = x; p.wp = w_packed; p.out = y; p.bias = bias; p.resid = resid;
   p.pro = make_pro(pro);
   p.ldi = ldx; p.ldo = ldy; p.ldr = ldr; p.tanh_out = tanh_out;
-  if (!g->transposed)
-    build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
-  else
-    build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+  build_for_forward(p, g);
+  if (stats_partials) {
+    MPGAN_CHECK_ARG(!resid && !tanh_out, "conv_forward: fused statistics describe the raw conv output (no resid/tanh)");
+    MPGAN_UNSUPPORTED(mpgan_conv_stats_rows(g, pro && pro->scale) == 0,
+                      "conv_forward: this geometry runs on a thin kernel without fused statistics "
+                      "(mpgan_conv_stats_rows() == 0): use mpgan_channel_stats");
+    p.stats = stats_partials;
+  }
   return launch_gather(p, (hipStream_t)stream);
 }
 
@@ -427,4 +763,30 @@ extern "C" int mpgan_conv_backward_data(const mpgan_conv_geom* g, const float* d
   else
     build_forward(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
   return launch_gather(p, (hipStream_t)stream);
+}
+
+extern "C" int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward_data, int32_t has_prologue) {
+  if (check_geom(g)) return -1;
+  GatherConv p{};
+  static const float dummy[4] = {0, 0, 0, 0};
+  p.in = dummy;  // 16-byte aligned stand-ins: only geometry drives the choice
+  p.pro = make_pro(nullptr);
+  if (has_prologue) p.pro.scale = dummy;
+  const int cg = backward_data ? g->cout : g->cin, cp = backward_data ? g->cin : g->cout;
+  const int32_t* gd = backward_data ? g->out_dhw : g->in_dhw;
+  const int32_t* pd = backward_data ? g->in_dhw : g->out_dhw;
+  if (backward_data) {
+    if (!g->transposed) build_transposed(p, g->n, gd, cg, pd, cp, g->k, g->stride, g->pad);
+    else build_forward(p, g->n, gd, cg, pd, cp, g->k, g->stride, g->pad);
+  } else {
+    if (!g->transposed) build_forward(p, g->n, gd, cg, pd, cp, g->k, g->stride, g->pad);
+    else build_transposed(p, g->n, gd, cg, pd, cp, g->k, g->stride, g->pad);
+  }
+  p.ldi = cg;
+  const int T = p.Kz * p.Ky * p.Kx;
+  const bool t1 = p.Cin == 1 && !p.pro.scale && (long)T * ((p.Cout + 3) / 4 * 4) * 4 <= 48 * 1024;
+  const int lanes = p.Cin / 4;
+  const bool t2 = p.Cout == 1 && !p.pro.scale && p.Cin % 4 == 0 && lanes >= 1 && lanes <= 64 &&
+                  (lanes & (lanes - 1)) == 0 && (long)T * p.Cin * 4 <= 48 * 1024;
+  return select_variant(p, max_phase_pixels(p), t1, t2);
 }

@@ -23,6 +23,7 @@ struct WgradParams {
   const float* dense;
   const float* gath;
   float* partial;  // [split][Cd][T*Cg]
+  float* bias_partial;  // [split][Cd] column sums of the dense operand (fused bias gradient) or null
   Pro pro;         // prologue on the gathered operand
   int ldd, Cd, ldg, Cg;
   int N, Mz, My, Mx;  // coarse grid
@@ -87,6 +88,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int dcc = tid % DCH, drow0 = tid / DCH;      // rows drow0 + (256/DCH)*i
 
   float4 rd[DLOADS], rg[GLOADS];
+  float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);   // fused bias gradient: column sums of the dense rows
+
+  // pixel cursors of this thread's gathered rows: divisions once, then += 32 with carries
+  constexpr int GROWSTEP = 256 / GCH;
+  int cn[GLOADS], cz[GLOADS], cy[GLOADS], cx[GLOADS];
+#pragma unroll
+  for (int i = 0; i < GLOADS; ++i) {
+    const unsigned um = (unsigned)(mbeg + grow0 + GROWSTEP * i), uMx = p.Mx, uMy = p.My, uMz = p.Mz;
+    cx[i] = (int)(um % uMx);
+    unsigned q = um / uMx;
+    cy[i] = (int)(q % uMy);
+    q /= uMy;
+    cz[i] = (int)(q % uMz);
+    cn[i] = (int)(q / uMz);
+  }
 
   auto global_load = [&](int kt) {
     const long mb = mbeg + (long)kt * WBK;
@@ -94,70 +110,69 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     for (int i = 0; i < DLOADS; ++i) {
       const long m = mb + drow0 + (256 / DCH) * i;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < mend) {
-        const int c = d0 + dcc * 4;
-        if constexpr (!SCALAR_D) {
-          if (c < p.Cd) v = *reinterpret_cast<const float4*>(p.dense + m * p.ldd + c);
-        } else {
-          const float* src = p.dense + m * p.ldd;
-          if (c + 0 < p.Cd) v.x = src[c + 0];
-          if (c + 1 < p.Cd) v.y = src[c + 1];
-          if (c + 2 < p.Cd) v.z = src[c + 2];
-          if (c + 3 < p.Cd) v.w = src[c + 3];
-        }
+      const int c = d0 + dcc * 4;
+      if constexpr (!SCALAR_D) {
+        const bool ok = m < mend && c < p.Cd;
+        v = *reinterpret_cast<const float4*>(p.dense + (ok ? m * p.ldd + c : 0));
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (m < mend) {
+        const float* src = p.dense + m * p.ldd;
+        if (c + 0 < p.Cd) v.x = src[c + 0];
+        if (c + 1 < p.Cd) v.y = src[c + 1];
+        if (c + 2 < p.Cd) v.z = src[c + 2];
+        if (c + 3 < p.Cd) v.w = src[c + 3];
       }
       rd[i] = v;
+      bacc.x += v.x; bacc.y += v.y; bacc.z += v.z; bacc.w += v.w;
     }
-    if (GTHREADS >= 256 || tid < GTHREADS) {
 #pragma unroll
-      for (int i = 0; i < GLOADS; ++i) {
-        const long m = mb + grow0 + (256 / GCH) * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < mend) {
-          int mx = (int)(m % p.Mx);
-          long q = m / p.Mx;
-          int my = (int)(q % p.My);
-          q /= p.My;
-          int mz = (int)(q % p.Mz);
-          int n = (int)(q / p.Mz);
-          const int bz = mz * p.sz - p.pz, by = my * p.sy - p.py, bx = mx * p.sx - p.px;
-          if constexpr (!SCALAR_G) {
-            int iz = bz + gkz[0], iy = by + gky[0], ix = bx + gkx[0];
-            if (gvalid[0] && (unsigned)iz < (unsigned)p.Gz && (unsigned)iy < (unsigned)p.Gy &&
-                (unsigned)ix < (unsigned)p.Gx) {
-              long pix = (((long)n * p.Gz + iz) * p.Gy + iy) * p.Gx + ix;
-              v = *reinterpret_cast<const float4*>(p.gath + pix * p.ldg + gci[0]);
-              if (p.pro.scale) {
-                int si = n * p.pro.n_stride + gci[0];
-                float4 sc = *reinterpret_cast<const float4*>(p.pro.scale + si);
-                float4 sh = *reinterpret_cast<const float4*>(p.pro.shift + si);
-                v.x = act_apply(v.x * sc.x + sh.x, p.pro.act, slope);
-                v.y = act_apply(v.y * sc.y + sh.y, p.pro.act, slope);
-                v.z = act_apply(v.z * sc.z + sh.z, p.pro.act, slope);
-                v.w = act_apply(v.w * sc.w + sh.w, p.pro.act, slope);
-              }
-            }
-          } else {
-            float w[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              w[e] = 0.f;
-              int iz = bz + gkz[e], iy = by + gky[e], ix = bx + gkx[e];
-              if (gvalid[e] && (unsigned)iz < (unsigned)p.Gz && (unsigned)iy < (unsigned)p.Gy &&
-                  (unsigned)ix < (unsigned)p.Gx) {
-                long pix = (((long)n * p.Gz + iz) * p.Gy + iy) * p.Gx + ix;
-                float x = p.gath[pix * p.ldg + gci[e]];
-                if (p.pro.scale) {
-                  int si = n * p.pro.n_stride + gci[e];
-                  x = act_apply(x * p.pro.scale[si] + p.pro.shift[si], p.pro.act, slope);
-                }
-                w[e] = x;
-              }
-            }
-            v = make_float4(w[0], w[1], w[2], w[3]);
-          }
+    for (int i = 0; i < GLOADS; ++i) {
+      const long m = mb + grow0 + GROWSTEP * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int n = cn[i];
+      const int bz = cz[i] * p.sz - p.pz, by = cy[i] * p.sy - p.py, bx = cx[i] * p.sx - p.px;
+      if constexpr (!SCALAR_G) {
+        const int iz = bz + gkz[0], iy = by + gky[0], ix = bx + gkx[0];
+        const bool ok = m < mend && gvalid[0] && (unsigned)iz < (unsigned)p.Gz && (unsigned)iy < (unsigned)p.Gy &&
+                        (unsigned)ix < (unsigned)p.Gx;
+        const long pix = (((long)n * p.Gz + iz) * p.Gy + iy) * p.Gx + ix;
+        v = *reinterpret_cast<const float4*>(p.gath + (ok ? pix * p.ldg + gci[0] : 0));
+        if (p.pro.scale) {
+          const int si = ok ? n * p.pro.n_stride + gci[0] : 0;
+          const float4 sc = *reinterpret_cast<const float4*>(p.pro.scale + si);
+          const float4 sh = *reinterpret_cast<const float4*>(p.pro.shift + si);
+          v.x = act_apply(v.x * sc.x + sh.x, p.pro.act, slope);
+          v.y = act_apply(v.y * sc.y + sh.y, p.pro.act, slope);
+          v.z = act_apply(v.z * sc.z + sh.z, p.pro.act, slope);
+          v.w = act_apply(v.w * sc.w + sh.w, p.pro.act, slope);
         }
-        rg[i] = v;
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int iz = bz + gkz[e], iy = by + gky[e], ix = bx + gkx[e];
+          const bool ok = m < mend && gvalid[e] && (unsigned)iz < (unsigned)p.Gz &&
+                          (unsigned)iy < (unsigned)p.Gy && (unsigned)ix < (unsigned)p.Gx;
+          const long pix = (((long)n * p.Gz + iz) * p.Gy + iy) * p.Gx + ix;
+          float x = p.gath[ok ? pix * p.ldg + gci[e] : 0];
+          if (p.pro.scale) {
+            const int si = ok ? n * p.pro.n_stride + gci[e] : 0;
+            x = act_apply(x * p.pro.scale[si] + p.pro.shift[si], p.pro.act, slope);
+          }
+          w[e] = ok ? x : 0.f;
+        }
+        v = make_float4(w[0], w[1], w[2], w[3]);
+      }
+      rg[i] = v;
+      // advance this row's cursor by one K-step (32 pixels)
+      cx[i] += WBK;
+      while (cx[i] >= p.Mx) {
+        cx[i] -= p.Mx;
+        if (++cy[i] == p.My) {
+          cy[i] = 0;
+          if (++cz[i] == p.Mz) { cz[i] = 0; ++cn[i]; }
+        }
       }
     }
   };
@@ -168,11 +183,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int i = 0; i < DLOADS; ++i)
       *reinterpret_cast<float4*>(Ds + (drow0 + (256 / DCH) * i) * BD + dcc * 4) = rd[i];
-    if (GTHREADS >= 256 || tid < GTHREADS) {
 #pragma unroll
-      for (int i = 0; i < GLOADS; ++i)
-        *reinterpret_cast<float4*>(Gs + (grow0 + (256 / GCH) * i) * BG + gcc * 4) = rg[i];
-    }
+    for (int i = 0; i < GLOADS; ++i)
+      *reinterpret_cast<float4*>(Gs + (grow0 + (256 / GCH) * i) * BG + gcc * 4) = rg[i];
   };
 
   f32x16 acc[TM][TN];
@@ -193,25 +206,54 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     if (kt + 1 < nk) global_load(kt + 1);
     const float* Ds = lds + cur * STAGE + wm * TM * 32 + li;
     const float* Gs = lds + cur * STAGE + WBK * BD + wn * TN * 32 + li;
+    // fragment reads run one group (4 MFMA K-steps) ahead of their MFMAs
+    constexpr int NG = (16 / KW) / 4;              // groups of 4 steps: 4 (KW=1) or 1 (KW=4)
+    float a[2][4][TM], b[2][4][TN];
+    auto read_group = [&](int g, int slot) {
 #pragma unroll
-    for (int s0 = 0; s0 < 16 / KW; ++s0) {
-      const int s = KW == 1 ? s0 : s0 + (16 / KW) * wid;
-      const int kk = 2 * s + lh;
-      float a[TM], b[TN];
+      for (int q = 0; q < 4; ++q) {
+        const int s = (KW == 1 ? 0 : (16 / KW) * wid) + 4 * g + q;
+        const int kk = 2 * s + lh;
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) a[tm] = Ds[kk * BD + tm * 32];
+        for (int tm = 0; tm < TM; ++tm) a[slot][q][tm] = Ds[kk * BD + tm * 32];
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) b[tn] = Gs[kk * BG + tn * 32];
+        for (int tn = 0; tn < TN; ++tn) b[slot][q][tn] = Gs[kk * BG + tn * 32];
+      }
+    };
+    read_group(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+    for (int g = 0; g < NG; ++g) {
+      const int sl = g & 1;
+      if (g + 1 < NG) read_group(g + 1, sl ^ 1);
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][q][tm], b[sl][q][tn], acc[tm][tn], 0, 0, 0);
+      if (g + 1 < NG) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (kt + 1 < nk) lds_store(cur ^ 1);
     __syncthreads();
   }
 
+  if (p.bias_partial != nullptr && blockIdx.x == 0) {
+    // block-reduce the per-thread column sums over the (256/DCH) row groups, fixed order
+    float* red = lds;   // [256/DCH][BD]; the K-loop is done with LDS
+    *reinterpret_cast<float4*>(red + drow0 * BD + dcc * 4) = bacc;
+    __syncthreads();
+    if (tid < BD && d0 + tid < p.Cd) {
+      float t = 0.f;
+      for (int r = 0; r < 256 / DCH; ++r) t += red[r * BD + tid];
+      p.bias_partial[(long)blockIdx.z * p.Cd + d0 + tid] = t;
+    }
+  }
   float* out = p.partial + ((long)blockIdx.z * KW + (KW == 1 ? 0 : wid)) * p.Cd * NC;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
@@ -228,21 +270,47 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 }
 
 // dW[cd][cg][t] = beta*dW + sum_split partial[split][cd][t*Cg+cg]
+// block = 32 consecutive elements x 8 split lanes; lanes sum their splits in
+// order, then the 8 lane sums are added in order: deterministic.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                            int nsplit, int Cd, int Cg, int T, float beta) {
+  __shared__ float sh[8][33];
   const long total = (long)Cd * Cg * T;
   const long NC = (long)T * Cg;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    // i enumerates the partial layout (coalesced reads): cd, t, cg
-    const long cd = i / NC;
-    const long rem = i - cd * NC;
-    const int t = (int)(rem / Cg);
-    const int cg = (int)(rem - (long)t * Cg);
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (long base = (long)blockIdx.x * 32; base < total; base += (long)gridDim.x * 32) {
+    const long i = base + e;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(long)k * total + i];
-    const long o = (cd * Cg + cg) * T + t;
-    dw[o] = beta != 0.f ? beta * dw[o] + s : s;
+    if (i < total)
+      for (int k = sl; k < nsplit; k += 8) s += partial[(long)k * total + i];
+    sh[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      float t = sh[0][e];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += sh[k][e];
+      const long cd = i / NC;
+      const long rem = i - cd * NC;
+      const int tt = (int)(rem / Cg);
+      const int cg = (int)(rem - (long)tt * Cg);
+      const long o = (cd * Cg + cg) * T + tt;
+      dw[o] = beta != 0.f ? beta * dw[o] + t : t;
+    }
+    __syncthreads();
   }
+}
+
+// db[c] += sum_split bias_partial[split][c]  (one wave per channel, fixed order)
+__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bp, int nsplit, int Cd,
+                                                                float* __restrict__ db, float beta) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gt >> 6, lane = threadIdx.x & 63;
+  if (c >= Cd) return;
+  double s = 0.0;
+  for (int k = lane; k < nsplit; k += 64) s += (double)bp[(long)k * Cd + c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) db[c] = beta != 0.f ? beta * db[c] + (float)s : (float)s;
 }
 
 struct WgradPlan {
@@ -262,11 +330,11 @@ static WgradPlan plan_wgrad(int Cd, int NC, long M) {
   pl.tiles_d = (Cd + pl.BD - 1) / pl.BD;
   long tiles = (long)pl.tiles_c * pl.tiles_d;
   long want = (1024 + tiles - 1) / tiles;          // ~4 blocks per CU in total
-  long maxsplit = (M + 255) / 256;                 // at least 256 pixels per split
+  long maxsplit = M / 1024;                        // at least 32 K-steps per split
   if (maxsplit < 1) maxsplit = 1;
   long ns = want < maxsplit ? want : maxsplit;
   if (ns < 1) ns = 1;
-  if (ns > 512) ns = 512;
+  if (ns > 256) ns = 256;
   long chunk = (M + ns - 1) / ns;
   chunk = (chunk + WBK - 1) / WBK * WBK;
   ns = (M + chunk - 1) / chunk;
@@ -329,23 +397,33 @@ extern "C" int64_t mpgan_conv_wgrad_workspace(const mpgan_conv_geom* g) {
   long M;
   wgrad_dims(g, Cd, Cg, T, M);
   WgradPlan pl = plan_wgrad(Cd, T * Cg, M);
-  return (int64_t)pl.nsplit * pl.kw * Cd * T * Cg * (int64_t)sizeof(float);
+  return ((int64_t)pl.nsplit * pl.kw * Cd * T * Cg + (int64_t)pl.nsplit * Cd) * (int64_t)sizeof(float);
 }
 
 extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float* x, int32_t ldx,
                                           const mpgan_prologue* pro, const float* dy, int32_t lddy, float* dw,
-                                          float beta, void* workspace, int64_t workspace_bytes, void* stream) {
+                                          float* dbias, float beta, void* workspace, int64_t workspace_bytes,
+                                          void* stream) {
   MPGAN_CHECK_ARG(g && x && dy && dw && workspace, "conv_backward_weight: null pointer");
   MPGAN_CHECK_ARG(ldx >= g->cin && lddy >= g->cout, "conv_backward_weight: bad pitch");
   int Cd, Cg, T;
   long M;
   wgrad_dims(g, Cd, Cg, T, M);
+  MPGAN_CHECK_ARG(M < (1L << 31) - 64 &&
+                      (long)g->n * g->in_dhw[0] * g->in_dhw[1] * g->in_dhw[2] < (1L << 31) &&
+                      (long)g->n * g->out_dhw[0] * g->out_dhw[1] * g->out_dhw[2] < (1L << 31),
+                  "conv_backward_weight: more than 2^31 pixels");
   WgradPlan pl = plan_wgrad(Cd, T * Cg, M);
-  const int64_t need = (int64_t)pl.nsplit * pl.kw * Cd * T * Cg * (int64_t)sizeof(float);
+  const int64_t slab_floats = (int64_t)pl.nsplit * pl.kw * Cd * T * Cg;
+  const int64_t need = (slab_floats + (int64_t)pl.nsplit * Cd) * (int64_t)sizeof(float);
   MPGAN_CHECK_ARG(workspace_bytes >= need, "conv_backward_weight: workspace %lld < %lld bytes",
                   (long long)workspace_bytes, (long long)need);
   WgradParams p{};
   p.partial = static_cast<float*>(workspace);
+  MPGAN_UNSUPPORTED(dbias && g->transposed,
+                    "conv_backward_weight: fused bias gradient is for ConvNd only (dy is the gathered operand of a "
+                    "transposed conv)");
+  p.bias_partial = dbias ? p.partial + slab_floats : nullptr;
   p.Kz = g->k[0]; p.Ky = g->k[1]; p.Kx = g->k[2];
   p.sz = g->stride[0]; p.sy = g->stride[1]; p.sx = g->stride[2];
   p.pz = g->pad[0]; p.py = g->pad[1]; p.px = g->pad[2];
@@ -378,8 +456,11 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
   else rc = dispatch_wgrad<true, true>(p, pl, st);
   if (rc) return rc;
   const long total = (long)Cd * Cg * T;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = (int)((total + 31) / 32);
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, pl.nsplit * pl.kw, Cd, Cg, T, beta);
+  if (dbias)
+    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Cd + 3) / 4), dim3(256), 0, st, p.bias_partial, pl.nsplit, Cd,
+                       dbias, beta);
   return check_launch("wgrad_reduce");
 }

@@ -117,6 +117,14 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
   });
 }
 
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// One wave per statistic: lanes stride over the partial rows (fixed assignment),
+// then a fixed butterfly -- deterministic, and no longer a serial 1000-row walk.
 __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ partials, int N, int chunks,
                                                             int C, long P, int instance,
                                                             const float* __restrict__ gamma,
@@ -126,18 +134,23 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restr
                                                             float* __restrict__ shift, float* __restrict__ mean,
                                                             float* __restrict__ invstd) {
   const int total = instance ? N * C : C;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && nbt) *nbt += 1;
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gt >> 6, lane = threadIdx.x & 63;
+  if (gt == 0 && nbt) *nbt += 1;
   if (i >= total) return;
   const int c = instance ? i % C : i;
   const int nb = instance ? i / C : 0, ne = instance ? nb + 1 : N;
+  const int rows = (ne - nb) * chunks;
+  const float* base = partials + (long)nb * chunks * 2 * C;
   double s = 0.0, ss = 0.0;
-  for (int n = nb; n < ne; ++n)
-    for (int k = 0; k < chunks; ++k) {
-      const float* row = partials + ((long)n * chunks + k) * 2 * C;
-      s += (double)row[c];
-      ss += (double)row[C + c];
-    }
+  for (int r = lane; r < rows; r += 64) {
+    const float* row = base + (long)r * 2 * C;
+    s += (double)row[c];
+    ss += (double)row[C + c];
+  }
+  s = wave_sum_d(s);
+  ss = wave_sum_d(ss);
+  if (lane != 0) return;
   const double cnt = (double)P * (ne - nb);
   const double m = s / cnt;
   double var = ss / cnt - m * m;
@@ -156,46 +169,64 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restr
   }
 }
 
-// one block; thread-strided over channels; deterministic
+// One wave per channel.  slope_tmp[c] receives the channel's PReLU-slope term.
 __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __restrict__ partials, int N, int chunks,
                                                                 int C, long P, int instance, float* dgamma,
-                                                                float* dbeta, float* dslope, float* __restrict__ c1,
-                                                                float* __restrict__ c2) {
-  __shared__ double sred[256];
-  double slope_acc = 0.0;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double t1 = 0.0, t2 = 0.0, t3 = 0.0;
-    for (int n = 0; n < N; ++n) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int k = 0; k < chunks; ++k) {
-        const float* row = partials + ((long)n * chunks + k) * 3 * C;
-        s1 += (double)row[c];
-        s2 += (double)row[C + c];
-        t3 += (double)row[2 * C + c];
-      }
-      t1 += s1;
-      t2 += s2;
-      if (instance) {
-        c1[n * C + c] = (float)(s1 / (double)P);
-        c2[n * C + c] = (float)(s2 / (double)P);
-      }
+                                                                float* dbeta, float* __restrict__ slope_tmp,
+                                                                float* __restrict__ c1, float* __restrict__ c2) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gt >> 6, lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double t1 = 0.0, t2 = 0.0, s3 = 0.0;
+  if (!instance) {
+    double s1 = 0.0, s2 = 0.0;
+    const int rows = N * chunks;
+    for (int r = lane; r < rows; r += 64) {
+      const float* row = partials + (long)r * 3 * C;
+      s1 += (double)row[c];
+      s2 += (double)row[C + c];
+      s3 += (double)row[2 * C + c];
     }
-    if (!instance) {
+    t1 = wave_sum_d(s1);
+    t2 = wave_sum_d(s2);
+    if (lane == 0) {
       const double cnt = (double)P * N;
       c1[c] = (float)(t1 / cnt);
       c2[c] = (float)(t2 / cnt);
     }
+  } else {
+    for (int n = 0; n < N; ++n) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = lane; k < chunks; k += 64) {
+        const float* row = partials + ((long)n * chunks + k) * 3 * C;
+        s1 += (double)row[c];
+        s2 += (double)row[C + c];
+        s3 += (double)row[2 * C + c];
+      }
+      s1 = wave_sum_d(s1);
+      s2 = wave_sum_d(s2);
+      t1 += s1;
+      t2 += s2;
+      if (lane == 0) {
+        c1[n * C + c] = (float)(s1 / (double)P);
+        c2[n * C + c] = (float)(s2 / (double)P);
+      }
+    }
+  }
+  s3 = wave_sum_d(s3);
+  if (lane == 0) {
     if (dgamma) dgamma[c] += (float)t2;
     if (dbeta) dbeta[c] += (float)t1;
-    slope_acc += t3;
+    if (slope_tmp) slope_tmp[c] = (float)s3;
   }
-  sred[threadIdx.x] = slope_acc;
-  __syncthreads();
-  if (threadIdx.x == 0 && dslope) {
-    double s = 0.0;
-    for (int i = 0; i < (int)blockDim.x; ++i) s += sred[i];
-    *dslope += (float)s;
-  }
+}
+
+// *out += sum(v[0..n)) : one wave, fixed order
+__global__ __launch_bounds__(64) void accum_sum_kernel(const float* __restrict__ v, int n, float* out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += (double)v[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) *out += (float)s;
 }
 
 // ---------------------------------------------------------------------------
@@ -279,11 +310,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* gr, in
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int rows,
                                                               int row_stride, int C, float* __restrict__ out,
                                                               float beta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gt >> 6, lane = threadIdx.x & 63;
   if (c >= C) return;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)partials[(long)r * row_stride + c];
-  out[c] = beta != 0.f ? beta * out[c] + (float)s : (float)s;
+  for (int r = lane; r < rows; r += 64) s += (double)partials[(long)r * row_stride + c];
+  s = wave_sum_d(s);
+  if (lane == 0) out[c] = beta != 0.f ? beta * out[c] + (float)s : (float)s;
 }
 
 template <int V>
@@ -355,7 +388,7 @@ extern "C" int mpgan_norm_finalize(const float* partials, int32_t n, int32_t chu
   MPGAN_CHECK_ARG(partials && scale && shift && mean && invstd && n > 0 && c > 0 && chunks > 0,
                   "norm_finalize: bad argument");
   const int total = instance ? n * c : c;
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, n,
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, n,
                      chunks, c, (long)P, instance, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale,
                      shift, mean, invstd);
   return check_launch("norm_finalize");
@@ -405,8 +438,11 @@ extern "C" int mpgan_norm_bwd_finalize(const float* partials, int32_t n, int32_t
                                        int32_t instance, float* dgamma, float* dbeta, float* dslope, float* c1,
                                        float* c2, void* stream) {
   MPGAN_CHECK_ARG(partials && c1 && c2 && n > 0 && c > 0 && chunks > 0, "norm_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n, chunks, c,
-                     (long)P, instance, dgamma, dbeta, dslope, c1, c2);
+  // per-channel slope terms go to the tail of the partials buffer (>= c floats past the partial rows)
+  float* slope_tmp = dslope ? const_cast<float*>(partials) + (long)n * chunks * 3 * c : nullptr;
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, n,
+                     chunks, c, (long)P, instance, dgamma, dbeta, slope_tmp, c1, c2);
+  if (dslope) hipLaunchKernelGGL(accum_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slope_tmp, c, dslope);
   return check_launch("norm_bwd_finalize");
 }
 
@@ -432,7 +468,7 @@ extern "C" int mpgan_norm_bwd_apply(const float* g, int32_t ldg, const float* z,
 extern "C" int mpgan_reduce_partials(const float* partials, int32_t rows, int32_t row_stride, int32_t c, float* out,
                                      float beta, void* stream) {
   MPGAN_CHECK_ARG(partials && out && rows > 0 && c > 0 && row_stride >= c, "reduce_partials: bad argument");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, rows,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, rows,
                      row_stride, c, out, beta);
   return check_launch("reduce_partials");
 }

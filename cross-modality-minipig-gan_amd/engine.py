@@ -30,29 +30,97 @@ from .ops import ACT_LEAKY, ACT_NONE, ConvGeom, Prologue
 # --------------------------------------------------------------------------
 # programs
 # --------------------------------------------------------------------------
+class KernelProbe:
+    """HIP-event timing of tagged launches (bench.py's live roofline figure):
+    events are recorded on the stream the kernels are launched on."""
+
+    def __init__(self, want=None):
+        self.want = want            # None = every tagged call, else a set of kernel names
+        self.samples = []           # (kernel, flops, ev0, ev1)
+
+    def summary(self):
+        """kernel -> dict(calls, ms, flops): durations read after a synchronize."""
+        out = {}
+        for k, fl, e0, e1 in self.samples:
+            d = out.setdefault(k, dict(calls=0, ms=0.0, flops=0.0))
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+        return out
+
+
+_PROBE: Optional[KernelProbe] = None
+
+
+def set_probe(p: Optional[KernelProbe]):
+    global _PROBE
+    _PROBE = p
+
+
 class Program:
     """A frozen list of C calls; `run` appends the stream and checks status."""
-    __slots__ = ("calls", "keep", "names")
+    __slots__ = ("calls", "keep", "names", "tags")
 
     def __init__(self):
         self.calls = []
         self.keep = []
         self.names = []
+        self.tags = []
 
-    def add(self, name, fn, *args, keep=()):
+    def add(self, name, fn, *args, keep=(), tag=None):
         self.calls.append((fn, args))
         self.names.append(name)
         self.keep.append(keep)
+        self.tags.append(tag)
+
+    def extend(self, other: "Program"):
+        self.calls += other.calls
+        self.names += other.names
+        self.keep += other.keep
+        self.tags += other.tags
 
     def run(self, stream=None):
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        probe = _PROBE
+        if probe is None:
+            for i, (fn, args) in enumerate(self.calls):
+                rc = fn(*args, s)
+                if rc:
+                    raise RuntimeError(f"{self.names[i]} failed (status {rc}): {lib().mpgan_last_error().decode()}")
+            return
         for i, (fn, args) in enumerate(self.calls):
+            tag = self.tags[i]
+            timed = tag is not None and (probe.want is None or tag[0] in probe.want)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             rc = fn(*args, s)
             if rc:
                 raise RuntimeError(f"{self.names[i]} failed (status {rc}): {lib().mpgan_last_error().decode()}")
+            if timed:
+                e1.record()
+                probe.samples.append((tag[0], tag[1], e0, e1))
 
     def __len__(self):
         return len(self.calls)
+
+
+def conv_macs(g: ConvGeom) -> int:
+    """Algorithmic multiply-accumulates of one conv (transposed conv counted input-side)."""
+    grid = g.in_dhw if g.transposed else g.out_dhw
+    return g.n * grid[0] * grid[1] * grid[2] * g.cin * g.cout * g.taps
+
+
+def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool) -> str:
+    """Label of the kernel the C dispatcher picks for this conv (mpgan_conv_variant)."""
+    gc = g.c()
+    v = int(lib().mpgan_conv_variant(C.byref(gc), int(backward_data), int(has_pro)))
+    if v == 1:
+        return "thin_cin1_kernel"
+    if v == 2:
+        return "thin_cout1_kernel"
+    cin_eff = g.cout if backward_data else g.cin
+    return f"gather_conv_kernel<BN={v},{'vec4' if cin_eff % 4 == 0 else 'scalar'}>"
 
 
 def _ld(t):
@@ -198,31 +266,34 @@ class NormBuf:
         return Prologue(self.scale, self.shift, self.c if self.instance else 0, act, slope, slope_t)
 
 
-def emit_conv_fwd(prog, g: ConvGeom, x, wp, bias, y, pro=None, resid=None, tanh=False):
+def emit_conv_fwd(prog, g: ConvGeom, x, wp, bias, y, pro=None, resid=None, tanh=False, stats=None):
     ops._check_in_out(g, x, y, "plan conv_forward")
     gc = g.c()
     pc = pro.c() if pro is not None else None
     prog.add("conv_forward", lib().mpgan_conv_forward, C.byref(gc), x.data_ptr(), _ld(x), wp.data_ptr(), _p(bias),
-             C.byref(pc) if pc is not None else None, _p(resid), _ld(resid), int(tanh), y.data_ptr(), _ld(y),
-             keep=(gc, pc, x, wp, bias, y, resid, pro))
+             C.byref(pc) if pc is not None else None, _p(resid), _ld(resid), int(tanh), _p(stats), y.data_ptr(), _ld(y),
+             keep=(gc, pc, x, wp, bias, y, resid, pro), tag=(gather_kernel_name(g, False, pro is not None), 2.0 * conv_macs(g)))
 
 
 def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):
     ops._check_in_out(g, dx, dy, "plan conv_backward_data")
     gc = g.c()
     prog.add("conv_backward_data", lib().mpgan_conv_backward_data, C.byref(gc), dy.data_ptr(), _ld(dy),
-             wp_bwd.data_ptr(), _p(resid), _ld(resid), dx.data_ptr(), _ld(dx), keep=(gc, dy, wp_bwd, dx, resid))
+             wp_bwd.data_ptr(), _p(resid), _ld(resid), dx.data_ptr(), _ld(dx), keep=(gc, dy, wp_bwd, dx, resid),
+             tag=(gather_kernel_name(g, True, False), 2.0 * conv_macs(g)))
 
 
-def emit_conv_wgrad(prog, g: ConvGeom, x, dy, dw, ws, pro=None):
+def emit_conv_wgrad(prog, g: ConvGeom, x, dy, dw, ws, pro=None, dbias=None):
+    """dW += wgrad; for a ConvNd, dbias += colsum(dy) rides along in the same kernel."""
     ops._check_in_out(g, x, dy, "plan conv_backward_weight")
     gc = g.c()
     pc = pro.c() if pro is not None else None
     need = ops.conv_wgrad_workspace(g)
     assert ws.numel() * 4 >= need, "wgrad workspace too small"
     prog.add("conv_backward_weight", lib().mpgan_conv_backward_weight, C.byref(gc), x.data_ptr(), _ld(x),
-             C.byref(pc) if pc is not None else None, dy.data_ptr(), _ld(dy), dw.data_ptr(), 1.0, ws.data_ptr(),
-             ws.numel() * 4, keep=(gc, pc, x, dy, dw, ws, pro))
+             C.byref(pc) if pc is not None else None, dy.data_ptr(), _ld(dy), dw.data_ptr(), _p(dbias), 1.0,
+             ws.data_ptr(), ws.numel() * 4, keep=(gc, pc, x, dy, dw, dbias, ws, pro),
+             tag=("wgrad_kernel", 2.0 * conv_macs(g)))
 
 
 def emit_bias_grad(prog, dy, db, partials):
@@ -261,6 +332,28 @@ def emit_norm_stats(prog, z, nb: NormBuf, norm_mod, partials, eps=1e-5, momentum
              keep=(norm_mod.weight, norm_mod.bias, rm, rv, nbt, nb))
 
 
+def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod, partials, pro=None):
+    """Conv whose raw output feeds a norm layer: BatchNorm statistics come out of the
+    conv's own epilogue when the MFMA kernel serves it (one finalize launch follows);
+    InstanceNorm and the thin VALU kernels take the separate statistics pass."""
+    rows = 0 if nb.instance else ops.conv_stats_rows(g, pro is not None)
+    if rows == 0:
+        emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro)
+        emit_norm_stats(prog, y, nb, norm_mod, partials)
+        return
+    c = g.cout
+    assert partials.numel() >= rows * 2 * c
+    emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro, stats=partials)
+    n, P, _ = ops._cl(y, "conv+norm")
+    rm = getattr(norm_mod, "running_mean", None)
+    rv = getattr(norm_mod, "running_var", None)
+    nbt = getattr(norm_mod, "num_batches_tracked", None)
+    prog.add("norm_finalize", lib().mpgan_norm_finalize, partials.data_ptr(), 1, rows, c, n * P, 0,
+             _p(norm_mod.weight), _p(norm_mod.bias), float(norm_mod.eps), float(norm_mod.momentum), _p(rm), _p(rv),
+             _p(nbt), nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
+             keep=(norm_mod.weight, norm_mod.bias, rm, rv, nbt, nb, partials))
+
+
 def emit_norm_act_add(prog, z, pz, r, pr, out, tanh=False):
     n, P, ldz = ops._cl(z, "norm_act_add z")
     assert out.shape == z.shape and (r is None or r.shape == z.shape)
@@ -278,7 +371,7 @@ def emit_norm_bwd(prog, g, z, nb: NormBuf, pro: Prologue, dz, partials, dgamma, 
     assert g.shape == z.shape and dz.shape == z.shape
     c = z.shape[-1]
     chunks = ops.stats_chunks(P, c)
-    assert partials.numel() >= n * chunks * 3 * c
+    assert partials.numel() >= n * chunks * 3 * c + c
     L = lib()
     pc = pro.c()
     prog.add("norm_bwd_reduce", L.mpgan_norm_bwd_reduce, g.data_ptr(), _ld(g), z.data_ptr(), ldz, C.byref(pc),
@@ -314,10 +407,13 @@ class Scratch:
         self.ws = None
 
     def want_partials(self, n, P, c):
-        self.partials_need = max(self.partials_need, n * ops.stats_chunks(P, c) * 3 * c)
+        self.partials_need = max(self.partials_need, n * ops.stats_chunks(P, c) * 3 * c + c)
 
     def want_ws(self, g: ConvGeom):
         self.ws_need = max(self.ws_need, ops.conv_wgrad_workspace(g) // 4)
+        # fused-statistics partial rows of the forward conv (with or without prologue: same count)
+        self.partials_need = max(self.partials_need, ops.conv_stats_rows(g, True) * 2 * g.cout,
+                                 ops.conv_stats_rows(g, False) * 2 * g.cout)
 
     def alloc(self):
         self.partials = torch.empty(max(self.partials_need, 4), device=self.dev)
@@ -479,29 +575,26 @@ class UNetPlan:
         for l in range(L - 1):
             s = down_state[l]
             (cv0, N0, A0), (cv1, N1, A1) = s["ru"].units
-            emit_conv_fwd(f, s["g0"], s["xin"], wp(R(cv0)), cv0.bias, s["z0"])
+            emit_conv_fwd_norm(f, s["g0"], s["xin"], wp(R(cv0)), cv0.bias, s["z0"], s["nb0"], N0, part)
             emit_conv_fwd(f, s["gr"], s["xin"], wp(R(s["ru"].res)), s["ru"].res.bias, s["r"])
-            emit_norm_stats(f, s["z0"], s["nb0"], N0, part)
-            emit_conv_fwd(f, s["g1"], s["z0"], wp(R(cv1)), cv1.bias, s["z1"], pro=prelu_pro(s["nb0"], A0))
-            emit_norm_stats(f, s["z1"], s["nb1"], N1, part)
+            emit_conv_fwd_norm(f, s["g1"], s["z0"], wp(R(cv1)), cv1.bias, s["z1"], s["nb1"], N1, part,
+                               pro=prelu_pro(s["nb0"], A0))
             emit_norm_act_add(f, s["z1"], prelu_pro(s["nb1"], A1), s["r"], None, cats[l][..., :s["c"]])
         d_last = cats[L - 2][..., :bt["cb_in"]]
-        emit_conv_fwd(f, bt["gb0"], d_last, wp(R(bt["bc0"])), bt["bc0"].bias, bt["zb0"])
+        emit_conv_fwd_norm(f, bt["gb0"], d_last, wp(R(bt["bc0"])), bt["bc0"].bias, bt["zb0"], bt["nbb0"], bt["BN0"],
+                           part)
         emit_conv_fwd(f, bt["gbr"], d_last, wp(R(bt["res"])), bt["res"].bias, bt["rb"])
-        emit_norm_stats(f, bt["zb0"], bt["nbb0"], bt["BN0"], part)
-        emit_conv_fwd(f, bt["gb1"], bt["zb0"], wp(R(bt["bc1"])), bt["bc1"].bias, bt["zb1"],
-                      pro=prelu_pro(bt["nbb0"], bt["BA0"]))
-        emit_norm_stats(f, bt["zb1"], bt["nbb1"], bt["BN1"], part)
+        emit_conv_fwd_norm(f, bt["gb1"], bt["zb0"], wp(R(bt["bc1"])), bt["bc1"].bias, bt["zb1"], bt["nbb1"],
+                           bt["BN1"], part, pro=prelu_pro(bt["nbb0"], bt["BA0"]))
         emit_norm_act_add(f, bt["zb1"], prelu_pro(bt["nbb1"], bt["BA1"]), bt["rb"], None,
                           cats[L - 2][..., bt["cb_in"]:])
         for l in range(L - 2, -1, -1):
             u = up_state[l]
-            emit_conv_fwd(f, u["gt"], cats[l], wp(R(u["ct"])), u["ct"].bias, u["zt"])
-            emit_norm_stats(f, u["zt"], u["nbt"], u["NT"], part)
+            emit_conv_fwd_norm(f, u["gt"], cats[l], wp(R(u["ct"])), u["ct"].bias, u["zt"], u["nbt"], u["NT"], part)
             pt = prelu_pro(u["nbt"], u["AT"])
             if "zu" in u:
-                emit_conv_fwd(f, u["gu"], u["zt"], wp(R(u["cu"])), u["cu"].bias, u["zu"], pro=pt)
-                emit_norm_stats(f, u["zu"], u["nbu"], u["NU"], part)
+                emit_conv_fwd_norm(f, u["gu"], u["zt"], wp(R(u["cu"])), u["cu"].bias, u["zu"], u["nbu"], u["NU"], part,
+                                   pro=pt)
                 dst = cats[l - 1][..., chans[l - 1]:] if l > 0 else y_out
                 emit_norm_act_add(f, u["zu"], prelu_pro(u["nbu"], u["AU"]), u["zt"], pt, dst,
                                   tanh=(a["tanh_out"] and l == 0))
@@ -526,13 +619,11 @@ class UNetPlan:
                 dzu, gta = G["dzu"][l], G["gta"][l]
                 emit_norm_bwd(b, g_u, u["zu"], u["nbu"], prelu_pro(u["nbu"], u["AU"]), dzu, part,
                               gv(u["NU"].weight), gv(u["NU"].bias), gv(u["AU"].weight))
-                emit_bias_grad(b, dzu, gv(u["cu"].bias), part)
-                emit_conv_wgrad(b, u["gu"], u["zt"], dzu, gv(u["cu"].weight), ws, pro=pt)
+                emit_conv_wgrad(b, u["gu"], u["zt"], dzu, gv(u["cu"].weight), ws, pro=pt, dbias=gv(u["cu"].bias))
                 emit_conv_dgrad(b, u["gu"], dzu, wpb(R(u["cu"])), gta, resid=g_u)
             else:
                 gta = G["gta"][l]
-                emit_bias_grad(b, g_u, gv(u["cu"].bias), part)
-                emit_conv_wgrad(b, u["gu"], u["ua"], g_u, gv(u["cu"].weight), ws)
+                emit_conv_wgrad(b, u["gu"], u["ua"], g_u, gv(u["cu"].weight), ws, dbias=gv(u["cu"].bias))
                 emit_conv_dgrad(b, u["gu"], g_u, wpb(R(u["cu"])), gta, resid=g_u)
             emit_norm_bwd(b, gta, u["zt"], u["nbt"], pt, gta, part, gv(u["NT"].weight), gv(u["NT"].bias),
                           gv(u["AT"].weight))
@@ -547,15 +638,13 @@ class UNetPlan:
         dzb1, gab0 = G["dzb1"], G["gab0"]
         emit_norm_bwd(b, g_b, bt["zb1"], bt["nbb1"], prelu_pro(bt["nbb1"], bt["BA1"]), dzb1, part,
                       gv(bt["BN1"].weight), gv(bt["BN1"].bias), gv(bt["BA1"].weight))
-        emit_bias_grad(b, dzb1, gv(bt["bc1"].bias), part)
-        emit_conv_wgrad(b, bt["gb1"], bt["zb0"], dzb1, gv(bt["bc1"].weight), ws, pro=prelu_pro(bt["nbb0"], bt["BA0"]))
+        emit_conv_wgrad(b, bt["gb1"], bt["zb0"], dzb1, gv(bt["bc1"].weight), ws, pro=prelu_pro(bt["nbb0"], bt["BA0"]),
+                        dbias=gv(bt["bc1"].bias))
         emit_conv_dgrad(b, bt["gb1"], dzb1, wpb(R(bt["bc1"])), gab0)
         emit_norm_bwd(b, gab0, bt["zb0"], bt["nbb0"], prelu_pro(bt["nbb0"], bt["BA0"]), gab0, part,
                       gv(bt["BN0"].weight), gv(bt["BN0"].bias), gv(bt["BA0"].weight))
-        emit_bias_grad(b, gab0, gv(bt["bc0"].bias), part)
-        emit_conv_wgrad(b, bt["gb0"], d_last, gab0, gv(bt["bc0"].weight), ws)
-        emit_bias_grad(b, g_b, gv(bt["res"].bias), part)
-        emit_conv_wgrad(b, bt["gbr"], d_last, g_b, gv(bt["res"].weight), ws)
+        emit_conv_wgrad(b, bt["gb0"], d_last, gab0, gv(bt["bc0"].weight), ws, dbias=gv(bt["bc0"].bias))
+        emit_conv_wgrad(b, bt["gbr"], d_last, g_b, gv(bt["res"].weight), ws, dbias=gv(bt["res"].bias))
         emit_conv_dgrad(b, bt["gb0"], gab0, wpb(R(bt["bc0"])), gd_last, resid=gd_last)
         emit_conv_dgrad(b, bt["gbr"], g_b, wpb(R(bt["res"])), gd_last, resid=gd_last)
         # ---- down path, bottom to top ----
@@ -566,15 +655,13 @@ class UNetPlan:
             dz1, ga0 = G["dz1"][l], G["ga0"][l]
             emit_norm_bwd(b, g_d, s["z1"], s["nb1"], prelu_pro(s["nb1"], A1), dz1, part, gv(N1.weight), gv(N1.bias),
                           gv(A1.weight))
-            emit_bias_grad(b, dz1, gv(cv1.bias), part)
-            emit_conv_wgrad(b, s["g1"], s["z0"], dz1, gv(cv1.weight), ws, pro=prelu_pro(s["nb0"], A0))
+            emit_conv_wgrad(b, s["g1"], s["z0"], dz1, gv(cv1.weight), ws, pro=prelu_pro(s["nb0"], A0),
+                            dbias=gv(cv1.bias))
             emit_conv_dgrad(b, s["g1"], dz1, wpb(R(cv1)), ga0)
             emit_norm_bwd(b, ga0, s["z0"], s["nb0"], prelu_pro(s["nb0"], A0), ga0, part, gv(N0.weight), gv(N0.bias),
                           gv(A0.weight))
-            emit_bias_grad(b, ga0, gv(cv0.bias), part)
-            emit_conv_wgrad(b, s["g0"], s["xin"], ga0, gv(cv0.weight), ws)
-            emit_bias_grad(b, g_d, gv(s["ru"].res.bias), part)
-            emit_conv_wgrad(b, s["gr"], s["xin"], g_d, gv(s["ru"].res.weight), ws)
+            emit_conv_wgrad(b, s["g0"], s["xin"], ga0, gv(cv0.weight), ws, dbias=gv(cv0.bias))
+            emit_conv_wgrad(b, s["gr"], s["xin"], g_d, gv(s["ru"].res.weight), ws, dbias=gv(s["ru"].res.bias))
             if l > 0:
                 tgt = G["gcat"][l - 1][..., :chans[l - 1]]
                 emit_conv_dgrad(b, s["g0"], ga0, wpb(R(cv0)), tgt, resid=tgt)
@@ -637,9 +724,7 @@ class GeneratorPlan:
         self.fwd = Program()
         store.emit_pack(self.fwd)
         for p in self.unet_plans:
-            self.fwd.calls += p.fwd.calls
-            self.fwd.names += p.fwd.names
-            self.fwd.keep += p.fwd.keep
+            self.fwd.extend(p.fwd)
         self.bwd = Program()
         if want_backward:
             L_ = lib()
@@ -647,9 +732,7 @@ class GeneratorPlan:
             self.bwd.add("tanh_backward", L_.mpgan_tanh_backward, self.g_y.data_ptr(), self.y.data_ptr(),
                          self.y.numel(), last.data_ptr(), keep=(self.g_y, self.y, last))
             for p in reversed(self.unet_plans):
-                self.bwd.calls += p.bwd.calls
-                self.bwd.names += p.bwd.names
-                self.bwd.keep += p.bwd.keep
+                self.bwd.extend(p.bwd)
             self.g_x = self.g_acts[0] if want_input_grad else None
         self.busy = False
 
@@ -704,8 +787,7 @@ class DiscPlan:
         lrelu = lambda nb: nb.prologue(ACT_LEAKY, 0.2, None)
         src, pro = self.x_in, None
         for i, cv in enumerate(convs):
-            emit_conv_fwd(f, geoms[i], src, store.wp(recs[i]), cv.bias, zs[i], pro=pro)
-            emit_norm_stats(f, zs[i], nbs[i], bns[i], part)
+            emit_conv_fwd_norm(f, geoms[i], src, store.wp(recs[i]), cv.bias, zs[i], nbs[i], bns[i], part, pro=pro)
             src, pro = zs[i], lrelu(nbs[i])
         pc = pro.c()
         f.add("linear1_forward", L.mpgan_linear1_forward, zs[-1].data_ptr(), C.byref(pc), n, P_last, c_last,
@@ -732,8 +814,8 @@ class DiscPlan:
             src = zs[i - 1] if i > 0 else self.x_in
             pro_in = lrelu(nbs[i - 1]) if i > 0 else None
             if want_param_grads:
-                emit_bias_grad(b, gas[i], gv(convs[i].bias), part)
-                emit_conv_wgrad(b, geoms[i], src, gas[i], gv(convs[i].weight), ws, pro=pro_in)
+                emit_conv_wgrad(b, geoms[i], src, gas[i], gv(convs[i].weight), ws, pro=pro_in,
+                                dbias=gv(convs[i].bias))
             if i > 0:
                 emit_conv_dgrad(b, geoms[i], gas[i], store.wp_bwd(recs[i]), gas[i - 1])
             elif want_input_grad:

@@ -124,8 +124,13 @@ def _check_in_out(g: ConvGeom, x: torch.Tensor, y: torch.Tensor, what: str):
         raise ValueError(f"{what}: output shape {tuple(y.shape)} != {(g.n, *g.out_dhw, g.cout)}")
 
 
+def conv_stats_rows(g: ConvGeom, has_prologue: bool) -> int:
+    gc = g.c()
+    return int(lib().mpgan_conv_stats_rows(C.byref(gc), int(has_prologue)))
+
+
 def conv_forward(g: ConvGeom, x, w_packed, bias, y, *, pro: Optional[Prologue] = None, resid=None,
-                 tanh_out: bool = False):
+                 tanh_out: bool = False, stats_partials=None):
     _check_in_out(g, x, y, "conv_forward")
     _, _, ldx = _cl(x, "conv_forward x")
     _, _, ldy = _cl(y, "conv_forward y")
@@ -137,8 +142,11 @@ def conv_forward(g: ConvGeom, x, w_packed, bias, y, *, pro: Optional[Prologue] =
     if w_packed.numel() < g.cout * g.cin * g.taps:
         raise ValueError("conv_forward: packed weight too small")
     gc = g.c()
+    if stats_partials is not None and stats_partials.numel() < conv_stats_rows(g, pro is not None) * 2 * g.cout:
+        raise ValueError("conv_forward: stats_partials too small")
     check(lib().mpgan_conv_forward(C.byref(gc), x.data_ptr(), ldx, w_packed.data_ptr(), _ptr(bias), _pro(pro),
-                                   _ptr(resid), ldr, int(tanh_out), y.data_ptr(), ldy, _stream()), "conv_forward")
+                                   _ptr(resid), ldr, int(tanh_out), _ptr(stats_partials), y.data_ptr(), ldy,
+                                   _stream()), "conv_forward")
     return y
 
 
@@ -162,7 +170,8 @@ def conv_wgrad_workspace(g: ConvGeom) -> int:
     return int(lib().mpgan_conv_wgrad_workspace(C.byref(gc)))
 
 
-def conv_backward_weight(g: ConvGeom, x, dy, dw, workspace, *, pro: Optional[Prologue] = None, beta: float = 0.0):
+def conv_backward_weight(g: ConvGeom, x, dy, dw, workspace, *, pro: Optional[Prologue] = None, beta: float = 0.0,
+                         dbias=None):
     _check_in_out(g, x, dy, "conv_backward_weight")
     _, _, ldx = _cl(x, "conv_backward_weight x")
     _, _, lddy = _cl(dy, "conv_backward_weight dy")
@@ -170,7 +179,7 @@ def conv_backward_weight(g: ConvGeom, x, dy, dw, workspace, *, pro: Optional[Pro
         raise ValueError("conv_backward_weight: dw must be the contiguous torch-layout weight gradient")
     gc = g.c()
     check(lib().mpgan_conv_backward_weight(C.byref(gc), x.data_ptr(), ldx, _pro(pro), dy.data_ptr(), lddy,
-                                           dw.data_ptr(), float(beta), workspace.data_ptr(),
+                                           dw.data_ptr(), _ptr(dbias), float(beta), workspace.data_ptr(),
                                            workspace.numel() * workspace.element_size(), _stream()),
           "conv_backward_weight")
     return dw
@@ -222,8 +231,8 @@ def norm_bwd_reduce(g, z, p: Prologue, mean, invstd, partials):
     if g.shape != z.shape:
         raise ValueError("norm_bwd_reduce: shape mismatch")
     c = z.shape[-1]
-    if partials.numel() < n * stats_chunks(P, c) * 3 * c:
-        raise ValueError("norm_bwd_reduce: partials too small")
+    if partials.numel() < n * stats_chunks(P, c) * 3 * c + c:
+        raise ValueError("norm_bwd_reduce: partials too small (need n*chunks*3*c + c floats)")
     check(lib().mpgan_norm_bwd_reduce(g.data_ptr(), ldg, z.data_ptr(), ldz, _pro(p), mean.data_ptr(),
                                       invstd.data_ptr(), n, P, c, partials.data_ptr(), _stream()), "norm_bwd_reduce")
 

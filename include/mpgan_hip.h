@@ -76,11 +76,17 @@ typedef struct {
  * ConvTransposeNd when g->transposed).
  * Replaces: conv3d/conv_transpose3d dispatched by MONAI Convolution /
  * ResidualUnit (GAN_final.py:106-114) and by Discriminator.model_conv
- * (GAN_final.py:167-189, test_runs/GAN.py:142-173). */
+ * (GAN_final.py:167-189, test_runs/GAN.py:142-173).
+ * stats_partials (nullable): fused BatchNorm statistics -- the kernel also leaves
+ * per-tile partial sums [rows][2][Cout] of (y, y^2), rows = mpgan_conv_stats_rows(),
+ * which mpgan_norm_finalize(n=1, chunks=rows, pixels=N*D*H*W, instance=0) consumes;
+ * rows == 0 means this geometry has no fused statistics (use mpgan_channel_stats). */
+int32_t mpgan_conv_stats_rows(const mpgan_conv_geom* g, int32_t has_prologue);
 int mpgan_conv_forward(const mpgan_conv_geom* g, const float* x, int32_t ldx,
                        const float* w_packed, const float* bias,
                        const mpgan_prologue* pro,
                        const float* resid, int32_t ldr, int32_t tanh_out,
+                       float* stats_partials,
                        float* y, int32_t ldy, void* stream);
 
 /* dx = conv_backward_data(dy) [+ resid]: gradient w.r.t. the conv input
@@ -94,6 +100,11 @@ int mpgan_conv_backward_data(const mpgan_conv_geom* g, const float* dy, int32_t 
                              const float* resid, int32_t ldr,
                              float* dx, int32_t lddx, void* stream);
 
+/* Which kernel serves this geometry (for profiling labels): 1 = thin Cin==1 VALU
+ * stencil, 2 = thin Cout==1 VALU stencil, 32/64/128 = fp32-MFMA implicit GEMM with
+ * that output-channel tile. */
+int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward_data, int32_t has_prologue);
+
 /* Weight gradient: dW (torch layout, (Cout,Cin,k..) or (Cin,Cout,k..) for a
  * transposed conv) = beta*dW + sum over pixels.  x is the conv's input (with
  * optional prologue), dy the gradient of its raw output.  `workspace` holds
@@ -102,7 +113,8 @@ int64_t mpgan_conv_wgrad_workspace(const mpgan_conv_geom* g);
 int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float* x, int32_t ldx,
                                const mpgan_prologue* pro,
                                const float* dy, int32_t lddy,
-                               float* dw, float beta,
+                               float* dw, float* dbias /* nullable; ConvNd only: dbias = beta*dbias + colsum(dy), fused */,
+                               float beta,
                                void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Repack every conv / linear weight of a network in ONE launch.
@@ -141,7 +153,8 @@ int mpgan_norm_act_add(const float* z, int32_t ldz, const mpgan_prologue* pz,
                        float* out, int32_t ldo, void* stream);
 
 /* Backward of a = act(z*scale+shift), given g = dL/da:
- *   reduce  : partials [n][chunks][3][C] of (sum gy, sum gy*zhat, sum g*min(y,0))
+ *   reduce  : partials [n][chunks][3][C] of (sum gy, sum gy*zhat, sum g*min(y,0));
+ *             the buffer must hold C more floats after those rows (finalize scratch)
  *   finalize: dgamma += , dbeta += , dslope += ; coef c1 = sum gy / M, c2 = sum gy*zhat / M
  *   apply   : dz = scale*(gy - c1 - zhat*c2)
  * g may carry a fused pointwise factor: g_eff = g * (1 - t^2) (tanh backward)

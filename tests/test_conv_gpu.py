@@ -80,11 +80,14 @@ def test_conv_forward_dgrad_wgrad(case):
 
     ws = torch.empty(ops.conv_wgrad_workspace(g) // 4, device="cuda")
     dw = torch.full_like(wc, float("nan"))
-    ops.conv_backward_weight(g, xc, to_cl(gy), dw, ws)
+    db = torch.full((cout,), float("nan"), device="cuda")
+    ops.conv_backward_weight(g, xc, to_cl(gy), dw, ws, dbias=db)
     assert_close(dw.cpu(), w.grad, what="wgrad")
+    assert_close(db.cpu(), b.grad, what="fused bias grad")
     # accumulate (beta = 1) doubles it
-    ops.conv_backward_weight(g, xc, to_cl(gy), dw, ws, beta=1.0)
+    ops.conv_backward_weight(g, xc, to_cl(gy), dw, ws, beta=1.0, dbias=db)
     assert_close(dw.cpu(), 2 * w.grad, what="wgrad beta=1")
+    assert_close(db.cpu(), 2 * b.grad, what="fused bias grad beta=1")
 
 
 @pytest.mark.parametrize("case", CONVT_CASES, ids=lambda c: "d{}_{}to{}".format(*c[:3]))
@@ -194,3 +197,45 @@ def test_unsupported_and_invalid_arguments_raise():
     g2 = ops.ConvGeom(1, (1, 8, 8), 4, 4, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     with pytest.raises(ValueError):
         ops.conv_forward(g2, x.cpu(), torch.zeros(144, device="cuda"), None, y)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,spatial,transposed", [
+    (16, 32, 3, 2, 1, (20, 24), False), (64, 128, 3, 1, 0, (20, 18), False), (256, 256, 4, 2, 0, (15, 13), False),
+    (192, 32, 3, 2, 1, (7, 5), True)])
+def test_fused_batchnorm_statistics_from_conv_epilogue(cin, cout, k, s, p, spatial, transposed):
+    """The conv's own epilogue leaves per-tile (sum, sum^2) rows; finalize turns them
+    into the same scale/shift/running stats as F.batch_norm on the conv output."""
+    from mpgan_amd import ops
+    n = 3
+    gen = torch.Generator().manual_seed(123 + cout)
+    x = torch.rand(n, cin, *spatial, generator=gen) * 2 - 1
+    if transposed:
+        w = (torch.rand(cin, cout, k, k, generator=gen) - 0.5) / (cin * k * k) ** 0.5
+        b = torch.rand(cout, generator=gen) - 0.5
+        z_ref = F.conv_transpose2d(x, w, b, stride=s, padding=p, output_padding=s - 1)
+    else:
+        w = (torch.rand(cout, cin, k, k, generator=gen) - 0.5) / (cin * k * k) ** 0.5
+        b = torch.rand(cout, generator=gen) - 0.5
+        z_ref = F.conv2d(x, w, b, stride=s, padding=p)
+    gamma, beta = torch.rand(cout, generator=gen) + 0.5, torch.rand(cout, generator=gen) - 0.5
+    rm, rv = torch.zeros(cout), torch.ones(cout)
+    y_ref = F.batch_norm(z_ref, rm, rv, gamma, beta, True, 0.1, 1e-5)
+
+    g = _geom(2, n, cin, cout, k, s, p, spatial, transposed=transposed)
+    rows = ops.conv_stats_rows(g, False)
+    assert rows > 0
+    part = torch.full((rows * 2 * cout,), float("nan"), device="cuda")
+    z = torch.empty(n, *g.out_dhw, cout, device="cuda")
+    ops.conv_forward(g, to_cl(x), ops.pack_weight(w.cuda(), transposed=transposed), b.cuda(), z, stats_partials=part)
+    assert_close(from_cl(z, 2), z_ref, what="conv output")
+    assert torch.isfinite(part).all()
+    scale, shift, mean, invstd = (torch.empty(cout, device="cuda") for _ in range(4))
+    rmd, rvd = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    P = n * g.out_dhw[0] * g.out_dhw[1] * g.out_dhw[2]
+    ops.norm_finalize(part, 1, rows, cout, P, False, gamma.cuda(), beta.cuda(), 1e-5, 0.1, rmd, rvd, nbt, scale, shift,
+                      mean, invstd)
+    y = from_cl(z, 2) * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None]
+    assert_close(y, y_ref, rtol=1e-4, what="normalised output")
+    assert_close(rmd.cpu(), rm, what="running_mean")
+    assert_close(rvd.cpu(), rv, rtol=1e-4, what="running_var")

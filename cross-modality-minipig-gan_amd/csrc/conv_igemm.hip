@@ -18,6 +18,8 @@
 // of its row with one ds_read_b128 (conflict-free at pitch 36), and the two
 // half-waves take different K quads so a quad feeds four MFMAs.
 #include "mpgan_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace mpgan {
 
@@ -50,6 +52,101 @@ struct GatherConv {
 constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int PITCH = BK + 4;
+
+// Shared epilogue: row -> output pixel map through LDS, bias / residual / tanh,
+// optional fused BatchNorm statistics.  Called after the K-loop's final barrier.
+template <int BN, int TM, int TN, int WN>
+__device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& ph, f32x16 (&acc)[TM][TN], float* lds,
+                                              long m0, int n0, long Mtot) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int Cout = p.Cout;
+  // ---- epilogue: row -> output pixel map through LDS, then bias/resid/tanh ----
+  int* rowpix = reinterpret_cast<int*>(lds);
+  if (tid < BM) {
+    const unsigned m = (unsigned)m0 + tid;
+    int pix = -1;
+    if (m < (unsigned)Mtot) {
+      const unsigned uMx = ph.Mx, uMy = ph.My, uMz = ph.Mz;
+      int mx = (int)(m % uMx);
+      unsigned q = m / uMx;
+      int my = (int)(q % uMy);
+      q /= uMy;
+      int mz = (int)(q % uMz);
+      int n = (int)(q / uMz);
+      int oz = mz * p.ostride[0] + ph.oz, oy = my * p.ostride[1] + ph.oy, ox = mx * p.ostride[2] + ph.ox;
+      if (oz < p.Do && oy < p.Ho && ox < p.Wo) pix = ((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+    }
+    rowpix[tid] = pix;
+  }
+  __syncthreads();
+  const float* gres = p.resid;
+  float* gout = p.out;
+  const int ldo = p.ldo, ldr = p.ldr, tanh_out = p.tanh_out;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int co = n0 + (wn * TN + tn) * 32 + li;
+      if (co >= Cout) continue;
+      const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int pix = rowpix[row];
+        if (pix < 0) continue;
+        float v = acc[tm][tn][r] + bv;
+        if (gres) v += gres[(long)pix * ldr + co];
+        if (tanh_out) v = tanhf(v);
+        gout[(long)pix * ldo + co] = v;
+      }
+    }
+  if (p.stats) {
+    // Fused BatchNorm statistics: column sums of z = acc + bias over this tile's valid
+    // rows -- registers, then the two half-waves (shuffle), then the WM waves that share
+    // a column range (LDS, fixed order): deterministic, no atomics.
+    constexpr int WM = 4 / WN;
+    float* st = lds + 1024;                 // [WM][2][BN], clear of rowpix
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = (wn * TN + tn) * 32 + li;
+      const int co = n0 + col;
+      const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (rowpix[row] >= 0) {
+            const float v = acc[tm][tn][r] + bv;
+            sm += v;
+            sq += v * v;
+          }
+        }
+      sm += __shfl_xor(sm, 32, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      if (lh == 0) {
+        st[(wm * 2 + 0) * BN + col] = sm;
+        st[(wm * 2 + 1) * BN + col] = sq;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < Cout) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        sm += st[(w * 2 + 0) * BN + tid];
+        sq += st[(w * 2 + 1) * BN + tid];
+      }
+      float* row = p.stats + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * Cout;
+      row[n0 + tid] = sm;
+      row[Cout + n0 + tid] = sq;
+    }
+  }
+}
 
 // Per-thread cursor over the flattened K = (tap, ci) axis.  It is decoded with
 // integer divisions ONCE; each K-step then advances it by 32 with compares only.
@@ -295,6 +392,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
     };
     read_group(0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);   // the MFMA stream must not lose issue slots to the partner wave's address math
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int sl = g & 1;
@@ -314,15 +412,64 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_s_setprio(0);
     if (kt + 1 < nk) lds_store(cb ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: row -> output pixel map through LDS, then bias/resid/tanh ----
-  int* rowpix = reinterpret_cast<int*>(lds);
-  if (tid < BM) {
-    const unsigned m = (unsigned)m0 + tid;
-    int pix = -1;
+  conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot);
+}
+
+// ---------------------------------------------------------------------------
+// Software-pipelined main kernel (vector path, Cin % 32 == 0 or Cin in {4,8,16}).
+// Same tiles and LDS image as gather_conv_kernel, but the K-step is ONE basic
+// block: cursor advance is branch-free, the next tile's address math + global
+// loads are interleaved with the MFMAs of fragment group 0 and its
+// normalise/mask + LDS stores with the MFMAs of group 3 (sched_group_barrier),
+// so a wave keeps the matrix pipe fed without relying on a partner wave.
+//   WRAPS : taps crossed per K-step (1 for Cin % 32 == 0, 32/Cin below 32)
+//   PRO   : 0 none, 1 per-channel scale/shift (BatchNorm), 2 per-(n,c) (InstanceNorm)
+// ---------------------------------------------------------------------------
+template <int BN, int TM, int TN, int WN, int WRAPS, int PRO>
+__global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int STAGE = (BM + BN) * PITCH;
+  constexpr int BROWS = BN / 32;
+  constexpr int NMF = 4 * TM * TN;          // MFMAs per fragment group
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const Phase ph = p.ph[blockIdx.z];
+  const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  if (m0 >= Mtot) {
+    if (p.stats && tid < BN && n0 + tid < p.Cout) {
+      float* row = p.stats + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * p.Cout;
+      row[n0 + tid] = 0.f;
+      row[p.Cout + n0 + tid] = 0.f;
+    }
+    return;
+  }
+  const int Cin = p.Cin, Cout = p.Cout, Di = p.Di, Hi = p.Hi, Wi = p.Wi, ldi = p.ldi;
+  const int ntaps = ph.nz * ph.ny * ph.nx;
+  const int Kp = ntaps * Cin;
+  const int nk = (Kp + BK - 1) / BK;
+  const long Ktot = (long)p.Kz * p.Ky * p.Kx * Cin;
+  const float* __restrict__ gin = p.in;
+  const float* __restrict__ gw = p.wp;
+  const float* __restrict__ gscale = p.pro.scale;
+  const float* __restrict__ gshift = p.pro.shift;
+  const int nstride = p.pro.n_stride, act = p.pro.act;
+  const float slope = PRO ? pro_slope(p.pro) : 1.f;
+
+  const int cc = tid & 7, r0 = tid >> 3;
+  int rn[4], rz[4], ry[4], rx[4], rbase[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned m = (unsigned)m0 + r0 + 32 * i;
     if (m < (unsigned)Mtot) {
       const unsigned uMx = ph.Mx, uMy = ph.My, uMz = ph.Mz;
       int mx = (int)(m % uMx);
@@ -330,77 +477,224 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
       int my = (int)(q % uMy);
       q /= uMy;
       int mz = (int)(q % uMz);
-      int n = (int)(q / uMz);
-      int oz = mz * p.ostride[0] + ph.oz, oy = my * p.ostride[1] + ph.oy, ox = mx * p.ostride[2] + ph.ox;
-      if (oz < p.Do && oy < p.Ho && ox < p.Wo) pix = ((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+      rn[i] = (int)(q / uMz);
+      rz[i] = mz * p.istride[0];
+      ry[i] = my * p.istride[1];
+      rx[i] = mx * p.istride[2];
+    } else {
+      rn[i] = 0;
+      rz[i] = ry[i] = rx[i] = -(1 << 28);
     }
-    rowpix[tid] = pix;
+    rbase[i] = ((rn[i] * Di + rz[i]) * Hi + ry[i]) * Wi + rx[i];
   }
-  __syncthreads();
-  const float* gres = p.resid;
-  float* gout = p.out;
-  const int ldo = p.ldo, ldr = p.ldr, tanh_out = p.tanh_out;
+  // B rows of this thread: element offsets of (co, k = 0), clamped for co >= Cout
+  int wrow[BROWS];                       // packed weights hold < 2^31 floats (host-checked)
+  unsigned bvalid = 0;
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+  for (int i = 0; i < BROWS; ++i) {
+    const int co = n0 + r0 + 32 * i;
+    const bool ok = co < Cout;
+    wrow[i] = ok ? co * (int)Ktot : 0;
+    bvalid |= (ok ? 1u : 0u) << i;
+  }
+  const int ksz = p.kstep[0], ksy = p.kstep[1], ksx = p.kstep[2];
+  const int dsz = p.dstep[0], dsy = p.dstep[1], dsx = p.dstep[2];
+  const int Ky = p.Ky, Kx = p.Kx;
+
+  // cursor (branch-free advance)
+  int ci, jz, jy, jx, dz, dy, dx, delta, woff;
+  int cvalid;                             // 0/1 -- all predicates below are bitwise so the K-step stays ONE basic block
+  auto place = [&]() {
+    cvalid = jz < ph.nz ? 1 : 0;
+    const int kz = ph.kz0 + ksz * jz, ky = ph.ky0 + ksy * jy, kx = ph.kx0 + ksx * jx;
+    woff = ((kz * Ky + ky) * Kx + kx) * Cin;
+    dz = ph.dz0 + dsz * jz;
+    dy = ph.dy0 + dsy * jy;
+    dx = ph.dx0 + dsx * jx;
+    delta = (dz * Hi + dy) * Wi + dx;
+  };
+  {
+    const int kidx = cc * 4;
+    const int tap = kidx / Cin;
+    ci = kidx - tap * Cin;
+    jx = tap % ph.nx;
+    const int tq = tap / ph.nx;
+    jy = tq % ph.ny;
+    jz = tq / ph.ny;
+    place();
+  }
+  auto advance = [&]() {
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int co = n0 + (wn * TN + tn) * 32 + li;
-      if (co >= Cout) continue;
-      const float bv = p.bias ? p.bias[co] : 0.f;
+    for (int w = 0; w < WRAPS; ++w) {
+      ci += BK / WRAPS;
+      const int wc = ci >= Cin ? 1 : 0;
+      ci -= wc * Cin;
+      jx += wc;
+      const int wx = jx == ph.nx ? 1 : 0;
+      jx -= wx * ph.nx;
+      jy += wx;
+      const int wy = jy == ph.ny ? 1 : 0;
+      jy -= wy * ph.ny;
+      jz += wy;
+    }
+    place();
+  };
+
+  // Two register stages: a tile is loaded during K-step kt (under the MFMAs of group 0),
+  // written to LDS during K-step kt+1 (under group 3) and consumed in K-step kt+2, so a
+  // global load has a whole K-step (~4000 cycles) to land before anything waits on it.
+  struct Stage {
+    float4 ra[4], rb[BROWS], rsc[PRO == 2 ? 4 : 1], rsh[PRO == 2 ? 4 : 1];
+    unsigned amask;
+    int kvalid;
+  };
+  Stage SX, SY;
+
+  auto issue_loads = [&](Stage& S) {
+    float4 (&ra)[4] = S.ra;
+    float4 (&rb)[BROWS] = S.rb;
+    auto& rsc = S.rsc;
+    auto& rsh = S.rsh;
+    unsigned amask = 0;
+    S.kvalid = cvalid;
+    const int cis = cvalid * ci;          // clamp to channel 0 past the last tap (scale/shift/weight reads stay in range)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int pix = rowpix[row];
-        if (pix < 0) continue;
-        float v = acc[tm][tn][r] + bv;
-        if (gres) v += gres[(long)pix * ldr + co];
-        if (tanh_out) v = tanhf(v);
-        gout[(long)pix * ldo + co] = v;
+    for (int i = 0; i < 4; ++i) {
+      const int iz = rz[i] + dz, iy = ry[i] + dy, ix = rx[i] + dx;
+      const int ok = cvalid & ((unsigned)iz < (unsigned)Di ? 1 : 0) & ((unsigned)iy < (unsigned)Hi ? 1 : 0) &
+                     ((unsigned)ix < (unsigned)Wi ? 1 : 0);
+      const int pix = ok * (rbase[i] + delta);
+      const long off = (long)pix * ldi + ok * ci;
+      ra[i] = *reinterpret_cast<const float4*>(gin + off);
+      amask |= (unsigned)ok << i;
+      if constexpr (PRO == 2) {
+        const int si = rn[i] * nstride + cis;
+        rsc[i] = *reinterpret_cast<const float4*>(gscale + si);
+        rsh[i] = *reinterpret_cast<const float4*>(gshift + si);
       }
     }
-  if (p.stats) {
-    // Fused BatchNorm statistics: column sums of z = acc + bias over this tile's valid
-    // rows -- registers, then the two half-waves (shuffle), then the WM waves that share
-    // a column range (LDS, fixed order): deterministic, no atomics.
-    constexpr int WM = 4 / WN;
-    float* st = lds + 1024;                 // [WM][2][BN], clear of rowpix
+    if constexpr (PRO == 1) {
+      rsc[0] = *reinterpret_cast<const float4*>(gscale + cis);
+      rsh[0] = *reinterpret_cast<const float4*>(gshift + cis);
+    }
+    const int wk = cvalid * (woff + ci);
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int col = (wn * TN + tn) * 32 + li;
-      const int co = n0 + col;
-      const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
-      float sm = 0.f, sq = 0.f;
+    for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const float4*>(gw + (cvalid * wrow[i] + wk));
+    S.amask = amask;
+    advance();
+  };
+
+  auto store_tile = [&](int buf, const Stage& S) {
+    const float4 (&ra)[4] = S.ra;
+    const float4 (&rb)[BROWS] = S.rb;
+    const auto& rsc = S.rsc;
+    const auto& rsh = S.rsh;
+    const unsigned amask = S.amask;
+    const int kvalid = S.kvalid;
+    float* As = lds + buf * STAGE;
+    float* Bs = As + BM * PITCH;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = ra[i];
+      if constexpr (PRO != 0) {
+        const float4 sc = rsc[PRO == 2 ? i : 0], sh = rsh[PRO == 2 ? i : 0];
+        v.x = act_apply(v.x * sc.x + sh.x, act, slope);
+        v.y = act_apply(v.y * sc.y + sh.y, act, slope);
+        v.z = act_apply(v.z * sc.z + sh.z, act, slope);
+        v.w = act_apply(v.w * sc.w + sh.w, act, slope);
+      }
+      const bool ok = (amask >> i) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<float4*>(As + (r0 + 32 * i) * PITCH + cc * 4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+      float4 v = rb[i];
+      const bool ok = (kvalid & (int)((bvalid >> i) & 1u)) != 0;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<float4*>(Bs + (r0 + 32 * i) * PITCH + cc * 4) = v;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (nk > 0) {
+    issue_loads(SX);        // tile 0
+    store_tile(0, SX);
+    issue_loads(SX);        // tile 1 stays in flight into the first K-step
+  }
+  __syncthreads();
+
+  // One K-step: MFMAs on LDS buffer cb; under group 0 load tile kt+2 into `Sn`, under
+  // group 3 write tile kt+1 (held by `Sp`) to the other buffer.  Loads past the last tile
+  // hit one clamped address (cvalid = 0) and store zeros nobody reads.
+  auto step = [&](int cb, Stage& Sn, const Stage& Sp) {
+    const float* As = lds + cb * STAGE + (wm * TM * 32 + li) * PITCH + 4 * lh;
+    const float* Bs = lds + cb * STAGE + BM * PITCH + (wn * TN * 32 + li) * PITCH + 4 * lh;
+    float4 a[2][TM], b[2][TN];
+    auto read_group = [&](int g, int slot) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        a[slot][tm] = *reinterpret_cast<const float4*>(As + tm * 32 * PITCH + 8 * g);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        b[slot][tn] = *reinterpret_cast<const float4*>(Bs + tn * 32 * PITCH + 8 * g);
+    };
+    read_group(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int sl = g & 1;
+      if (g < 3) read_group(g + 1, sl ^ 1);
+      if (g == 0) issue_loads(Sn);
+      if (g == 3) store_tile(cb ^ 1, Sp);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (rowpix[row] >= 0) {
-            const float v = acc[tm][tn][r] + bv;
-            sm += v;
-            sq += v * v;
-          }
+        for (int tn = 0; tn < TN; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][tm].x, b[sl][tn].x, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][tm].y, b[sl][tn].y, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][tm].z, b[sl][tn].z, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][tm].w, b[sl][tn].w, acc[tm][tn], 0, 0, 0);
         }
-      sm += __shfl_xor(sm, 32, 64);
-      sq += __shfl_xor(sq, 32, 64);
-      if (lh == 0) {
-        st[(wm * 2 + 0) * BN + col] = sm;
-        st[(wm * 2 + 1) * BN + col] = sq;
-      }
-    }
-    __syncthreads();
-    if (tid < BN && n0 + tid < Cout) {
-      float sm = 0.f, sq = 0.f;
+      // ---- issue order inside this group ----
+      if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);       // next group's fragment reads
+      if (g == 0) {
 #pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        sm += st[(w * 2 + 0) * BN + tid];
-        sq += st[(w * 2 + 1) * BN + tid];
+        for (int i = 0; i < NMF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x006, 13, 0);                    // address math (VALU|SALU)
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // one global load
+        }
+      } else if (g == 3) {
+#pragma unroll
+        for (int i = 0; i < NMF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 11, 0);                    // normalise / mask
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                     // one LDS store
+        }
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
       }
-      float* row = p.stats + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * Cout;
-      row[n0 + tid] = sm;
-      row[Cout + n0 + tid] = sq;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(0, SY, SX);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      step(1, SX, SY);
+      __syncthreads();
     }
   }
+  conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot);
 }
 
 // ---------------------------------------------------------------------------
@@ -574,7 +868,8 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
 template <int BN, int TM, int TN, int WN, bool SCALAR>
 static int launch_variant(const GatherConv& p, long maxM, hipStream_t st) {
   auto kern = gather_conv_kernel<BN, TM, TN, WN, SCALAR>;
-  constexpr int smem = 2 * (BM + BN) * PITCH * (int)sizeof(float);
+  static const int lds_pad = getenv("MPGAN_DBG_LDS_PAD") ? atoi(getenv("MPGAN_DBG_LDS_PAD")) : 0;
+  const int smem = 2 * (BM + BN) * PITCH * (int)sizeof(float) + lds_pad;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -614,12 +909,47 @@ static int select_variant(const GatherConv& p, long maxM, bool thin1, bool thin2
   return bn;
 }
 
+template <int BN, int TM, int TN, int WN, int WRAPS, int PRO>
+static int launch_pipe_variant(const GatherConv& p, long maxM, hipStream_t st) {
+  auto kern = gather_conv_pipe_kernel<BN, TM, TN, WN, WRAPS, PRO>;
+  static const int lds_pad = getenv("MPGAN_DBG_LDS_PAD") ? atoi(getenv("MPGAN_DBG_LDS_PAD")) : 0;
+  const int smem = 2 * (BM + BN) * PITCH * (int)sizeof(float) + lds_pad;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      set_error("gather_conv_pipe: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((maxM + BM - 1) / BM), (unsigned)((p.Cout + BN - 1) / BN), (unsigned)p.nphase);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+  return check_launch("gather_conv_pipe");
+}
+
+template <int WRAPS, int PRO>
+static int launch_pipe_bn(const GatherConv& p, int variant, long maxM, hipStream_t st) {
+  if (variant == 128) return launch_pipe_variant<128, 2, 2, 2, WRAPS, PRO>(p, maxM, st);
+  if (variant == 64) return launch_pipe_variant<64, 1, 2, 1, WRAPS, PRO>(p, maxM, st);
+  return launch_pipe_variant<32, 1, 1, 1, WRAPS, PRO>(p, maxM, st);
+}
+
+template <int WRAPS>
+static int launch_pipe_pro(const GatherConv& p, int variant, long maxM, hipStream_t st) {
+  if (!p.pro.scale) return launch_pipe_bn<WRAPS, 0>(p, variant, maxM, st);
+  if (p.pro.n_stride == 0) return launch_pipe_bn<WRAPS, 1>(p, variant, maxM, st);
+  return launch_pipe_bn<WRAPS, 2>(p, variant, maxM, st);
+}
+
 static int launch_gather(const GatherConv& p, hipStream_t st) {
   const long maxM = max_phase_pixels(p);
   if (maxM == 0) return MPGAN_OK;
   MPGAN_CHECK_ARG((long)p.N * p.Do * p.Ho * p.Wo < (1L << 31) && (long)p.N * p.Di * p.Hi * p.Wi < (1L << 31) &&
                       maxM < (1L << 31) - 256,
                   "gather_conv: more than 2^31 pixels");
+  MPGAN_CHECK_ARG((long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx < (1L << 31), "gather_conv: weight larger than 2^31");
   const int variant = select_variant(p, maxM, thin_cin1_ok(p), thin_cout1_ok(p));
   if (variant <= 2) return launch_thin(p, maxM, st);
   const bool vec = (p.Cin % 4 == 0) && (p.ldi % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0) &&
@@ -627,6 +957,11 @@ static int launch_gather(const GatherConv& p, hipStream_t st) {
                    (!p.pro.scale || (((reinterpret_cast<uintptr_t>(p.pro.scale) |
                                        reinterpret_cast<uintptr_t>(p.pro.shift)) & 15) == 0 &&
                                      p.pro.n_stride % 4 == 0));
+  static const bool no_pipe = getenv("MPGAN_DBG_NO_PIPE") != nullptr;
+  if (vec && !no_pipe) {
+    if (p.Cin % 32 == 0) return launch_pipe_pro<1>(p, variant, maxM, st);
+    if (p.Cin == 16) return launch_pipe_pro<2>(p, variant, maxM, st);
+  }
   if (vec) {
     if (variant == 128) return launch_variant<128, 2, 2, 2, false>(p, maxM, st);
     if (variant == 64) return launch_variant<64, 1, 2, 1, false>(p, maxM, st);

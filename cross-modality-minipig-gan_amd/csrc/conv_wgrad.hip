@@ -14,6 +14,7 @@
 // tile[2s+h][i]: consecutive lanes read consecutive floats -- conflict-free
 // ds_read_b32 with no transposition.
 #include "mpgan_common.h"
+#include <stdlib.h>
 
 namespace mpgan {
 
@@ -269,6 +270,242 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Software-pipelined variant (both operands 16-byte vectorisable, coarse grid
+// at least 32 wide, BatchNorm-or-no prologue): the K-step is one basic block;
+// tile kt+2 is loaded under the MFMAs of group 0, tile kt+1 goes to LDS under
+// group 3 (two register stages), exactly as gather_conv_pipe_kernel does.
+// ---------------------------------------------------------------------------
+template <int BD, int BG, int TM, int TN, int WN, int PRO>
+__global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int STAGE = WBK * (BD + BG);
+  constexpr int DCH = BD / 4, GCH = BG / 4;
+  constexpr int DLOADS = (WBK * DCH) / 256, GLOADS = (WBK * GCH) / 256;
+  constexpr int DROWSTEP = 256 / DCH, GROWSTEP = 256 / GCH;
+  constexpr int NMF = 4 * TM * TN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int T = p.Kz * p.Ky * p.Kx;
+  const int NC = T * p.Cg;
+  const int c0 = blockIdx.x * BG;
+  const int d0 = blockIdx.y * BD;
+  const long M = (long)p.N * p.Mz * p.My * p.Mx;
+  const long mbeg = (long)blockIdx.z * p.chunk;
+  const long mend = mbeg + p.chunk < M ? mbeg + p.chunk : M;
+  const int nk = mbeg < mend ? (int)((mend - mbeg + WBK - 1) / WBK) : 0;
+  const float slope = PRO ? pro_slope(p.pro) : 1.f;
+  const int act = p.pro.act;
+  const float* __restrict__ gd = p.dense;
+  const float* __restrict__ gg = p.gath;
+  const int ldd = p.ldd, ldg = p.ldg, Gz = p.Gz, Gy = p.Gy, Gx = p.Gx, Mx = p.Mx, My = p.My, Mz = p.Mz;
+
+  // gathered operand: this thread's column chunk (tap, channel) is fixed for the block
+  const int gcc = tid % GCH, grow0 = tid / GCH;
+  int gci, gkz, gky, gkx, gok;
+  {
+    const int col = c0 + gcc * 4;
+    gok = col < NC ? 1 : 0;
+    const int t = gok ? col / p.Cg : 0;
+    gci = gok ? col - t * p.Cg : 0;
+    gkx = t % p.Kx;
+    const int q = t / p.Kx;
+    gky = q % p.Ky;
+    gkz = q / p.Ky;
+  }
+  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (PRO == 1) {          // per-channel scale/shift of this thread's channels: loaded once
+    psc = *reinterpret_cast<const float4*>(p.pro.scale + gci);
+    psh = *reinterpret_cast<const float4*>(p.pro.shift + gci);
+  }
+  const int dcc = tid % DCH, drow0 = tid / DCH;
+  const int dcol = d0 + dcc * 4;
+  const int dok = dcol < p.Cd ? 1 : 0;
+
+  int cn[GLOADS], cz[GLOADS], cy[GLOADS], cx[GLOADS];
+#pragma unroll
+  for (int i = 0; i < GLOADS; ++i) {
+    const unsigned um = (unsigned)(mbeg + grow0 + GROWSTEP * i), uMx = Mx, uMy = My, uMz = Mz;
+    cx[i] = (int)(um % uMx);
+    unsigned q = um / uMx;
+    cy[i] = (int)(q % uMy);
+    q /= uMy;
+    cz[i] = (int)(q % uMz);
+    cn[i] = (int)(q / uMz);
+  }
+  int mrow = (int)(mbeg - 0);        // first pixel of the tile being loaded (32-bit: M < 2^31)
+  const int imend = (int)mend;
+
+  struct Stage {
+    float4 rd[DLOADS], rg[GLOADS];
+    unsigned gmask;
+  };
+  Stage SX, SY;
+  float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto issue_loads = [&](Stage& S) {
+#pragma unroll
+    for (int i = 0; i < DLOADS; ++i) {
+      const int m = mrow + drow0 + DROWSTEP * i;
+      const int ok = (m < imend ? 1 : 0) & dok;
+      S.rd[i] = *reinterpret_cast<const float4*>(gd + ((long)(ok * m) * ldd + ok * dcol));
+      // rows past the chunk / channels past Cd are zeroed at the LDS store; bias sums use the masked value there
+      if (!ok) S.rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    unsigned gm = 0;
+#pragma unroll
+    for (int i = 0; i < GLOADS; ++i) {
+      const int m = mrow + grow0 + GROWSTEP * i;
+      const int iz = cz[i] * p.sz - p.pz + gkz, iy = cy[i] * p.sy - p.py + gky, ix = cx[i] * p.sx - p.px + gkx;
+      const int ok = (m < imend ? 1 : 0) & gok & ((unsigned)iz < (unsigned)Gz ? 1 : 0) &
+                     ((unsigned)iy < (unsigned)Gy ? 1 : 0) & ((unsigned)ix < (unsigned)Gx ? 1 : 0);
+      const int pix = ok * (((cn[i] * Gz + iz) * Gy + iy) * Gx + ix);
+      S.rg[i] = *reinterpret_cast<const float4*>(gg + ((long)pix * ldg + ok * gci));
+      gm |= (unsigned)ok << i;
+      // advance the cursor by one K-step (32 pixels <= Mx: at most one carry per level)
+      cx[i] += WBK;
+      const int wx = cx[i] >= Mx ? 1 : 0;
+      cx[i] -= wx * Mx;
+      cy[i] += wx;
+      const int wy = cy[i] == My ? 1 : 0;
+      cy[i] -= wy * My;
+      cz[i] += wy;
+      const int wz = cz[i] == Mz ? 1 : 0;
+      cz[i] -= wz * Mz;
+      cn[i] += wz;
+    }
+    S.gmask = gm;
+    mrow += WBK;
+  };
+
+  auto store_tile = [&](int buf, const Stage& S) {
+    float* Ds = lds + buf * STAGE;
+    float* Gs = Ds + WBK * BD;
+#pragma unroll
+    for (int i = 0; i < DLOADS; ++i) {
+      const float4 v = S.rd[i];
+      bacc.x += v.x; bacc.y += v.y; bacc.z += v.z; bacc.w += v.w;
+      *reinterpret_cast<float4*>(Ds + (drow0 + DROWSTEP * i) * BD + dcc * 4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < GLOADS; ++i) {
+      float4 v = S.rg[i];
+      if constexpr (PRO == 1) {
+        v.x = act_apply(v.x * psc.x + psh.x, act, slope);
+        v.y = act_apply(v.y * psc.y + psh.y, act, slope);
+        v.z = act_apply(v.z * psc.z + psh.z, act, slope);
+        v.w = act_apply(v.w * psc.w + psh.w, act, slope);
+      }
+      const bool ok = (S.gmask >> i) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<float4*>(Gs + (grow0 + GROWSTEP * i) * BG + gcc * 4) = v;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (nk > 0) {
+    issue_loads(SX);
+    store_tile(0, SX);
+    issue_loads(SX);
+  }
+  __syncthreads();
+
+  auto step = [&](int cb, Stage& Sn, const Stage& Sp) {
+    const float* Ds = lds + cb * STAGE + wm * TM * 32 + li;
+    const float* Gs = lds + cb * STAGE + WBK * BD + wn * TN * 32 + li;
+    float a[2][4][TM], b[2][4][TN];
+    auto read_group = [&](int g, int slot) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kk = 2 * (4 * g + q) + lh;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) a[slot][q][tm] = Ds[kk * BD + tm * 32];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) b[slot][q][tn] = Gs[kk * BG + tn * 32];
+      }
+    };
+    read_group(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int sl = g & 1;
+      if (g < 3) read_group(g + 1, sl ^ 1);
+      if (g == 0) issue_loads(Sn);
+      if (g == 3) store_tile(cb ^ 1, Sp);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][q][tm], b[sl][q][tn], acc[tm][tn], 0, 0, 0);
+      if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+      if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < NMF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 13, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      } else if (g == 3) {
+#pragma unroll
+        for (int i = 0; i < NMF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 11, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(0, SY, SX);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      step(1, SX, SY);
+      __syncthreads();
+    }
+  }
+  // tiles past the chunk were stored (as zeros) once more than consumed: bacc saw only zeros there
+
+  if (p.bias_partial != nullptr && blockIdx.x == 0) {
+    float* red = lds;
+    *reinterpret_cast<float4*>(red + drow0 * BD + dcc * 4) = bacc;
+    __syncthreads();
+    if (tid < BD && d0 + tid < p.Cd) {
+      float t = 0.f;
+      for (int r = 0; r < DROWSTEP; ++r) t += red[r * BD + tid];
+      p.bias_partial[(long)blockIdx.z * p.Cd + d0 + tid] = t;
+    }
+  }
+  float* out = p.partial + (long)blockIdx.z * p.Cd * NC;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = c0 + (wn * TN + tn) * 32 + li;
+      if (col >= NC) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cd = d0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (cd < p.Cd) out[(long)cd * NC + col] = acc[tm][tn][r];
+      }
+    }
+}
+
 // dW[cd][cg][t] = beta*dW + sum_split partial[split][cd][t*Cg+cg]
 // block = 32 consecutive elements x 8 split lanes; lanes sum their splits in
 // order, then the 8 lane sums are added in order: deterministic.
@@ -363,6 +600,39 @@ static int launch_wgrad_variant(const WgradParams& p, const WgradPlan& pl, hipSt
   return check_launch("wgrad");
 }
 
+template <int BD, int BG, int TM, int TN, int WN, int PRO>
+static int launch_wgrad_pipe_variant(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+  auto kern = wgrad_pipe_kernel<BD, BG, TM, TN, WN, PRO>;
+  constexpr int smem = 2 * WBK * (BD + BG) * (int)sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      set_error("wgrad_pipe: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid((unsigned)pl.tiles_c, (unsigned)pl.tiles_d, (unsigned)pl.nsplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+  return check_launch("wgrad_pipe");
+}
+
+// returns 1 if no pipelined instance covers this plan
+template <int PRO>
+static int dispatch_wgrad_pipe(const WgradParams& p, const WgradPlan& pl, hipStream_t st, bool& handled) {
+  handled = true;
+  if (pl.BD == 128 && pl.BG == 128) return launch_wgrad_pipe_variant<128, 128, 2, 2, 2, PRO>(p, pl, st);
+  if (pl.BD == 128 && pl.BG == 64) return launch_wgrad_pipe_variant<128, 64, 1, 2, 1, PRO>(p, pl, st);
+  if (pl.BD == 64 && pl.BG == 128) return launch_wgrad_pipe_variant<64, 128, 2, 1, 4, PRO>(p, pl, st);
+  if (pl.BD == 64 && pl.BG == 64) return launch_wgrad_pipe_variant<64, 64, 1, 1, 2, PRO>(p, pl, st);
+  if (pl.BD == 32 && pl.BG == 128) return launch_wgrad_pipe_variant<32, 128, 1, 1, 4, PRO>(p, pl, st);
+  if (pl.BD == 128 && pl.BG == 32) return launch_wgrad_pipe_variant<128, 32, 1, 1, 1, PRO>(p, pl, st);
+  handled = false;
+  return MPGAN_OK;
+}
+
 template <bool SD, bool SG>
 static int dispatch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
   if (pl.BD == 128 && pl.BG == 128) return launch_wgrad_variant<128, 128, 2, 2, 2, 1, SD, SG>(p, pl, st);
@@ -449,8 +719,14 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
                                       reinterpret_cast<uintptr_t>(p.pro.shift)) & 15) == 0 &&
                                     p.pro.n_stride % 4 == 0));
   hipStream_t st = (hipStream_t)stream;
-  int rc;
-  if (vd && vg) rc = dispatch_wgrad<false, false>(p, pl, st);
+  int rc = MPGAN_OK;
+  bool handled = false;
+  static const bool no_pipe = getenv("MPGAN_DBG_NO_PIPE") != nullptr;
+  if (vd && vg && pl.kw == 1 && p.Mx >= WBK && p.pro.n_stride == 0 && !no_pipe) {
+    rc = p.pro.scale ? dispatch_wgrad_pipe<1>(p, pl, st, handled) : dispatch_wgrad_pipe<0>(p, pl, st, handled);
+  }
+  if (handled) { /* done */ }
+  else if (vd && vg) rc = dispatch_wgrad<false, false>(p, pl, st);
   else if (vd) rc = dispatch_wgrad<false, true>(p, pl, st);
   else if (vg) rc = dispatch_wgrad<true, false>(p, pl, st);
   else rc = dispatch_wgrad<true, true>(p, pl, st);

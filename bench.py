@@ -32,7 +32,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
-DOMINANT = "gather_conv_kernel<BN=128,vec4>"
+DOMINANT = "gather_conv_pipe_kernel<BN=128>"
 
 
 def synthetic_batch(bs, spatial, rank, device):

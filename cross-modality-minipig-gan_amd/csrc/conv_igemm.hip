@@ -46,8 +46,20 @@ struct GatherConv {
   int Kz, Ky, Kx;
   int ostride[3], istride[3], kstep[3], dstep[3];
   int nphase, tanh_out;
+  int mtiles, ntiles;   // 1-D launch of nphase*mtiles*ntiles blocks, XCD-remapped, n-tile fastest
   Phase ph[8];
 };
+
+struct BlockId { int mt, nt, phase; };
+__device__ __forceinline__ BlockId conv_block_id(const GatherConv& p) {
+  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
+  BlockId b;
+  b.nt = (int)(w % (unsigned)p.ntiles);
+  const unsigned q = w / (unsigned)p.ntiles;
+  b.mt = (int)(q % (unsigned)p.mtiles);
+  b.phase = (int)(q / (unsigned)p.mtiles);
+  return b;
+}
 
 constexpr int BM = 128;
 constexpr int BK = 32;
@@ -57,7 +69,7 @@ constexpr int PITCH = BK + 4;
 // optional fused BatchNorm statistics.  Called after the K-loop's final barrier.
 template <int BN, int TM, int TN, int WN>
 __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& ph, f32x16 (&acc)[TM][TN], float* lds,
-                                              long m0, int n0, long Mtot) {
+                                              long m0, int n0, long Mtot, int stats_row) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -141,7 +153,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
         sm += st[(w * 2 + 0) * BN + tid];
         sq += st[(w * 2 + 1) * BN + tid];
       }
-      float* row = p.stats + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * Cout;
+      float* row = p.stats + (long)stats_row * 2 * Cout;
       row[n0 + tid] = sm;
       row[Cout + n0 + tid] = sq;
     }
@@ -168,13 +180,15 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
   const int lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
-  const Phase ph = p.ph[blockIdx.z];
+  const BlockId bid = conv_block_id(p);
+  const Phase ph = p.ph[bid.phase];
   const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  const long m0 = (long)bid.mt * BM;
+  const int n0 = bid.nt * BN;
+  const int stats_row = bid.phase * p.mtiles + bid.mt;
   if (m0 >= Mtot) {
     if (p.stats && tid < BN && n0 + tid < p.Cout) {   // an empty tile of a short phase still owns a partial row
-      float* row = p.stats + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * p.Cout;
+      float* row = p.stats + (long)stats_row * 2 * p.Cout;
       row[n0 + tid] = 0.f;
       row[p.Cout + n0 + tid] = 0.f;
     }
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
     __syncthreads();
   }
 
-  conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot);
+  conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot, stats_row);
 }
 
 // ---------------------------------------------------------------------------
@@ -441,13 +455,15 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
   const int lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
-  const Phase ph = p.ph[blockIdx.z];
+  const BlockId bid = conv_block_id(p);
+  const Phase ph = p.ph[bid.phase];
   const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  const long m0 = (long)bid.mt * BM;
+  const int n0 = bid.nt * BN;
+  const int stats_row = bid.phase * p.mtiles + bid.mt;
   if (m0 >= Mtot) {
     if (p.stats && tid < BN && n0 + tid < p.Cout) {
-      float* row = p.stats + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * p.Cout;
+      float* row = p.stats + (long)stats_row * 2 * p.Cout;
       row[n0 + tid] = 0.f;
       row[p.Cout + n0 + tid] = 0.f;
     }
@@ -694,7 +710,7 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
       __syncthreads();
     }
   }
-  conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot);
+  conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot, stats_row);
 }
 
 // ---------------------------------------------------------------------------
@@ -880,8 +896,11 @@ static int launch_variant(const GatherConv& p, long maxM, hipStream_t st) {
     }
     attr_set = true;
   }
-  dim3 grid((unsigned)((maxM + BM - 1) / BM), (unsigned)((p.Cout + BN - 1) / BN), (unsigned)p.nphase);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+  GatherConv q = p;
+  q.mtiles = (int)((maxM + BM - 1) / BM);
+  q.ntiles = (p.Cout + BN - 1) / BN;
+  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
   return check_launch("gather_conv");
 }
 
@@ -924,8 +943,11 @@ static int launch_pipe_variant(const GatherConv& p, long maxM, hipStream_t st) {
     }
     attr_set = true;
   }
-  dim3 grid((unsigned)((maxM + BM - 1) / BM), (unsigned)((p.Cout + BN - 1) / BN), (unsigned)p.nphase);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+  GatherConv q = p;
+  q.mtiles = (int)((maxM + BM - 1) / BM);
+  q.ntiles = (p.Cout + BN - 1) / BN;
+  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
   return check_launch("gather_conv_pipe");
 }
 

@@ -33,7 +33,19 @@ struct WgradParams {
   int sz, sy, sx, pz, py, px;
   int nsplit;
   long chunk;  // pixels per split (multiple of 32)
+  int tiles_c, tiles_d;  // 1-D launch of tiles_c*tiles_d*nsplit blocks, XCD-remapped, column tile fastest
 };
+
+struct WBlockId { int tc, td, split; };
+__device__ __forceinline__ WBlockId wgrad_block_id(const WgradParams& p) {
+  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
+  WBlockId b;
+  b.tc = (int)(w % (unsigned)p.tiles_c);
+  const unsigned q = w / (unsigned)p.tiles_c;
+  b.td = (int)(q % (unsigned)p.tiles_d);
+  b.split = (int)(q / (unsigned)p.tiles_d);
+  return b;
+}
 
 constexpr int WBK = 32;
 
@@ -55,10 +67,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int wm = KW == 1 ? wid / WN : 0, wn = KW == 1 ? wid % WN : 0;
   const int T = p.Kz * p.Ky * p.Kx;
   const int NC = T * p.Cg;  // columns of R
-  const int c0 = blockIdx.x * BG;
-  const int d0 = blockIdx.y * BD;
+  const WBlockId bid = wgrad_block_id(p);
+  const int c0 = bid.tc * BG;
+  const int d0 = bid.td * BD;
   const long M = (long)p.N * p.Mz * p.My * p.Mx;
-  const long mbeg = (long)blockIdx.z * p.chunk;
+  const long mbeg = (long)bid.split * p.chunk;
   const long mend = mbeg + p.chunk < M ? mbeg + p.chunk : M;
   const int nk = mbeg < mend ? (int)((mend - mbeg + WBK - 1) / WBK) : 0;
   const float slope = pro_slope(p.pro);
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     __syncthreads();
   }
 
-  if (p.bias_partial != nullptr && blockIdx.x == 0) {
+  if (p.bias_partial != nullptr && bid.tc == 0) {
     // block-reduce the per-thread column sums over the (256/DCH) row groups, fixed order
     float* red = lds;   // [256/DCH][BD]; the K-loop is done with LDS
     *reinterpret_cast<float4*>(red + drow0 * BD + dcc * 4) = bacc;
@@ -252,10 +265,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     if (tid < BD && d0 + tid < p.Cd) {
       float t = 0.f;
       for (int r = 0; r < 256 / DCH; ++r) t += red[r * BD + tid];
-      p.bias_partial[(long)blockIdx.z * p.Cd + d0 + tid] = t;
+      p.bias_partial[(long)bid.split * p.Cd + d0 + tid] = t;
     }
   }
-  float* out = p.partial + ((long)blockIdx.z * KW + (KW == 1 ? 0 : wid)) * p.Cd * NC;
+  float* out = p.partial + ((long)bid.split * KW + (KW == 1 ? 0 : wid)) * p.Cd * NC;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -291,10 +304,11 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
   const int wm = wid / WN, wn = wid % WN;
   const int T = p.Kz * p.Ky * p.Kx;
   const int NC = T * p.Cg;
-  const int c0 = blockIdx.x * BG;
-  const int d0 = blockIdx.y * BD;
+  const WBlockId bid = wgrad_block_id(p);
+  const int c0 = bid.tc * BG;
+  const int d0 = bid.td * BD;
   const long M = (long)p.N * p.Mz * p.My * p.Mx;
-  const long mbeg = (long)blockIdx.z * p.chunk;
+  const long mbeg = (long)bid.split * p.chunk;
   const long mend = mbeg + p.chunk < M ? mbeg + p.chunk : M;
   const int nk = mbeg < mend ? (int)((mend - mbeg + WBK - 1) / WBK) : 0;
   const float slope = PRO ? pro_slope(p.pro) : 1.f;
@@ -481,17 +495,17 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
   }
   // tiles past the chunk were stored (as zeros) once more than consumed: bacc saw only zeros there
 
-  if (p.bias_partial != nullptr && blockIdx.x == 0) {
+  if (p.bias_partial != nullptr && bid.tc == 0) {
     float* red = lds;
     *reinterpret_cast<float4*>(red + drow0 * BD + dcc * 4) = bacc;
     __syncthreads();
     if (tid < BD && d0 + tid < p.Cd) {
       float t = 0.f;
       for (int r = 0; r < DROWSTEP; ++r) t += red[r * BD + tid];
-      p.bias_partial[(long)blockIdx.z * p.Cd + d0 + tid] = t;
+      p.bias_partial[(long)bid.split * p.Cd + d0 + tid] = t;
     }
   }
-  float* out = p.partial + (long)blockIdx.z * p.Cd * NC;
+  float* out = p.partial + (long)bid.split * p.Cd * NC;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -595,7 +609,7 @@ static int launch_wgrad_variant(const WgradParams& p, const WgradPlan& pl, hipSt
     }
     attr_set = true;
   }
-  dim3 grid((unsigned)pl.tiles_c, (unsigned)pl.tiles_d, (unsigned)pl.nsplit);
+  dim3 grid((unsigned)pl.tiles_c * pl.tiles_d * pl.nsplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
   return check_launch("wgrad");
 }
@@ -614,7 +628,7 @@ static int launch_wgrad_pipe_variant(const WgradParams& p, const WgradPlan& pl, 
     }
     attr_set = true;
   }
-  dim3 grid((unsigned)pl.tiles_c, (unsigned)pl.tiles_d, (unsigned)pl.nsplit);
+  dim3 grid((unsigned)pl.tiles_c * pl.tiles_d * pl.nsplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
   return check_launch("wgrad_pipe");
 }
@@ -699,6 +713,7 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
   p.pz = g->pad[0]; p.py = g->pad[1]; p.px = g->pad[2];
   p.N = g->n;
   p.nsplit = pl.nsplit; p.chunk = pl.chunk;
+  p.tiles_c = pl.tiles_c; p.tiles_d = pl.tiles_d;
   if (!g->transposed) {
     p.dense = dy; p.ldd = lddy; p.Cd = g->cout;
     p.gath = x; p.ldg = ldx; p.Cg = g->cin;

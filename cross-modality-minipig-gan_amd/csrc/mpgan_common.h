@@ -65,6 +65,15 @@ __device__ __forceinline__ float act_apply(float y, int act, float slope) {
   return (act == MPGAN_ACT_LEAKY && y < 0.f) ? y * slope : y;
 }
 
+// Blocks are dealt round-robin over the 8 XCDs (each with a private L2).  Map the
+// hardware block id to a WORK id so that each XCD walks a contiguous range of work
+// items: neighbouring tiles (shared halo rows, shared dy panels) then hit the same L2.
+// Bijective for any grid size.  Placement is a speed matter only, never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned orig, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7u, xcd = orig & 7u;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

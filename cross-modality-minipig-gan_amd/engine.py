@@ -120,6 +120,8 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool) -> str:
     if v == 2:
         return "thin_cout1_kernel"
     cin_eff = g.cout if backward_data else g.cin
+    if cin_eff % 32 == 0 or cin_eff == 16:
+        return f"gather_conv_pipe_kernel<BN={v}>"      # software-pipelined main kernel
     return f"gather_conv_kernel<BN={v},{'vec4' if cin_eff % 4 == 0 else 'scalar'}>"
 
 

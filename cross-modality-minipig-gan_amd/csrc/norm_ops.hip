@@ -169,6 +169,22 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restr
   }
 }
 
+// Thousands of partial rows (a conv's fused statistics leave one per pixel tile) are first
+// folded to NQ_COMPACT rows with coalesced reads: lane = channel, waves stride over rows.
+constexpr int COMPACT_ROWS = 32;
+__global__ __launch_bounds__(256) void partials_compact_kernel(const float* __restrict__ partials, int rows, int W,
+                                                               float* __restrict__ compact) {
+  __shared__ float sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);   // column of the [rows][W] matrix (W = NQ*C)
+  const int w = threadIdx.x >> 6, g = blockIdx.y;
+  float s = 0.f;
+  if (c < W)
+    for (int r = g * 4 + w; r < rows; r += COMPACT_ROWS * 4) s += partials[(long)r * W + c];
+  sh[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < W) compact[(long)g * W + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
 // One wave per channel.  slope_tmp[c] receives the channel's PReLU-slope term.
 __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __restrict__ partials, int N, int chunks,
                                                                 int C, long P, int instance, float* dgamma,
@@ -387,6 +403,17 @@ extern "C" int mpgan_norm_finalize(const float* partials, int32_t n, int32_t chu
                                    float* scale, float* shift, float* mean, float* invstd, void* stream) {
   MPGAN_CHECK_ARG(partials && scale && shift && mean && invstd && n > 0 && c > 0 && chunks > 0,
                   "norm_finalize: bad argument");
+  if (!instance && (long)n * chunks > 512) {
+    // fold the rows first; the compact rows live in the caller's buffer right after the input rows
+    const int rows = n * chunks, W = 2 * c;
+    float* compact = const_cast<float*>(partials) + (long)rows * W;
+    hipLaunchKernelGGL(partials_compact_kernel, dim3((W + 63) / 64, COMPACT_ROWS), dim3(256), 0, (hipStream_t)stream,
+                       partials, rows, W, compact);
+    partials = compact;
+    P = P * n;   // the element count per channel stays n*P
+    n = 1;
+    chunks = COMPACT_ROWS;
+  }
   const int total = instance ? n * c : c;
   hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, n,
                      chunks, c, (long)P, instance, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale,

@@ -344,7 +344,7 @@ def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod,
         emit_norm_stats(prog, y, nb, norm_mod, partials)
         return
     c = g.cout
-    assert partials.numel() >= rows * 2 * c
+    assert partials.numel() >= (rows + 32) * 2 * c
     emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro, stats=partials)
     n, P, _ = ops._cl(y, "conv+norm")
     rm = getattr(norm_mod, "running_mean", None)
@@ -409,13 +409,13 @@ class Scratch:
         self.ws = None
 
     def want_partials(self, n, P, c):
-        self.partials_need = max(self.partials_need, n * ops.stats_chunks(P, c) * 3 * c + c)
+        self.partials_need = max(self.partials_need, (n * ops.stats_chunks(P, c) + 32) * 3 * c + c)
 
     def want_ws(self, g: ConvGeom):
         self.ws_need = max(self.ws_need, ops.conv_wgrad_workspace(g) // 4)
         # fused-statistics partial rows of the forward conv (with or without prologue: same count)
-        self.partials_need = max(self.partials_need, ops.conv_stats_rows(g, True) * 2 * g.cout,
-                                 ops.conv_stats_rows(g, False) * 2 * g.cout)
+        rows = max(ops.conv_stats_rows(g, True), ops.conv_stats_rows(g, False))
+        self.partials_need = max(self.partials_need, (rows + 32) * 2 * g.cout)   # + finalize's fold scratch
 
     def alloc(self):
         self.partials = torch.empty(max(self.partials_need, 4), device=self.dev)

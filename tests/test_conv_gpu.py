@@ -224,11 +224,11 @@ def test_fused_batchnorm_statistics_from_conv_epilogue(cin, cout, k, s, p, spati
     g = _geom(2, n, cin, cout, k, s, p, spatial, transposed=transposed)
     rows = ops.conv_stats_rows(g, False)
     assert rows > 0
-    part = torch.full((rows * 2 * cout,), float("nan"), device="cuda")
+    part = torch.full(((rows + 32) * 2 * cout,), float("nan"), device="cuda")   # + finalize's fold scratch
     z = torch.empty(n, *g.out_dhw, cout, device="cuda")
     ops.conv_forward(g, to_cl(x), ops.pack_weight(w.cuda(), transposed=transposed), b.cuda(), z, stats_partials=part)
     assert_close(from_cl(z, 2), z_ref, what="conv output")
-    assert torch.isfinite(part).all()
+    assert torch.isfinite(part[:rows * 2 * cout]).all()
     scale, shift, mean, invstd = (torch.empty(cout, device="cuda") for _ in range(4))
     rmd, rvd = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")
     nbt = torch.zeros((), dtype=torch.int64, device="cuda")

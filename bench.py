@@ -35,6 +35,10 @@ PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix (= vector) 
 DOMINANT = "gather_conv_pipe_kernel<BN=128>"
 
 
+def note(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def synthetic_batch(bs, spatial, rank, device):
     g = torch.Generator().manual_seed(1234 + rank)
     t1 = torch.rand(bs, 1, *spatial, generator=g) * 2 - 1
@@ -65,8 +69,10 @@ def cpu_baseline_leg(gan, spatial, sample_bs=2, timed_steps=2):
     l1 = (y - y_ref).abs().mean().item()
     mse = ((y - y_ref) ** 2).mean().item()
     psnr = float("inf") if mse == 0 else 10.0 * torch.log10(torch.tensor(4.0 / mse)).item()  # data range 2
+    note(f"cpu baseline: oracle G forward done (L1 vs HIP {l1:.2e}); timing {timed_steps} oracle steps on {cores} threads")
     opts, _ = ref.configure_optimizers()
     ref.step(batch, 0, opts)                      # warm-up
+    note("cpu baseline: warm-up step done")
     t0 = time.perf_counter()
     for i in range(timed_steps):
         ref.step(batch, i + 1, opts)
@@ -74,10 +80,6 @@ def cpu_baseline_leg(gan, spatial, sample_bs=2, timed_steps=2):
     return {"value": sample_bs * timed_steps / dt, "unit": "slices/s", "cores": cores, "kind": "port",
             "sample": f"{timed_steps} G+D steps of the torch-CPU oracle at 256x256, bs {sample_bs} (1 warm-up)",
             "g_output_l1_vs_cpu": l1, "g_output_psnr_vs_cpu_db": psnr}
-
-
-def note(msg):
-    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():

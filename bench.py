@@ -16,7 +16,7 @@ batch already resident in HBM.  Rank 0 prints ONE JSON line.
                  achieved = algorithmic FLOPs of those launches / their time,
                  against the 157.3 TFLOP/s fp32 matrix peak.
   cpu_baseline : the CPU oracle (plain torch restatement, oracle/) timed on this
-                 host on a bounded sample (2 slices per step), plus the
+                 host on a bounded sample (4 slices per step, 6 steps), plus the
                  G-output L1 between the HIP path and that oracle.
 """
 import argparse
@@ -46,7 +46,7 @@ def synthetic_batch(bs, spatial, rank, device):
     return {"t1w": t1.to(device), "t2w": t2.to(device)}
 
 
-def cpu_baseline_leg(gan, spatial, sample_bs=2, timed_steps=2):
+def cpu_baseline_leg(gan, spatial, sample_bs=4, timed_steps=6):
     """Oracle on the host cores: bounded sample of the same workload + the
     G-output L1 of the HIP path against it (same weights, same input)."""
     from oracle import refmodel as R

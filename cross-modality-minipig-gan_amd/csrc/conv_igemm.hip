@@ -26,6 +26,7 @@ namespace mpgan {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct Phase {
+  FastDiv fMx, fMy, fMz;
   int Mz, My, Mx;     // extents of the m-grid of this phase
   int oz, oy, ox;     // output coordinate = m*ostride + o?
   int nz, ny, nx;     // taps per dimension
@@ -81,13 +82,12 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
     const unsigned m = (unsigned)m0 + tid;
     int pix = -1;
     if (m < (unsigned)Mtot) {
-      const unsigned uMx = ph.Mx, uMy = ph.My, uMz = ph.Mz;
-      int mx = (int)(m % uMx);
-      unsigned q = m / uMx;
-      int my = (int)(q % uMy);
-      q /= uMy;
-      int mz = (int)(q % uMz);
-      int n = (int)(q / uMz);
+      unsigned q, umx, umy, umz;
+      fdivmod(m, ph.fMx, q, umx);
+      fdivmod(q, ph.fMy, q, umy);
+      fdivmod(q, ph.fMz, q, umz);
+      const int mx = (int)umx, my = (int)umy, mz = (int)umz;
+      const int n = (int)q;
       int oz = mz * p.ostride[0] + ph.oz, oy = my * p.ostride[1] + ph.oy, ox = mx * p.ostride[2] + ph.ox;
       if (oz < p.Do && oy < p.Ho && ox < p.Wo) pix = ((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
     }
@@ -213,13 +213,12 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
   for (int i = 0; i < 4; ++i) {
     const unsigned m = (unsigned)m0 + r0 + 32 * i;   // host guarantees Mtot < 2^31
     if (m < (unsigned)Mtot) {
-      const unsigned uMx = ph.Mx, uMy = ph.My, uMz = ph.Mz;
-      int mx = (int)(m % uMx);
-      unsigned q = m / uMx;
-      int my = (int)(q % uMy);
-      q /= uMy;
-      int mz = (int)(q % uMz);
-      rn[i] = (int)(q / uMz);
+      unsigned q, umx, umy, umz;
+      fdivmod(m, ph.fMx, q, umx);
+      fdivmod(q, ph.fMy, q, umy);
+      fdivmod(q, ph.fMz, q, umz);
+      const int mx = (int)umx, my = (int)umy, mz = (int)umz;
+      rn[i] = (int)q;
       rz[i] = mz * p.istride[0];
       ry[i] = my * p.istride[1];
       rx[i] = mx * p.istride[2];
@@ -487,13 +486,12 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
   for (int i = 0; i < 4; ++i) {
     const unsigned m = (unsigned)m0 + r0 + 32 * i;
     if (m < (unsigned)Mtot) {
-      const unsigned uMx = ph.Mx, uMy = ph.My, uMz = ph.Mz;
-      int mx = (int)(m % uMx);
-      unsigned q = m / uMx;
-      int my = (int)(q % uMy);
-      q /= uMy;
-      int mz = (int)(q % uMz);
-      rn[i] = (int)(q / uMz);
+      unsigned q, umx, umy, umz;
+      fdivmod(m, ph.fMx, q, umx);
+      fdivmod(q, ph.fMy, q, umy);
+      fdivmod(q, ph.fMz, q, umz);
+      const int mx = (int)umx, my = (int)umy, mz = (int)umz;
+      rn[i] = (int)q;
       rz[i] = mz * p.istride[0];
       ry[i] = my * p.istride[1];
       rx[i] = mx * p.istride[2];
@@ -724,13 +722,12 @@ struct PixDecode {
 
 __device__ __forceinline__ PixDecode decode_pixel(const GatherConv& p, const Phase& ph, unsigned m) {
   PixDecode d;
-  const unsigned uMx = ph.Mx, uMy = ph.My, uMz = ph.Mz;
-  const int mx = (int)(m % uMx);
-  unsigned q = m / uMx;
-  const int my = (int)(q % uMy);
-  q /= uMy;
-  const int mz = (int)(q % uMz);
-  d.n = (int)(q / uMz);
+  unsigned q, umx, umy, umz;
+  fdivmod(m, ph.fMx, q, umx);
+  fdivmod(q, ph.fMy, q, umy);
+  fdivmod(q, ph.fMz, q, umz);
+  const int mx = (int)umx, my = (int)umy, mz = (int)umz;
+  d.n = (int)q;
   d.bz = mz * p.istride[0]; d.by = my * p.istride[1]; d.bx = mx * p.istride[2];
   const int oz = mz * p.ostride[0] + ph.oz, oy = my * p.ostride[1] + ph.oy, ox = mx * p.ostride[2] + ph.ox;
   d.opix = (oz < p.Do && oy < p.Ho && ox < p.Wo) ? ((d.n * p.Do + oz) * p.Ho + oy) * p.Wo + ox : -1;
@@ -920,11 +917,14 @@ static int select_variant(const GatherConv& p, long maxM, bool thin1, bool thin2
   if (thin2) return 2;
   // Largest channel tile that still yields >= 2 blocks per CU; small-M layers (the
   // U-Net bottom: 16K pixels) take narrower tiles rather than leave CUs idle.
+  // Widest channel tile that still gives every CU a block: the pipelined kernel keeps the
+  // matrix pipe ~85 % fed from ONE resident block, while narrow tiles (16 MFMAs per K-step
+  // and wave) cannot cover their own load/store/barrier overhead.
   const long mtiles = (maxM + BM - 1) / BM * p.nphase;
   int bn = 32;
-  if (p.Cout > 64 && mtiles * ((p.Cout + 127) / 128) >= 512) bn = 128;
-  else if (p.Cout > 32 && mtiles * ((p.Cout + 63) / 64) >= 512) bn = 64;
-  else if (p.Cout > 64 && mtiles * ((p.Cout + 31) / 32) < 256) bn = 64;   // tiny problem: fewer, fatter tiles
+  if (p.Cout > 64 && mtiles * ((p.Cout + 127) / 128) >= 256) bn = 128;
+  else if (p.Cout > 32 && mtiles * ((p.Cout + 63) / 64) >= 256) bn = 64;
+  else if (p.Cout > 64 && mtiles * ((p.Cout + 63) / 64) >= 128) bn = 64;
   return bn;
 }
 
@@ -1024,6 +1024,7 @@ static void build_forward(GatherConv& p, int n, const int32_t* gath_dhw, int cg,
   p.nphase = 1;
   Phase& ph = p.ph[0];
   ph.Mz = prod_dhw[0]; ph.My = prod_dhw[1]; ph.Mx = prod_dhw[2];
+  ph.fMx = make_fastdiv(ph.Mx); ph.fMy = make_fastdiv(ph.My); ph.fMz = make_fastdiv(ph.Mz);
   ph.oz = ph.oy = ph.ox = 0;
   ph.nz = k[0]; ph.ny = k[1]; ph.nx = k[2];
   ph.kz0 = ph.ky0 = ph.kx0 = 0;
@@ -1052,6 +1053,8 @@ static void build_transposed(GatherConv& p, int n, const int32_t* gath_dhw, int 
           M[d] = prod_dhw[d] > phs[d] ? (prod_dhw[d] - phs[d] + s[d] - 1) / s[d] : 0;
         }
         ph.Mz = M[0]; ph.My = M[1]; ph.Mx = M[2];
+        ph.fMx = make_fastdiv(M[2] > 0 ? M[2] : 1); ph.fMy = make_fastdiv(M[1] > 0 ? M[1] : 1);
+        ph.fMz = make_fastdiv(M[0] > 0 ? M[0] : 1);
         ph.oz = pz; ph.oy = py; ph.ox = px;
         ph.nz = nj[0]; ph.ny = nj[1]; ph.nx = nj[2];
         ph.kz0 = k0[0]; ph.ky0 = k0[1]; ph.kx0 = k0[2];

@@ -74,6 +74,31 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned orig, unsigned nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
+// Division of a 32-bit unsigned by a launch-time constant: multiply-high + shift
+// (Granlund-Montgomery, branch-free form) instead of the ~40-instruction software divide.
+struct FastDiv {
+  unsigned d, mul, sh;   // q = (((n - t) >> 1) + t) >> sh, t = mulhi(mul, n);  d == 1: q = n
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.mul = 0; f.sh = 0; f.d = 1; return f; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  f.sh = l - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  const unsigned t = __umulhi(f.mul, n);
+  return (((n - t) >> 1) + t) >> f.sh;
+}
+__device__ __forceinline__ void fdivmod(unsigned n, const FastDiv& f, unsigned& q, unsigned& r) {
+  q = fdiv(n, f);
+  r = n - q * f.d;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

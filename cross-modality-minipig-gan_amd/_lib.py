@@ -15,6 +15,11 @@ class ConvGeomC(C.Structure):
                 ("stride", C.c_int32 * 3), ("pad", C.c_int32 * 3), ("transposed", C.c_int32)]
 
 
+class PeerTapsC(C.Structure):
+    _fields_ = [("z_peer", C.c_void_p), ("ld_peer", C.c_int32), ("scale_peer", C.c_void_p),
+                ("shift_peer", C.c_void_p), ("coef", C.c_void_p)]
+
+
 class PrologueC(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("n_stride", C.c_int32),
                 ("act", C.c_int32), ("slope", C.c_float), ("slope_ptr", C.c_void_p)]
@@ -43,9 +48,14 @@ SIGNATURES = {
     "mpgan_channel_stats": (_I, [_P, _I, _I, _L, _I, _P, _P]),
     "mpgan_norm_finalize": (_I, [_P, _I, _I, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mpgan_norm_act_add": (_I, [_P, _I, _PR, _P, _I, _PR, _I, _L, _I, _I, _P, _I, _P]),
-    "mpgan_norm_bwd_reduce": (_I, [_P, _I, _P, _I, _PR, _P, _P, _I, _L, _I, _P, _P]),
+    "mpgan_norm_bwd_reduce": (_I, [_P, _I, _P, _I, _PR, _P, _P, C.POINTER(PeerTapsC), _I, _L, _I, _P, _P]),
+    "mpgan_tap_l1_partials": (_I, []),
+    "mpgan_tap_l1": (_I, [_P, _I, _PR, _P, _I, _PR, _L, _I, _P, _P, _P]),
+    "mpgan_conv_splitk_workspace": (_L, [_G]),
+    "mpgan_conv_forward_splitk": (_I, [_G, _P, _I, _P, _P, _PR, _P, _L, _P, _I, _P]),
+    "mpgan_sigmoid_forward": (_I, [_P, _I, _P, _P]),
     "mpgan_norm_bwd_finalize": (_I, [_P, _I, _I, _I, _L, _I, _P, _P, _P, _P, _P, _P]),
-    "mpgan_norm_bwd_apply": (_I, [_P, _I, _P, _I, _PR, _P, _P, _P, _P, _I, _L, _I, _P, _I, _P]),
+    "mpgan_norm_bwd_apply": (_I, [_P, _I, _P, _I, _PR, _P, _P, _P, _P, C.POINTER(PeerTapsC), _I, _L, _I, _P, _I, _P]),
     "mpgan_reduce_partials": (_I, [_P, _I, _I, _I, _P, _F, _P]),
     "mpgan_add_tanh": (_I, [_P, _P, _L, _I, _P, _P]),
     "mpgan_tanh_backward": (_I, [_P, _P, _L, _P, _P]),

@@ -47,18 +47,22 @@ struct GatherConv {
   int Kz, Ky, Kx;
   int ostride[3], istride[3], kstep[3], dstep[3];
   int nphase, tanh_out;
-  int mtiles, ntiles;   // 1-D launch of nphase*mtiles*ntiles blocks, XCD-remapped, n-tile fastest
+  int mtiles, ntiles;   // 1-D launch of ksplit*nphase*mtiles*ntiles blocks, XCD-remapped, n-tile fastest
+  int ksplit;           // > 1: each block covers a K slice and leaves raw partial sums in kpartial
+  float* kpartial;      // [ksplit][N*Do*Ho*Wo][Cout]
   Phase ph[8];
 };
 
-struct BlockId { int mt, nt, phase; };
+struct BlockId { int mt, nt, phase, split; };
 __device__ __forceinline__ BlockId conv_block_id(const GatherConv& p) {
   const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
   BlockId b;
   b.nt = (int)(w % (unsigned)p.ntiles);
-  const unsigned q = w / (unsigned)p.ntiles;
+  unsigned q = w / (unsigned)p.ntiles;
   b.mt = (int)(q % (unsigned)p.mtiles);
-  b.phase = (int)(q / (unsigned)p.mtiles);
+  q /= (unsigned)p.mtiles;
+  b.phase = (int)(q % (unsigned)p.nphase);
+  b.split = (int)(q / (unsigned)p.nphase);
   return b;
 }
 
@@ -76,6 +80,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
   const int Cout = p.Cout;
+  const int ksplit_id = p.ksplit > 1 ? (int)(xcd_remap(blockIdx.x, gridDim.x) / (unsigned)(p.ntiles * p.mtiles * p.nphase)) : 0;
   // ---- epilogue: row -> output pixel map through LDS, then bias/resid/tanh ----
   int* rowpix = reinterpret_cast<int*>(lds);
   if (tid < BM) {
@@ -94,6 +99,23 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
     rowpix[tid] = pix;
   }
   __syncthreads();
+  if (p.ksplit > 1) {   // split-K: raw partial sums, reduced (with bias) by splitk_reduce_kernel
+    float* part = p.kpartial + (long)ksplit_id * ((long)p.N * p.Do * p.Ho * p.Wo) * Cout;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int co = n0 + (wn * TN + tn) * 32 + li;
+        if (co >= Cout) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int pix = rowpix[row];
+          if (pix >= 0) part[(long)pix * Cout + co] = acc[tm][tn][r];
+        }
+      }
+    return;
+  }
   const float* gres = p.resid;
   float* gout = p.out;
   const int ldo = p.ldo, ldr = p.ldr, tanh_out = p.tanh_out;
@@ -471,7 +493,10 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
   const int Cin = p.Cin, Cout = p.Cout, Di = p.Di, Hi = p.Hi, Wi = p.Wi, ldi = p.ldi;
   const int ntaps = ph.nz * ph.ny * ph.nx;
   const int Kp = ntaps * Cin;
-  const int nk = (Kp + BK - 1) / BK;
+  const int nk_all = (Kp + BK - 1) / BK;
+  const int nk_per = (nk_all + p.ksplit - 1) / p.ksplit;
+  const int kt_begin = bid.split * nk_per;              // split-K: this block's K-step range
+  const int nk = nk_all - kt_begin < nk_per ? (nk_all - kt_begin > 0 ? nk_all - kt_begin : 0) : nk_per;
   const long Ktot = (long)p.Kz * p.Ky * p.Kx * Cin;
   const float* __restrict__ gin = p.in;
   const float* __restrict__ gw = p.wp;
@@ -528,7 +553,7 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
     delta = (dz * Hi + dy) * Wi + dx;
   };
   {
-    const int kidx = cc * 4;
+    const int kidx = kt_begin * BK + cc * 4;
     const int tap = kidx / Cin;
     ci = kidx - tap * Cin;
     jx = tap % ph.nx;
@@ -896,6 +921,7 @@ static int launch_variant(const GatherConv& p, long maxM, hipStream_t st) {
   GatherConv q = p;
   q.mtiles = (int)((maxM + BM - 1) / BM);
   q.ntiles = (p.Cout + BN - 1) / BN;
+  q.ksplit = 1;
   dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
   return check_launch("gather_conv");
@@ -946,7 +972,8 @@ static int launch_pipe_variant(const GatherConv& p, long maxM, hipStream_t st) {
   GatherConv q = p;
   q.mtiles = (int)((maxM + BM - 1) / BM);
   q.ntiles = (p.Cout + BN - 1) / BN;
-  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
+  if (q.ksplit < 1) q.ksplit = 1;
+  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase * q.ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
   return check_launch("gather_conv_pipe");
 }
@@ -1077,6 +1104,45 @@ static void build_for_forward(GatherConv& p, const mpgan_conv_geom* g) {
     build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
 }
 
+// out[pix][co] = bias[co] + sum_s partial[s][pix][co]   (fixed order)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long rows,
+                                                            int Cout, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int ldo) {
+  const long total = rows * Cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / Cout;
+    const int co = (int)(i - pix * Cout);
+    float s = bias ? bias[co] : 0.f;
+    for (int k = 0; k < ksplit; ++k) s += part[(long)k * total + i];
+    out[pix * ldo + co] = s;
+  }
+}
+
+// Split-K plan for a forward conv whose output grid alone cannot fill the chip
+// (the variant-B head Linear(512*8^3 -> 64): 7 pixel tiles, 8192 K-steps).
+static int plan_ksplit(const GatherConv& p) {
+  if (!(p.Cin % 32 == 0) || p.Cout == 1 || p.nphase != 1) return 1;
+  const long maxM = max_phase_pixels(p);
+  const int variant = select_variant(p, maxM, false, false);
+  const long blocks = (maxM + BM - 1) / BM * ((p.Cout + variant - 1) / variant) * p.nphase;
+  if (blocks >= 128) return 1;
+  const Phase& ph = p.ph[0];
+  const long nk = ((long)ph.nz * ph.ny * ph.nx * p.Cin + BK - 1) / BK;
+  long want = (512 + blocks - 1) / blocks;
+  if (want > nk / 8) want = nk / 8;            // keep >= 8 K-steps per slice
+  if (want > 256) want = 256;
+  return want < 2 ? 1 : (int)want;
+}
+
+extern "C" int64_t mpgan_conv_splitk_workspace(const mpgan_conv_geom* g) {
+  if (check_geom(g)) return -1;
+  GatherConv p{};
+  build_for_forward(p, g);
+  const int ks = plan_ksplit(p);
+  if (ks <= 1) return 0;
+  return (int64_t)ks * g->n * g->out_dhw[0] * g->out_dhw[1] * g->out_dhw[2] * g->cout * (int64_t)sizeof(float);
+}
+
 extern "C" int32_t mpgan_conv_stats_rows(const mpgan_conv_geom* g, int32_t has_prologue) {
   const int v = mpgan_conv_variant(g, 0, has_prologue);
   if (v < 32) return 0;   // thin VALU kernels (or invalid geometry): no fused statistics
@@ -1105,6 +1171,39 @@ extern "C" int mpgan_conv_forward(const mpgan_conv_geom* g, const float* x, int3
     p.stats = stats_partials;
   }
   return launch_gather(p, (hipStream_t)stream);
+}
+
+// y = conv(prologue(x)) + bias with the K axis split over blocks (small output grids).
+extern "C" int mpgan_conv_forward_splitk(const mpgan_conv_geom* g, const float* x, int32_t ldx, const float* w_packed,
+                                         const float* bias, const mpgan_prologue* pro, void* workspace,
+                                         int64_t workspace_bytes, float* y, int32_t ldy, void* stream) {
+  int rc = check_geom(g);
+  if (rc) return rc;
+  MPGAN_CHECK_ARG(x && w_packed && y, "conv_forward_splitk: null pointer");
+  MPGAN_CHECK_ARG(ldx >= g->cin && ldy >= g->cout, "conv_forward_splitk: bad pitch");
+  GatherConv p{};
+  p.in = x; p.wp = w_packed; p.out = y; p.bias = bias;
+  p.pro = make_pro(pro);
+  p.ldi = ldx; p.ldo = ldy;
+  build_for_forward(p, g);
+  const int ks = plan_ksplit(p);
+  if (ks <= 1) return launch_gather(p, (hipStream_t)stream);
+  const long rows = (long)g->n * g->out_dhw[0] * g->out_dhw[1] * g->out_dhw[2];
+  const int64_t need = (int64_t)ks * rows * g->cout * (int64_t)sizeof(float);
+  MPGAN_CHECK_ARG(workspace && workspace_bytes >= need, "conv_forward_splitk: workspace %lld < %lld bytes",
+                  (long long)workspace_bytes, (long long)need);
+  MPGAN_UNSUPPORTED((p.ldi % 4) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w_packed) & 15),
+                    "conv_forward_splitk: operands must be 16-byte vectorisable");
+  p.ksplit = ks;
+  p.kpartial = static_cast<float*>(workspace);
+  p.bias = nullptr;
+  rc = launch_gather(p, (hipStream_t)stream);
+  if (rc) return rc;
+  long blocks = (rows * g->cout + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p.kpartial, ks,
+                     rows, g->cout, bias, y, ldy);
+  return check_launch("splitk_reduce");
 }
 
 extern "C" int mpgan_conv_backward_data(const mpgan_conv_geom* g, const float* dy, int32_t lddy,

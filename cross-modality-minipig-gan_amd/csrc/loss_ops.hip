@@ -95,6 +95,11 @@ __global__ void sigmoid_backward_kernel(const float* __restrict__ dprob, const f
   dlogit[i] = dprob[i] * (1.f - pr) * pr;
 }
 
+__global__ void sigmoid_forward_kernel(const float* __restrict__ logit, int n, float* __restrict__ prob) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) prob[i] = 1.f / (1.f + expf(-logit[i]));
+}
+
 __global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ scalar, long numel,
                                                               float* __restrict__ y) {
@@ -233,16 +238,21 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     int co, ci, t;
-    if (!dgrad) {  // dst [co][t][ci]
+    if (dgrad == 0) {  // dst [co][t][ci]
       ci = (int)(i % Cin);
       long q = i / Cin;
       t = (int)(q % T);
       co = (int)(q / T);
-    } else {  // dst [ci][t][co]
+    } else if (dgrad == 1) {  // dst [ci][t][co]
       co = (int)(i % Cout);
       long q = i / Cout;
       t = (int)(q % T);
       ci = (int)(q / T);
+    } else {  // dst [t][ci][co]: a Linear-as-conv's data gradient run as one (P x Cout) * (Cout x T*Cin) GEMM
+      co = (int)(i % Cout);
+      long q = i / Cout;
+      ci = (int)(q % Cin);
+      t = (int)(q / Cin);
     }
     const long s = transposed ? ((long)ci * Cout + co) * T + t : ((long)co * Cin + ci) * T + t;
     dst[dof + i] = src[so + s];
@@ -386,6 +396,12 @@ extern "C" int mpgan_sigmoid_backward(const float* dprob, const float* prob, int
   hipLaunchKernelGGL(sigmoid_backward_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dprob, prob, n,
                      dlogit);
   return check_launch("sigmoid_backward");
+}
+
+extern "C" int mpgan_sigmoid_forward(const float* logit, int32_t n, float* prob, void* stream) {
+  MPGAN_CHECK_ARG(logit && prob && n > 0, "sigmoid_forward: bad argument");
+  hipLaunchKernelGGL(sigmoid_forward_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, logit, n, prob);
+  return check_launch("sigmoid_forward");
 }
 
 extern "C" int mpgan_scale_by_device_scalar(const float* x, const float* scalar, int64_t numel, float* y,

@@ -45,6 +45,24 @@ struct Pro {
   int act;
 };
 
+// Device view of mpgan_peer_taps (perceptual-loss taps against a peer pass).
+struct Peer {
+  const float* z;
+  const float* scale;
+  const float* shift;
+  const float* coef;   // device float[3]: (z, y, a) gradient coefficients; null => no peer
+  int ld;
+};
+
+inline Peer make_peer(const mpgan_peer_taps* t) {
+  Peer r;
+  if (t == nullptr || t->coef == nullptr) { r.z = r.scale = r.shift = r.coef = nullptr; r.ld = 0; }
+  else { r.z = t->z_peer; r.scale = t->scale_peer; r.shift = t->shift_peer; r.coef = t->coef; r.ld = t->ld_peer; }
+  return r;
+}
+
+__device__ __forceinline__ float sgn(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+
 inline Pro make_pro(const mpgan_prologue* p) {
   Pro r;
   if (p == nullptr || p->scale == nullptr) {

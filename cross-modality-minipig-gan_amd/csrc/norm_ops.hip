@@ -92,13 +92,42 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
   });
 }
 
+// Gradient w.r.t. the norm output for one element, including the perceptual-loss taps of a
+// peer pass when present (test_runs/GAN.py:288-298: L1 between the two passes' activations):
+//   g_a = g - ca*sign(a_peer - a),  gy = g_a*act'(y) - cy*sign(y_peer - y)
+// and the extra dz term -cz*sign(z_peer - z) that bypasses the norm.
+struct TapGrad { float gy, dz_extra, slope_term; };
+__device__ __forceinline__ TapGrad tap_grad(float g, float z, float y, bool leaky, float slope, const Peer& pr,
+                                            long prow, int c, int si_peer, float cz, float cy, float ca) {
+  TapGrad t;
+  t.dz_extra = 0.f;
+  float ga = g;
+  float gy_extra = 0.f;
+  if (pr.coef) {
+    const float zp = pr.z[prow * pr.ld + c];
+    const float yp = zp * pr.scale[si_peer] + pr.shift[si_peer];
+    const float ap = (leaky && yp < 0.f) ? yp * slope : yp;
+    const float a = (leaky && y < 0.f) ? y * slope : y;
+    ga -= ca * sgn(ap - a);
+    gy_extra = -cy * sgn(yp - y);
+    t.dz_extra = -cz * sgn(zp - z);
+  }
+  const bool neg = leaky && y < 0.f;
+  t.gy = (neg ? ga * slope : ga) + gy_extra;
+  t.slope_term = neg ? ga * y : 0.f;
+  return t;
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ gr, int ldg,
                                                               const float* __restrict__ z, int ldz, Pro p,
                                                               const float* __restrict__ mean,
-                                                              const float* __restrict__ invstd, ReduceGeom g,
+                                                              const float* __restrict__ invstd, Peer pr, ReduceGeom g,
                                                               float* __restrict__ partials) {
   const float slope = pro_slope(p);
+  const bool leaky = p.act == MPGAN_ACT_LEAKY;
+  float cz = 0.f, cy = 0.f, ca = 0.f;
+  if (pr.coef) { cz = pr.coef[0]; cy = pr.coef[1]; ca = pr.coef[2]; }
   chunk_reduce<V, 3>(g, partials, [&](int n, int c, long row, float (&acc)[3][V]) {
     float zv[V], gv[V];
     Vec<V>::load(z + row * ldz + c, zv);
@@ -108,11 +137,10 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
     for (int e = 0; e < V; ++e) {
       const float y = zv[e] * p.scale[si + e] + p.shift[si + e];
       const float zh = (zv[e] - mean[si + e]) * invstd[si + e];
-      const bool neg = (p.act == MPGAN_ACT_LEAKY) && y < 0.f;
-      const float gy = neg ? gv[e] * slope : gv[e];
-      acc[0][e] += gy;
-      acc[1][e] += gy * zh;
-      acc[2][e] += neg ? gv[e] * y : 0.f;
+      const TapGrad t = tap_grad(gv[e], zv[e], y, leaky, slope, pr, row, c + e, c + e, cz, cy, ca);
+      acc[0][e] += t.gy;
+      acc[1][e] += t.gy * zh;
+      acc[2][e] += t.slope_term;
     }
   });
 }
@@ -292,18 +320,21 @@ __global__ __launch_bounds__(256) void norm_act_add_kernel(const float* __restri
   }
 }
 
-template <int V>
 // gr and dz may alias (in-place): every element is read before it is written by the same thread.
+template <int V>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* gr, int ldg,
                                                              const float* __restrict__ z, int ldz, Pro p,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
                                                              const float* __restrict__ c1,
-                                                             const float* __restrict__ c2, long rows, long P, int C,
-                                                             float* dz, int lddz) {
+                                                             const float* __restrict__ c2, Peer pr, long rows, long P,
+                                                             int C, float* dz, int lddz) {
   const int CG = C / V;
   const long total = rows * CG;
   const float slope = pro_slope(p);
+  const bool leaky = p.act == MPGAN_ACT_LEAKY;
+  float cz = 0.f, cy = 0.f, ca = 0.f;
+  if (pr.coef) { cz = pr.coef[0]; cy = pr.coef[1]; ca = pr.coef[2]; }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long row = i / CG;
     const int c = (int)(i - row * CG) * V;
@@ -316,11 +347,45 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* gr, in
     for (int e = 0; e < V; ++e) {
       const float y = zv[e] * p.scale[si + e] + p.shift[si + e];
       const float zh = (zv[e] - mean[si + e]) * invstd[si + e];
-      const float gy = ((p.act == MPGAN_ACT_LEAKY) && y < 0.f) ? gv[e] * slope : gv[e];
-      o[e] = p.scale[si + e] * (gy - c1[si + e] - zh * c2[si + e]);
+      const TapGrad t = tap_grad(gv[e], zv[e], y, leaky, slope, pr, row, c + e, c + e, cz, cy, ca);
+      o[e] = p.scale[si + e] * (t.gy - c1[si + e] - zh * c2[si + e]) + t.dz_extra;
     }
     Vec<V>::store(dz + row * lddz + c, o);
   }
+}
+
+// Perceptual-loss value of one conv+norm+act layer: sums of |z-z'|, |y-y'|, |a-a'| (block partials).
+__global__ __launch_bounds__(256) void tap_l1_kernel(const float* __restrict__ za, int lda, Pro pa,
+                                                     const float* __restrict__ zb, int ldb, Pro pb, long rows, int C,
+                                                     float* __restrict__ partials) {
+  __shared__ float sh[3][4];
+  const float sa = pro_slope(pa), sb = pro_slope(pb);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const long total = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C;
+    const int c = (int)(i - row * C);
+    const float z1 = za[row * lda + c], z2 = zb[row * ldb + c];
+    const float y1 = z1 * pa.scale[c] + pa.shift[c], y2 = z2 * pb.scale[c] + pb.shift[c];
+    const float a1 = act_apply(y1, pa.act, sa), a2 = act_apply(y2, pb.act, sb);
+    s0 += fabsf(z1 - z2);
+    s1 += fabsf(y1 - y2);
+    s2 += fabsf(a1 - a2);
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sh[0][w] = s0; sh[1][w] = s1; sh[2][w] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 3) partials[blockIdx.x * 3 + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+
+__global__ __launch_bounds__(64) void tap_l1_final_kernel(const float* __restrict__ partials, int nblocks, double inv_numel,
+                                                          float* __restrict__ out3) {
+  const int q = threadIdx.x;
+  if (q >= 3) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += (double)partials[b * 3 + q];
+  out3[q] = (float)(s * inv_numel);
 }
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int rows,
@@ -440,8 +505,9 @@ extern "C" int mpgan_norm_act_add(const float* z, int32_t ldz, const mpgan_prolo
 }
 
 extern "C" int mpgan_norm_bwd_reduce(const float* g, int32_t ldg, const float* z, int32_t ldz,
-                                     const mpgan_prologue* p, const float* mean, const float* invstd, int32_t n,
-                                     int64_t P, int32_t c, float* partials, void* stream) {
+                                     const mpgan_prologue* p, const float* mean, const float* invstd,
+                                     const mpgan_peer_taps* peer, int32_t n, int64_t P, int32_t c, float* partials,
+                                     void* stream) {
   MPGAN_CHECK_ARG(g && z && p && p->scale && mean && invstd && partials && n > 0 && P > 0 && c > 0 && ldg >= c &&
                       ldz >= c,
                   "norm_bwd_reduce: bad argument");
@@ -452,12 +518,14 @@ extern "C" int mpgan_norm_bwd_reduce(const float* g, int32_t ldg, const float* z
   dim3 grid(geo.chunks, n);
   const size_t smem = (size_t)geo.R * 3 * c * sizeof(float);
   Pro pp = make_pro(p);
+  Peer pe = make_peer(peer);
+  MPGAN_UNSUPPORTED(pe.coef && p->n_stride != 0, "norm_bwd_reduce: peer taps are defined for BatchNorm layers only");
   if (vec)
     hipLaunchKernelGGL(norm_bwd_reduce_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, g, ldg, z, ldz, pp, mean,
-                       invstd, geo, partials);
+                       invstd, pe, geo, partials);
   else
     hipLaunchKernelGGL(norm_bwd_reduce_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, g, ldg, z, ldz, pp, mean,
-                       invstd, geo, partials);
+                       invstd, pe, geo, partials);
   return check_launch("norm_bwd_reduce");
 }
 
@@ -475,7 +543,8 @@ extern "C" int mpgan_norm_bwd_finalize(const float* partials, int32_t n, int32_t
 
 extern "C" int mpgan_norm_bwd_apply(const float* g, int32_t ldg, const float* z, int32_t ldz, const mpgan_prologue* p,
                                     const float* mean, const float* invstd, const float* c1, const float* c2,
-                                    int32_t n, int64_t P, int32_t c, float* dz, int32_t lddz, void* stream) {
+                                    const mpgan_peer_taps* peer, int32_t n, int64_t P, int32_t c, float* dz,
+                                    int32_t lddz, void* stream) {
   MPGAN_CHECK_ARG(g && z && p && p->scale && mean && invstd && c1 && c2 && dz && n > 0 && P > 0 && c > 0 &&
                       ldg >= c && ldz >= c && lddz >= c,
                   "norm_bwd_apply: bad argument");
@@ -483,12 +552,13 @@ extern "C" int mpgan_norm_bwd_apply(const float* g, int32_t ldg, const float* z,
                    aligned16(g) && aligned16(dz);
   const long rows = (long)n * P;
   Pro pp = make_pro(p);
+  Peer pe = make_peer(peer);
   if (vec)
     hipLaunchKernelGGL(norm_bwd_apply_kernel<4>, dim3(ew_blocks(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream, g,
-                       ldg, z, ldz, pp, mean, invstd, c1, c2, rows, (long)P, c, dz, lddz);
+                       ldg, z, ldz, pp, mean, invstd, c1, c2, pe, rows, (long)P, c, dz, lddz);
   else
     hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, dim3(ew_blocks(rows * c)), dim3(256), 0, (hipStream_t)stream, g, ldg,
-                       z, ldz, pp, mean, invstd, c1, c2, rows, (long)P, c, dz, lddz);
+                       z, ldz, pp, mean, invstd, c1, c2, pe, rows, (long)P, c, dz, lddz);
   return check_launch("norm_bwd_apply");
 }
 
@@ -511,4 +581,21 @@ extern "C" int mpgan_copy_slice(const float* src, int32_t lds_, float* dst, int3
     hipLaunchKernelGGL(copy_slice_kernel<1>, dim3(ew_blocks(pixels * c)), dim3(256), 0, (hipStream_t)stream, src, lds_,
                        dst, ldd, (long)pixels, c, accumulate);
   return check_launch("copy_slice");
+}
+
+extern "C" int32_t mpgan_tap_l1_partials(void) { return 3 * 1024; }
+
+extern "C" int mpgan_tap_l1(const float* za, int32_t lda, const mpgan_prologue* pa, const float* zb, int32_t ldb,
+                            const mpgan_prologue* pb, int64_t rows, int32_t c, float* partials, float* out3,
+                            void* stream) {
+  MPGAN_CHECK_ARG(za && zb && pa && pb && pa->scale && pb->scale && partials && out3 && rows > 0 && c > 0,
+                  "tap_l1: bad argument");
+  MPGAN_UNSUPPORTED(pa->n_stride != 0 || pb->n_stride != 0, "tap_l1: BatchNorm layers only");
+  long blocks = (rows * c + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(tap_l1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, za, lda, make_pro(pa), zb,
+                     ldb, make_pro(pb), (long)rows, c, partials);
+  hipLaunchKernelGGL(tap_l1_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, (int)blocks,
+                     1.0 / ((double)rows * c), out3);
+  return check_launch("tap_l1");
 }

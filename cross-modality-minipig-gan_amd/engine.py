@@ -138,7 +138,7 @@ def _p(t):
 # --------------------------------------------------------------------------
 class ConvRec:
     """One conv / transposed conv / linear-as-conv weight in the flat store."""
-    __slots__ = ("mod", "transposed", "cout", "cin", "taps", "w_off", "fwd_off", "bwd_off")
+    __slots__ = ("mod", "transposed", "cout", "cin", "taps", "w_off", "fwd_off", "bwd_off", "tco", "tco_off")
 
 
 class ParamStore:
@@ -203,7 +203,7 @@ class ParamStore:
         o = self._off[id(p)]
         return self.flat_grad[o:o + p.numel()].view(p.shape)
 
-    def register_conv(self, mod, *, cout, cin, taps, transposed=False):
+    def register_conv(self, mod, *, cout, cin, taps, transposed=False, tco=False):
         """Register a weight for packing.  All weights must be registered before
         the first plan is built (packed offsets are baked into the programs)."""
         if id(mod) in self._by_mod:
@@ -214,6 +214,7 @@ class ParamStore:
             raise RuntimeError("ParamStore: conv registered after plans were built")
         r = ConvRec()
         r.mod, r.transposed, r.cout, r.cin, r.taps = mod, transposed, cout, cin, taps
+        r.tco, r.tco_off = tco, -1
         self.convs.append(r)
         self._by_mod[id(mod)] = r
         if self.flat is not None:
@@ -234,6 +235,10 @@ class ParamStore:
             off += (n + 3) // 4 * 4
             rows.append([r.w_off, r.fwd_off, r.cout, r.cin, r.taps, int(r.transposed), 0, 0])
             rows.append([r.w_off, r.bwd_off, r.cout, r.cin, r.taps, int(r.transposed), 1, 0])
+            if r.tco:
+                r.tco_off = off
+                off += (n + 3) // 4 * 4
+                rows.append([r.w_off, r.tco_off, r.cout, r.cin, r.taps, int(r.transposed), 2, 0])
         dev = self.flat.device
         self.packed = torch.empty(off, dtype=torch.float32, device=dev)
         self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
@@ -249,6 +254,9 @@ class ParamStore:
 
     def wp_bwd(self, rec: ConvRec) -> torch.Tensor:
         return self.packed[rec.bwd_off:rec.bwd_off + rec.cout * rec.cin * rec.taps]
+
+    def wp_tco(self, rec: ConvRec) -> torch.Tensor:
+        return self.packed[rec.tco_off:rec.tco_off + rec.cout * rec.cin * rec.taps]
 
 
 # --------------------------------------------------------------------------
@@ -366,7 +374,7 @@ def emit_norm_act_add(prog, z, pz, r, pr, out, tanh=False):
              keep=(z, pzc, pz, r, prc, pr, out))
 
 
-def emit_norm_bwd(prog, g, z, nb: NormBuf, pro: Prologue, dz, partials, dgamma, dbeta, dslope):
+def emit_norm_bwd(prog, g, z, nb: NormBuf, pro: Prologue, dz, partials, dgamma, dbeta, dslope, peer=None):
     """reduce -> finalize -> apply.  dgamma/dbeta/dslope are gradient views
     (accumulated into) or None when the owner's parameters are frozen."""
     n, P, ldz = ops._cl(z, "norm_bwd z")
@@ -376,13 +384,16 @@ def emit_norm_bwd(prog, g, z, nb: NormBuf, pro: Prologue, dz, partials, dgamma, 
     assert partials.numel() >= n * chunks * 3 * c + c
     L = lib()
     pc = pro.c()
+    pe = peer.c() if peer is not None else None
+    pe_ref = C.byref(pe) if pe is not None else None
     prog.add("norm_bwd_reduce", L.mpgan_norm_bwd_reduce, g.data_ptr(), _ld(g), z.data_ptr(), ldz, C.byref(pc),
-             nb.mean.data_ptr(), nb.invstd.data_ptr(), n, P, c, partials.data_ptr(), keep=(g, z, pc, pro, nb, partials))
+             nb.mean.data_ptr(), nb.invstd.data_ptr(), pe_ref, n, P, c, partials.data_ptr(),
+             keep=(g, z, pc, pro, nb, partials, pe, peer))
     prog.add("norm_bwd_finalize", L.mpgan_norm_bwd_finalize, partials.data_ptr(), n, chunks, c, P, int(nb.instance),
              _p(dgamma), _p(dbeta), _p(dslope), nb.c1.data_ptr(), nb.c2.data_ptr(), keep=(dgamma, dbeta, dslope))
     prog.add("norm_bwd_apply", L.mpgan_norm_bwd_apply, g.data_ptr(), _ld(g), z.data_ptr(), ldz, C.byref(pc),
-             nb.mean.data_ptr(), nb.invstd.data_ptr(), nb.c1.data_ptr(), nb.c2.data_ptr(), n, P, c, dz.data_ptr(),
-             _ld(dz), keep=(dz,))
+             nb.mean.data_ptr(), nb.invstd.data_ptr(), nb.c1.data_ptr(), nb.c2.data_ptr(), pe_ref, n, P, c,
+             dz.data_ptr(), _ld(dz), keep=(dz,))
 
 
 def _t3(v, dims, fill):
@@ -823,3 +834,143 @@ class DiscPlan:
             elif want_input_grad:
                 self.g_x = E(n, *dhw, 1)
                 emit_conv_dgrad(b, geoms[0], gas[0], store.wp_bwd(recs[0]), self.g_x)
+
+
+# --------------------------------------------------------------------------
+# patch discriminator (variant B)
+# --------------------------------------------------------------------------
+class PatchDiscPlan:
+    """4 x (valid k3 conv -> BN -> LeakyReLU 0.2) -> Flatten -> Linear(F,64) -> Linear(64,1) ->
+    Sigmoid on small patches (test_runs/GAN.py:136-198).  The 16 perceptual taps are never
+    materialised: their L1 terms and gradients come from the raw conv outputs of the two
+    passes (`peer`), see mpgan_peer_taps."""
+
+    def __init__(self, disc, store: ParamStore, n: int, spatial: Sequence[int], *, want_backward: bool,
+                 want_input_grad: bool, want_param_grads: bool):
+        dims = disc.dimensions
+        dev = store.flat.device
+        dhw = _t3(spatial, dims, 1)
+        self.n, self.dhw, self.dims, self.store, self.disc = n, dhw, dims, store, disc
+        self.want_input_grad, self.want_param_grads = want_input_grad, want_param_grads
+        E = lambda *shape: torch.empty(*shape, device=dev)
+        Z = lambda *shape: torch.zeros(*shape, device=dev)
+        convs = [disc.model_conv[i] for i in (0, 3, 6, 9)]
+        bns = [disc.model_conv[i] for i in (1, 4, 7, 10)]
+        lin1, lin2 = disc.model_linear[1], disc.model_linear[2]
+        self.convs, self.bns, self.lin1, self.lin2 = convs, bns, lin1, lin2
+        self.x_in = E(n, *dhw, 1)
+        self.geoms, self.zs, self.nbs, self.recs = [], [], [], []
+        size = dhw
+        scratch = Scratch(dev)
+        for cv in convs:
+            g = conv_geom_of(cv, n, size, dims)
+            self.geoms.append(g)
+            size = g.out_dhw
+            if min(size) < 1:
+                raise ValueError(f"patch discriminator input {spatial} too small")
+            self.zs.append(E(n, *size, cv.out_channels))
+            self.nbs.append(NormBuf(n, cv.out_channels, False, dev))
+            self.recs.append(store.register_conv(cv, cout=cv.out_channels, cin=cv.in_channels,
+                                                 taps=int(torch.tensor(cv.kernel_size).prod())))
+            scratch.want_partials(n, size[0] * size[1] * size[2], cv.out_channels)
+            scratch.want_ws(g)
+        c_last = convs[-1].out_channels
+        P_last = size[0] * size[1] * size[2]
+        if lin1.in_features != P_last * c_last:
+            raise ValueError(f"Linear.in_features {lin1.in_features} != {c_last}*{P_last} for patches {spatial}")
+        # Linear(F, 64) as a conv whose kernel spans the last feature map (packing realises the flatten order)
+        self.g_l1 = ConvGeom(n, tuple(size), c_last, lin1.out_features, tuple(size), (1, 1, 1), (0, 0, 0))
+        self.g_l2 = ConvGeom(n, (1, 1, 1), lin1.out_features, 1, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+        self.r_l1 = store.register_conv(lin1, cout=lin1.out_features, cin=c_last, taps=P_last, tco=True)
+        # its data gradient as ONE GEMM: (P x 64) * (64 x taps*C) -> the channels-last gradient of the last map
+        self.g_l1_bwd = ConvGeom(n, (1, 1, 1), lin1.out_features, P_last * c_last, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+        self.r_l2 = store.register_conv(lin2, cout=1, cin=lin1.out_features, taps=1)
+        scratch.want_ws(self.g_l1)
+        scratch.want_ws(self.g_l2)
+        scratch.alloc()
+        self.scratch = scratch
+        part, ws = scratch.partials, scratch.ws
+        self.h = E(n, 1, 1, 1, lin1.out_features)
+        self.logit, self.prob = E(n, 1, 1, 1, 1), E(n)
+        self.splitk_ws = E(max(ops.conv_splitk_workspace(self.g_l1) // 4, 4))
+        L = lib()
+        self.lrelu = lambda nb: nb.prologue(ACT_LEAKY, 0.2, None)
+        f = self.fwd = Program()
+        store.emit_pack(f)
+        src, pro = self.x_in, None
+        for i, cv in enumerate(convs):
+            emit_conv_fwd_norm(f, self.geoms[i], src, store.wp(self.recs[i]), cv.bias, self.zs[i], self.nbs[i], bns[i],
+                               part, pro=pro)
+            src, pro = self.zs[i], self.lrelu(self.nbs[i])
+        gc1, pc = self.g_l1.c(), pro.c()
+        f.add("conv_forward_splitk", L.mpgan_conv_forward_splitk, C.byref(gc1), self.zs[-1].data_ptr(), _ld(self.zs[-1]),
+              store.wp(self.r_l1).data_ptr(), lin1.bias.data_ptr(), C.byref(pc), self.splitk_ws.data_ptr(),
+              self.splitk_ws.numel() * 4, self.h.data_ptr(), _ld(self.h), keep=(gc1, pc, pro),
+              tag=("gather_conv_pipe_kernel<splitK>", 2.0 * conv_macs(self.g_l1)))
+        emit_conv_fwd(f, self.g_l2, self.h, store.wp(self.r_l2), lin2.bias, self.logit)
+        f.add("sigmoid_forward", L.mpgan_sigmoid_forward, self.logit.data_ptr(), n, self.prob.data_ptr())
+        self.busy = False
+        self.g_x = None
+        self._bwd_cache = {}
+        if not want_backward:
+            return
+        self.g_prob = E(n)
+        self.dlogit = E(n, 1, 1, 1, 1)
+        self.dh = E(n, 1, 1, 1, lin1.out_features)
+        self.gas = [E(*z.shape) for z in self.zs]
+        # gradients arriving through the perceptual taps of the three head tensors (zero unless a
+        # perceptual loss deposited them) and the per-layer (z, y, a) coefficients
+        self.tap_g_h, self.tap_g_logit, self.tap_g_prob = Z(*self.h.shape), Z(n), Z(n)
+        self.coef = [Z(4) for _ in convs]
+        if want_input_grad:
+            self.g_x = E(n, *dhw, 1)
+
+    def backward_program(self, peer: Optional["PatchDiscPlan"]) -> Program:
+        key = id(peer) if peer is not None else 0
+        if key in self._bwd_cache:
+            return self._bwd_cache[key]
+        store, L = self.store, lib()
+        part, ws = self.scratch.partials, self.scratch.ws
+        gv = store.grad_view if self.want_param_grads else (lambda p: None)
+        b = Program()
+        n = self.n
+        # sigmoid: dlogit = (g_prob + tap_prob) * p(1-p) + tap_logit
+        b.add("axpby", L.mpgan_axpby, self.g_prob.data_ptr(), 1.0, self.tap_g_prob.data_ptr(), 1.0, n,
+              self.g_prob.data_ptr())
+        b.add("sigmoid_backward", L.mpgan_sigmoid_backward, self.g_prob.data_ptr(), self.prob.data_ptr(), n,
+              self.dlogit.data_ptr())
+        b.add("axpby", L.mpgan_axpby, self.dlogit.data_ptr(), 1.0, self.tap_g_logit.data_ptr(), 1.0, n,
+              self.dlogit.data_ptr())
+        if self.want_param_grads:
+            emit_conv_wgrad(b, self.g_l2, self.h, self.dlogit, gv(self.lin2.weight), ws, dbias=gv(self.lin2.bias))
+        emit_conv_dgrad(b, self.g_l2, self.dlogit, store.wp_bwd(self.r_l2), self.dh, resid=self.tap_g_h)
+        pro4 = self.lrelu(self.nbs[-1])
+        if self.want_param_grads:
+            emit_conv_wgrad(b, self.g_l1, self.zs[-1], self.dh, gv(self.lin1.weight), ws, pro=pro4,
+                            dbias=gv(self.lin1.bias))
+        emit_conv_fwd(b, self.g_l1_bwd, self.dh, store.wp_tco(self.r_l1), None,
+                      self.gas[-1].view(n, 1, 1, 1, -1))
+        for i in range(len(self.convs) - 1, -1, -1):
+            pr = None
+            if peer is not None:
+                pr = ops.PeerTaps(peer.zs[i], peer.nbs[i].scale, peer.nbs[i].shift, self.coef[i])
+            emit_norm_bwd(b, self.gas[i], self.zs[i], self.nbs[i], self.lrelu(self.nbs[i]), self.gas[i], part,
+                          gv(self.bns[i].weight), gv(self.bns[i].bias), None, peer=pr)
+            src = self.zs[i - 1] if i > 0 else self.x_in
+            pro_in = self.lrelu(self.nbs[i - 1]) if i > 0 else None
+            if self.want_param_grads:
+                emit_conv_wgrad(b, self.geoms[i], src, self.gas[i], gv(self.convs[i].weight), ws, pro=pro_in,
+                                dbias=gv(self.convs[i].bias))
+            if i > 0:
+                emit_conv_dgrad(b, self.geoms[i], self.gas[i], store.wp_bwd(self.recs[i]), self.gas[i - 1])
+            elif self.want_input_grad:
+                emit_conv_dgrad(b, self.geoms[0], self.gas[0], store.wp_bwd(self.recs[0]), self.g_x)
+        self._bwd_cache[key] = b
+        return b
+
+    def clear_taps(self):
+        if hasattr(self, "tap_g_h"):
+            self.tap_g_h.zero_()
+            self.tap_g_logit.zero_()
+            self.tap_g_prob.zero_()
+        self.peer = None

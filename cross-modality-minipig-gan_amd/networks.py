@@ -321,3 +321,133 @@ class Discriminator(_EngineModule):
         store = self.store
         self._anchor.requires_grad_(torch.is_grad_enabled() and self._params_require_grad())
         return _DiscFn.apply(img.contiguous(), self._anchor, self)
+
+
+# --------------------------------------------------------------------------
+# variant B: patch discriminator with perceptual taps (test_runs/GAN.py:136-198)
+# --------------------------------------------------------------------------
+class TapSet:
+    """The 16 activation taps of one PatchDiscriminator pass.  The reference returns
+    16 cloned tensors; here they stay implicit (raw conv outputs + norm vectors inside the
+    plan) and `perceptual_loss` evaluates their L1 terms and gradients from those.
+    `handle` is the autograd edge standing for all of them."""
+
+    KEYS = tuple(range(16))
+
+    def __init__(self, handle, lease):
+        self.handle, self.lease = handle, lease
+
+    @property
+    def plan(self):
+        return self.lease.plan
+
+    def materialize(self, key: int) -> torch.Tensor:
+        """The tap as the reference would hold it (NC(D)HW, detached) -- for inspection / tests."""
+        plan, dims = self.plan, self.plan.dims
+        n = plan.n
+        if key < 12:
+            i, kind = divmod(key, 3)
+            z = plan.zs[i]
+            if kind == 0:
+                t = z
+            else:
+                pro = plan.lrelu(plan.nbs[i]) if kind == 2 else plan.nbs[i].prologue(ops.ACT_NONE)
+                t = torch.empty_like(z)
+                ops.norm_act_add(z, pro, None, None, t)
+            t = t.permute(0, 4, 1, 2, 3)
+            return (t.squeeze(2) if dims == 2 else t).contiguous()
+        if key == 12:
+            return self.materialize(11).flatten(1)
+        if key == 13:
+            return plan.h.reshape(n, -1).clone()
+        if key == 14:
+            return plan.logit.reshape(n, 1).clone()
+        return plan.prob.reshape(n, 1).clone()
+
+
+class TapDict(dict):
+    """dict[int -> TapSet] with the reference's 16 keys (all values are the same TapSet)."""
+
+    def __init__(self, tapset: TapSet):
+        super().__init__({k: tapset for k in TapSet.KEYS})
+        self.tapset = tapset
+
+
+class _PatchDiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, disc):
+        want_in, want_par = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1])
+        need_bwd = want_in or want_par
+        spatial = _spatial(x, disc.dimensions)
+        n = x.shape[0]
+        store = disc.store
+        from .engine import PatchDiscPlan
+        key = ("patch", n, spatial, need_bwd, want_in, want_par)
+        plan = disc._acquire(key, lambda: PatchDiscPlan(disc, store, n, spatial, want_backward=need_bwd,
+                                                        want_input_grad=want_in, want_param_grads=want_par))
+        lease = _Lease(plan)
+        plan.clear_taps()
+        plan.x_in.view(-1).copy_(x.reshape(-1))
+        plan.fwd.run()
+        prob = plan.prob.view(n, 1).clone()
+        handle = torch.zeros(1, device=x.device)
+        ctx.lease = lease
+        ctx.shape = x.shape
+        ctx.need_bwd = need_bwd
+        disc._last_lease = lease
+        if want_par:
+            store.attach_grads()
+        return prob, handle
+
+    @staticmethod
+    def backward(ctx, gprob, ghandle):
+        plan = ctx.lease.plan
+        if gprob is None:
+            plan.g_prob.zero_()
+        else:
+            plan.g_prob.copy_(gprob.reshape(-1))
+        plan.backward_program(getattr(plan, "peer", None)).run()
+        gx = plan.g_x.view(ctx.shape).clone() if ctx.needs_input_grad[0] else None
+        plan.peer = None
+        plan.peer_lease = None
+        ctx.lease.release()
+        return gx, None, None
+
+
+class PatchDiscriminator(_EngineModule):
+    """test_runs/GAN.py:136-198: returns (validity, perceptual_dict)."""
+
+    def __init__(self, img_shape, use_perceptual=True, *, dimensions=3, patch=16, device=None):
+        super().__init__()
+        self.use_perceptual = use_perceptual
+        self.img_shape = img_shape
+        self.dimensions = dimensions
+        Cv, Bn = _CONV[dimensions], _BN[dimensions]
+        self.model_conv = nn.Sequential(
+            Cv(1, 64, 3, 1), Bn(64), nn.LeakyReLU(0.2, inplace=True),
+            Cv(64, 128, 3, 1), Bn(128), nn.LeakyReLU(0.2, inplace=True),
+            Cv(128, 256, 3, 1), Bn(256), nn.LeakyReLU(0.2, inplace=True),
+            Cv(256, 512, 3, 1), Bn(512), nn.LeakyReLU(0.2, inplace=True))
+        last = patch - 8
+        if last < 1:
+            raise ValueError("patch too small")
+        self.model_linear = nn.Sequential(nn.Flatten(), nn.Linear(512 * last ** dimensions, 64), nn.Linear(64, 1),
+                                          nn.Sigmoid())
+        self._last_lease = None
+        if device is not None:
+            self.to(device)
+
+    def _register_extra(self, store):
+        lin1, lin2 = self.model_linear[1], self.model_linear[2]
+        store.register_conv(lin1, cout=lin1.out_features, cin=512, taps=lin1.in_features // 512, tco=True)
+        store.register_conv(lin2, cout=1, cin=lin1.out_features, taps=1)
+
+    def forward(self, x):
+        if not self.training:
+            raise NotImplementedError("eval-mode discriminator is not built (the reference never evaluates D)")
+        store = self.store
+        self._anchor.requires_grad_(torch.is_grad_enabled() and self._params_require_grad())
+        prob, handle = _PatchDiscFn.apply(x.contiguous(), self._anchor, self)
+        taps = TapDict(TapSet(handle, self._last_lease)) if self.use_perceptual else {}
+        self._last_lease = None
+        return prob, taps

@@ -13,7 +13,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from ._lib import ConvGeomC, PrologueC, check, lib
+from ._lib import ConvGeomC, PeerTapsC, PrologueC, check, lib
 
 ACT_NONE = 0
 ACT_LEAKY = 1
@@ -115,6 +115,28 @@ class Prologue:
 
 def _pro(p: Optional[Prologue]):
     return None if p is None else C.byref(p.c())
+
+
+@dataclass
+class PeerTaps:
+    """The other pass of a perceptual-loss pair (see mpgan_peer_taps)."""
+    z: torch.Tensor
+    scale: torch.Tensor
+    shift: torch.Tensor
+    coef: torch.Tensor  # device float[3]
+
+    def c(self) -> PeerTapsC:
+        t = PeerTapsC()
+        t.z_peer = self.z.data_ptr()
+        t.ld_peer = _cl(self.z, "peer z")[2]
+        t.scale_peer = self.scale.data_ptr()
+        t.shift_peer = self.shift.data_ptr()
+        t.coef = self.coef.data_ptr()
+        return t
+
+
+def _peer(t: Optional[PeerTaps]):
+    return None if t is None else C.byref(t.c())
 
 
 def _check_in_out(g: ConvGeom, x: torch.Tensor, y: torch.Tensor, what: str):
@@ -225,7 +247,7 @@ def norm_act_add(z, pz: Optional[Prologue], r, pr: Optional[Prologue], out, *, t
     return out
 
 
-def norm_bwd_reduce(g, z, p: Prologue, mean, invstd, partials):
+def norm_bwd_reduce(g, z, p: Prologue, mean, invstd, partials, peer: Optional[PeerTaps] = None):
     n, P, ldz = _cl(z, "norm_bwd_reduce z")
     _, _, ldg = _cl(g, "norm_bwd_reduce g")
     if g.shape != z.shape:
@@ -234,7 +256,8 @@ def norm_bwd_reduce(g, z, p: Prologue, mean, invstd, partials):
     if partials.numel() < n * stats_chunks(P, c) * 3 * c + c:
         raise ValueError("norm_bwd_reduce: partials too small (need n*chunks*3*c + c floats)")
     check(lib().mpgan_norm_bwd_reduce(g.data_ptr(), ldg, z.data_ptr(), ldz, _pro(p), mean.data_ptr(),
-                                      invstd.data_ptr(), n, P, c, partials.data_ptr(), _stream()), "norm_bwd_reduce")
+                                      invstd.data_ptr(), _peer(peer), n, P, c, partials.data_ptr(), _stream()),
+          "norm_bwd_reduce")
 
 
 def norm_bwd_finalize(partials, n, chunks, c, P, instance, dgamma, dbeta, dslope, c1, c2):
@@ -242,16 +265,52 @@ def norm_bwd_finalize(partials, n, chunks, c, P, instance, dgamma, dbeta, dslope
                                         _ptr(dslope), c1.data_ptr(), c2.data_ptr(), _stream()), "norm_bwd_finalize")
 
 
-def norm_bwd_apply(g, z, p: Prologue, mean, invstd, c1, c2, dz):
+def norm_bwd_apply(g, z, p: Prologue, mean, invstd, c1, c2, dz, peer: Optional[PeerTaps] = None):
     n, P, ldz = _cl(z, "norm_bwd_apply z")
     _, _, ldg = _cl(g, "norm_bwd_apply g")
     _, _, lddz = _cl(dz, "norm_bwd_apply dz")
     if g.shape != z.shape or dz.shape != z.shape:
         raise ValueError("norm_bwd_apply: shape mismatch")
     check(lib().mpgan_norm_bwd_apply(g.data_ptr(), ldg, z.data_ptr(), ldz, _pro(p), mean.data_ptr(),
-                                     invstd.data_ptr(), c1.data_ptr(), c2.data_ptr(), n, P, z.shape[-1],
+                                     invstd.data_ptr(), c1.data_ptr(), c2.data_ptr(), _peer(peer), n, P, z.shape[-1],
                                      dz.data_ptr(), lddz, _stream()), "norm_bwd_apply")
     return dz
+
+
+def tap_l1_partials() -> int:
+    return int(lib().mpgan_tap_l1_partials())
+
+
+def tap_l1(za, pa: Prologue, zb, pb: Prologue, partials, out3):
+    """out3 = mean |z_a-z_b|, |y_a-y_b|, |a_a-a_b| of one conv+BN+act layer of two passes."""
+    n, P, lda = _cl(za, "tap_l1 a")
+    _, _, ldb = _cl(zb, "tap_l1 b")
+    if za.shape != zb.shape:
+        raise ValueError("tap_l1: shape mismatch")
+    check(lib().mpgan_tap_l1(za.data_ptr(), lda, _pro(pa), zb.data_ptr(), ldb, _pro(pb), n * P, za.shape[-1],
+                             partials.data_ptr(), out3.data_ptr(), _stream()), "tap_l1")
+    return out3
+
+
+def conv_splitk_workspace(g: ConvGeom) -> int:
+    gc = g.c()
+    return int(lib().mpgan_conv_splitk_workspace(C.byref(gc)))
+
+
+def conv_forward_splitk(g: ConvGeom, x, w_packed, bias, y, workspace, *, pro: Optional[Prologue] = None):
+    _check_in_out(g, x, y, "conv_forward_splitk")
+    _, _, ldx = _cl(x, "conv_forward_splitk x")
+    _, _, ldy = _cl(y, "conv_forward_splitk y")
+    gc = g.c()
+    check(lib().mpgan_conv_forward_splitk(C.byref(gc), x.data_ptr(), ldx, w_packed.data_ptr(), _ptr(bias), _pro(pro),
+                                          workspace.data_ptr(), workspace.numel() * 4, y.data_ptr(), ldy, _stream()),
+          "conv_forward_splitk")
+    return y
+
+
+def sigmoid_forward(logit, prob):
+    check(lib().mpgan_sigmoid_forward(logit.data_ptr(), logit.numel(), prob.data_ptr(), _stream()), "sigmoid_forward")
+    return prob
 
 
 def reduce_partials(partials, rows, row_stride, c, out, beta=0.0):

@@ -89,6 +89,15 @@ int mpgan_conv_forward(const mpgan_conv_geom* g, const float* x, int32_t ldx,
                        float* stats_partials,
                        float* y, int32_t ldy, void* stream);
 
+/* The same forward with the K axis split over blocks, for output grids too small to fill
+ * the chip (variant B's Linear(512*8^3 -> 64) expressed as a conv whose kernel spans the
+ * 8^3 grid, test_runs/GAN.py:176-181).  workspace >= mpgan_conv_splitk_workspace() bytes
+ * (0 = no split needed: plain forward is used). */
+int64_t mpgan_conv_splitk_workspace(const mpgan_conv_geom* g);
+int mpgan_conv_forward_splitk(const mpgan_conv_geom* g, const float* x, int32_t ldx,
+                              const float* w_packed, const float* bias, const mpgan_prologue* pro,
+                              void* workspace, int64_t workspace_bytes, float* y, int32_t ldy, void* stream);
+
 /* dx = conv_backward_data(dy) [+ resid]: gradient w.r.t. the conv input
  * (for g->transposed: gradient w.r.t. the transposed conv's input).
  * `w_packed_bwd` is the packed weight for the backward direction
@@ -119,9 +128,30 @@ int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float* x, int32_t
 
 /* Repack every conv / linear weight of a network in ONE launch.
  * table: device int64 [n_entries][8] = {src_off, dst_off, cout, cin, taps,
- * transposed, for_dgrad, k_spatial_code}; offsets in floats into `flat_params` / `packed`. */
+ * transposed, layout, 0}; offsets in floats into `flat_params` / `packed`;
+ * layout 0 = [cout][tap][cin] (forward), 1 = [cin][tap][cout] (backward-data),
+ * 2 = [tap][cin][cout] (backward-data of a Linear expressed as a whole-grid conv). */
 int mpgan_pack_weights(const float* flat_params, float* packed, const int64_t* table,
                        int32_t n_entries, int64_t max_elems, void* stream);
+
+/* Perceptual-loss taps (variant B, test_runs/GAN.py:183-198,288-298): the discriminator
+ * returns clones of every intermediate; the G loss adds sum_k mean|real_k - fake_k| / numel_k.
+ * For a conv -> BatchNorm -> LeakyReLU layer the three taps (conv out z, norm out y,
+ * activation a) are never materialised: their L1 terms and gradients are evaluated from the
+ * two passes' raw conv outputs.  coef = device float[3]: d(loss)/d|tap| for (z, y, a). */
+typedef struct {
+  const float* z_peer;      /* the other pass's raw conv output, same shape */
+  int32_t ld_peer;
+  const float* scale_peer;  /* its norm scale / shift (per channel) */
+  const float* shift_peer;
+  const float* coef;        /* null => no peer */
+} mpgan_peer_taps;
+
+/* out3 = (mean|z_a-z_b|, mean|y_a-y_b|, mean|a_a-a_b|); partials >= mpgan_tap_l1_partials() floats */
+int32_t mpgan_tap_l1_partials(void);
+int mpgan_tap_l1(const float* za, int32_t lda, const mpgan_prologue* pa,
+                 const float* zb, int32_t ldb, const mpgan_prologue* pb,
+                 int64_t rows, int32_t c, float* partials, float* out3, void* stream);
 
 /* ---- normalisation (BatchNorm training mode / InstanceNorm) -------------- */
 
@@ -163,6 +193,7 @@ int mpgan_norm_act_add(const float* z, int32_t ldz, const mpgan_prologue* pz,
  * when tanh_y != null. */
 int mpgan_norm_bwd_reduce(const float* g, int32_t ldg, const float* z, int32_t ldz,
                           const mpgan_prologue* p, const float* mean, const float* invstd,
+                          const mpgan_peer_taps* peer /* nullable */,
                           int32_t n, int64_t pixels_per_sample, int32_t c,
                           float* partials, void* stream);
 int mpgan_norm_bwd_finalize(const float* partials, int32_t n, int32_t chunks, int32_t c,
@@ -172,6 +203,7 @@ int mpgan_norm_bwd_finalize(const float* partials, int32_t n, int32_t chunks, in
 int mpgan_norm_bwd_apply(const float* g, int32_t ldg, const float* z, int32_t ldz,
                          const mpgan_prologue* p, const float* mean, const float* invstd,
                          const float* c1, const float* c2,
+                         const mpgan_peer_taps* peer /* nullable */,
                          int32_t n, int64_t pixels_per_sample, int32_t c,
                          float* dz, int32_t lddz, void* stream);
 
@@ -222,6 +254,7 @@ int mpgan_sigmoid_bce(const float* logit, int32_t n, float target, float loss_sc
 int mpgan_bce_forward(const float* prob, const float* target, int32_t n, float* loss, void* stream);
 int mpgan_bce_backward(const float* prob, const float* target, int32_t n, const float* gout,
                        float* dprob, void* stream);
+int mpgan_sigmoid_forward(const float* logit, int32_t n, float* prob, void* stream);
 int mpgan_sigmoid_backward(const float* dprob, const float* prob, int32_t n, float* dlogit, void* stream);
 /* y = x * (*scalar)  (scalar on the device: an upstream autograd gradient) */
 int mpgan_scale_by_device_scalar(const float* x, const float* scalar, int64_t numel, float* y, void* stream);

@@ -356,6 +356,76 @@ class GAN(nn.Module):
         return dict(self.logged)
 
 
+class PatchGAN(nn.Module):
+    """Variant B trainer, test_runs/GAN.py:236-464 without Lightning/MONAI: G forward
+    first (:308), the same random 16^3 crops of fake and real (:313-337), then the G
+    branch (perceptual + BCE + L1 on patches, :340-390) or the D branch (:393-438)."""
+
+    def __init__(self, img_shape, *, dimensions=3, n_unet_blocks=4, channels=(32, 64, 128, 256),
+                 strides=(2, 2, 2, 2), lr=2e-4, b1=0.5, b2=0.999, one_sided_label_value=0.9, roi=16,
+                 num_samples=128, crop_seed=None, use_perceptual=True):
+        super().__init__()
+        self.hparams = dict(lr=lr, b1=b1, b2=b2, one_sided_label_value=one_sided_label_value)
+        self.generator = CasNetGenerator(img_shape, n_unet_blocks, dimensions=dimensions, channels=channels,
+                                         strides=strides)
+        self.discriminator = PatchDiscriminator(img_shape, use_perceptual=use_perceptual, dimensions=dimensions,
+                                                patch=roi)
+        self.roi, self.num_samples = roi, num_samples
+        self.R = np.random.RandomState(crop_seed)
+        self.logged: Dict[str, float] = {}
+
+    def forward(self, x):
+        return self.generator(x)
+
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        t1w, t2w = batch["t1w"], batch["t2w"]
+        gen = self(t1w)
+        corners = draw_corners(self.R, gen.shape[0], self.num_samples, tuple(gen.shape[2:]), self.roi)
+        fake_p = crop_patches(gen, corners, self.roi)
+        real_p = crop_patches(t2w, corners, self.roi)
+        if optimizer_idx == 0:
+            valid = torch.ones(real_p.shape[0], 1).type_as(real_p)
+            out_fake, acts_fake = self.discriminator(fake_p)
+            _, acts_real = self.discriminator(real_p)
+            g_adv = adversarial_loss(out_fake, valid)
+            g_rec = reconstruction_loss(fake_p, real_p)
+            g_loss = g_adv + g_rec
+            self.logged.update(g_adv_loss=g_adv.item(), g_recon_loss=g_rec.item())
+            if self.discriminator.use_perceptual:
+                g_perc = perceptual_loss(acts_fake, acts_real)
+                g_loss = g_loss + g_perc
+                self.logged.update(g_perceptual_loss=g_perc.item())
+            self.logged.update(g_loss=g_loss.item())
+            return g_loss
+        if optimizer_idx == 1:
+            valid = (torch.ones(real_p.shape[0], 1) * self.hparams["one_sided_label_value"]).type_as(real_p)
+            real_loss = adversarial_loss(self.discriminator(real_p)[0], valid)
+            fake = torch.zeros(fake_p.shape[0], 1).type_as(fake_p)
+            fake_loss = adversarial_loss(self.discriminator(fake_p)[0], fake)
+            d_loss = (real_loss + fake_loss) / 2
+            self.logged.update(d_loss=d_loss.item())
+            return d_loss
+
+    def configure_optimizers(self):
+        h = self.hparams
+        return [torch.optim.Adam(self.generator.parameters(), lr=h["lr"], betas=(h["b1"], h["b2"])),
+                torch.optim.Adam(self.discriminator.parameters(), lr=h["lr"], betas=(h["b1"], h["b2"]))], []
+
+    def step(self, batch, batch_idx, optimizers):
+        nets = [self.generator, self.discriminator]
+        for idx, opt in enumerate(optimizers):
+            other = nets[1 - idx]
+            for p in other.parameters():
+                p.requires_grad_(False)
+            opt.zero_grad()
+            loss = self.training_step(batch, batch_idx, idx)
+            loss.backward()
+            opt.step()
+            for p in other.parameters():
+                p.requires_grad_(True)
+        return dict(self.logged)
+
+
 # --------------------------------------------------------------------------
 # deterministic closed-form weights (fixtures hold inputs/outputs only)
 # --------------------------------------------------------------------------

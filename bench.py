@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="slices per GPU (C3/C4: 16)")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dims", type=int, default=2, choices=(2, 3),
+                    help="2: BASELINE configs C3/C4 (256x256 slices); 3: config C5's shape (the reference's own "
+                         "3-D graph, e.g. --dims 3 --size 128 --batch 4; fp32 -- bf16 storage is not built)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-6,
                     help="Adam lr for both nets.  The reference's 5e-4 drives the 952,576-input Linear head into "
@@ -112,9 +115,9 @@ def main():
     from mpgan_amd.gan import GAN
     from mpgan_amd.parallel import DataParallelGAN
 
-    spatial = (args.size, args.size)
+    spatial = (args.size,) * args.dims
     torch.manual_seed(0)                           # torch default init, identical on every rank
-    gan = GAN(1, args.size, args.size, dimensions=2, device=dev, g_lr=args.lr, d_lr=args.lr)
+    gan = GAN(1, *spatial, dimensions=args.dims, device=dev, g_lr=args.lr, d_lr=args.lr)
     # With torch-default init the 952,576-input Linear saturates the sigmoid (BCE sits on its
     # -100 clamp, as in the reference's own checkpoints: g_loss=100.03, d_loss=45.00), which
     # makes every discriminator gradient exactly zero.  All-zero MFMA operands let the chip
@@ -125,6 +128,9 @@ def main():
     ddp = DataParallelGAN(gan)
     opts, _ = gan.configure_optimizers()
     batch = synthetic_batch(args.batch, spatial, rank, dev)
+    if args.dims == 3:      # keep the 3-D head (6,243,584 inputs at 128^3) out of saturation as well
+        with torch.no_grad():
+            gan.discriminator.model_linear[1].weight.mul_(0.4)
 
     def barrier():
         if world > 1:
@@ -171,24 +177,30 @@ def main():
                 gan.generator(batch["t1w"])
             torch.cuda.synchronize()
             g_fwd_ms = (time.perf_counter() - t1) / reps * 1e3
-        g_fwd_flops = 7.2423e9 * args.batch * (args.size / 256.0) ** 2
+        # algorithmic FLOPs per sample: 2-D 256^2: G 7.2423 GF, step 298.0 GF; 3-D 128^3: 145.131 GF, 16.64 TF
+        if args.dims == 2:
+            g_flops_sample, step_flops_sample = 7.2423e9 * (args.size / 256.0) ** 2, 298.0e9 * (args.size / 256.0) ** 2
+        else:
+            g_flops_sample, step_flops_sample = 145.131e9 * (args.size / 128.0) ** 3, 16.64e12 * (args.size / 128.0) ** 3
+        g_fwd_flops = g_flops_sample * args.batch
         out = {
-            "metric": "T1->T2 256x256 slices/sec (G+D step)", "value": world * args.batch * args.steps / dt,
-            "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": ("T1->T2 256x256 slices/sec (G+D step)" if args.dims == 2 else
+                       f"T1->T2 {args.size}^3 volumes/sec (G+D step)"),
+            "value": world * args.batch * args.steps / dt, "unit": "slices/s" if args.dims == 2 else "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C3: {args.size}x{args.size} bs{args.batch}/GPU full G+D adversarial step "
-                                   "(6-UNet CasNet G + conv D, BatchNorm, Adam x2)",
+            "config": {"workload": (f"C3: {args.size}x{args.size} bs{args.batch}/GPU" if args.dims == 2 else
+                                    f"C5 shape (fp32): {args.size}^3 bs{args.batch}/GPU") +
+                                   " full G+D adversarial step (6-UNet CasNet G + conv D, BatchNorm, Adam x2)",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "adam_lr": args.lr},
             "roofline": roofline,
-            "step_mfma_frac": (298.0e9 * args.batch * (args.size / 256.0) ** 2) / (dt / args.steps) / 1e12
-                              / PEAK_FP32_TFLOPS,
+            "step_mfma_frac": (step_flops_sample * args.batch) / (dt / args.steps) / 1e12 / PEAK_FP32_TFLOPS,
             "g_forward": {"ms": g_fwd_ms, "slices_per_s": args.batch / (g_fwd_ms * 1e-3),
                           "mfma_frac": g_fwd_flops / (g_fwd_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
             "losses": losses,
         }
         note(f"G forward {g_fwd_ms:.2f} ms")
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.dims == 2:
             out["cpu_baseline"] = cpu_baseline_leg(gan, spatial)
             note("cpu baseline done")
         print(json.dumps(out), flush=True)

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mpgan_stats_chunks": (_I, [_L, _I]),
     "mpgan_channel_stats": (_I, [_P, _I, _I, _L, _I, _P, _P]),
     "mpgan_norm_finalize": (_I, [_P, _I, _I, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mpgan_norm_from_running": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
     "mpgan_norm_act_add": (_I, [_P, _I, _PR, _P, _I, _PR, _I, _L, _I, _I, _P, _I, _P]),
     "mpgan_norm_bwd_reduce": (_I, [_P, _I, _P, _I, _PR, _P, _P, C.POINTER(PeerTapsC), _I, _L, _I, _P, _P]),
     "mpgan_tap_l1_partials": (_I, []),
@@ -71,6 +72,9 @@ SIGNATURES = {
     "mpgan_sigmoid_bce": (_I, [_P, _I, _F, _F, _P, _P, _P, _P]),
     "mpgan_l1_partials": (_I, []),
     "mpgan_l1_loss": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
+    "mpgan_metric_partials": (_I, []),
+    "mpgan_rescale_minmax": (_I, [_P, _L, _F, _F, _I, _P, _P, _P, _P]),
+    "mpgan_image_errors": (_I, [_P, _P, _L, _F, _P, _P, _P]),
     "mpgan_adam_step": (_I, [_P, _P, _P, _P, _L, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, _P]),
     "mpgan_patch_gather": (_I, [_P, _I, _I3, _P, _I, _I3, _P, _P]),
     "mpgan_patch_scatter_add": (_I, [_P, _I, _I3, _P, _I, _I3, _P, _P]),

@@ -34,6 +34,7 @@ struct WgradParams {
   int nsplit;
   long chunk;  // pixels per split (multiple of 32)
   int tiles_c, tiles_d;  // 1-D launch of tiles_c*tiles_d*nsplit blocks, XCD-remapped, column tile fastest
+  FastDiv fMx, fMy, fMz;
 };
 
 struct WBlockId { int tc, td, split; };
@@ -564,6 +565,100 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
   if (lane == 0) db[c] = beta != 0.f ? beta * db[c] + (float)s : (float)s;
 }
 
+// ---------------------------------------------------------------------------
+// Thin weight gradient: the gathered operand has ONE channel (Cin == 1 convs:
+// G down0, D conv1, the 1->1 conv; and the 32->1 transposed conv, whose gathered
+// operand is dy).  dW[c][t] = sum_m dense[m][c] * g[pix(m,t)] is an HBM-bound
+// reduction with C*T <= a few hundred outputs -- an MFMA tile would be >95 %
+// padding.  One thread = V channels x all taps, pixel lanes strided over the
+// chunk; LDS reduction over the lanes in fixed order; per-block partial slabs go
+// through the same deterministic slab reducer as the MFMA path.
+// ---------------------------------------------------------------------------
+template <int V, int T>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p) {
+  extern __shared__ float red[];                 // [PL][Cd*T + Cd]
+  const int CQ = (p.Cd + V - 1) / V;
+  const int PL = 256 / CQ;                       // pixel lanes
+  const int q = threadIdx.x % CQ, pl = threadIdx.x / CQ;
+  const int c = q * V;
+  const long M = (long)p.N * p.Mz * p.My * p.Mx;
+  const long mbeg = (long)blockIdx.x * p.chunk;
+  const long mend = mbeg + p.chunk < M ? mbeg + p.chunk : M;
+  float acc[T][V], bsum[V];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[t][e] = 0.f;
+#pragma unroll
+  for (int e = 0; e < V; ++e) bsum[e] = 0.f;
+  if (pl < PL) {
+    for (long m = mbeg + pl; m < mend; m += PL) {
+      unsigned r, umx, umy, umz;
+      fdivmod((unsigned)m, p.fMx, r, umx);
+      fdivmod(r, p.fMy, r, umy);
+      fdivmod(r, p.fMz, r, umz);
+      const int mx = (int)umx, my = (int)umy, mz = (int)umz, n = (int)r;
+      float d[V];
+      if (V == 4 && c + 3 < p.Cd) {
+        const float4 t4 = *reinterpret_cast<const float4*>(p.dense + m * p.ldd + c);
+        d[0] = t4.x; d[V > 1 ? 1 : 0] = t4.y; d[V > 2 ? 2 : 0] = t4.z; d[V > 3 ? 3 : 0] = t4.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = c + e < p.Cd ? p.dense[m * p.ldd + c + e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < V; ++e) bsum[e] += d[e];
+      const int bz = mz * p.sz - p.pz, by = my * p.sy - p.py, bx = mx * p.sx - p.px;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        constexpr int KX = T == 1 ? 1 : 3, KY = KX;       // host admits only 1, 3x3 and 3x3x3 kernels here
+        const int kx = t % KX, ky = (t / KX) % KY, kz = t / (KX * KY);   // constants after unrolling
+        const int iz = bz + kz, iy = by + ky, ix = bx + kx;
+        const bool ok = (unsigned)iz < (unsigned)p.Gz && (unsigned)iy < (unsigned)p.Gy && (unsigned)ix < (unsigned)p.Gx;
+        const long pix = (((long)n * p.Gz + iz) * p.Gy + iy) * p.Gx + ix;
+        const float g = ok ? p.gath[pix * p.ldg] : 0.f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[t][e] = fmaf(d[e], g, acc[t][e]);
+      }
+    }
+  }
+  const int W = p.Cd * T + p.Cd;                 // floats per lane row: [c][t] then bias[c]
+  if (pl < PL) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      if (c + e >= p.Cd) break;
+#pragma unroll
+      for (int t = 0; t < T; ++t) red[pl * W + (c + e) * T + t] = acc[t][e];
+      red[pl * W + p.Cd * T + c + e] = bsum[e];
+    }
+  }
+  __syncthreads();
+  float* out = p.partial + (long)blockIdx.x * p.Cd * T;
+  for (int i = threadIdx.x; i < W; i += 256) {
+    float s2 = 0.f;
+    for (int r = 0; r < PL; ++r) s2 += red[r * W + i];
+    if (i < p.Cd * T) out[i] = s2;
+    else if (p.bias_partial) p.bias_partial[(long)blockIdx.x * p.Cd + (i - p.Cd * T)] = s2;
+  }
+}
+
+struct ThinWgradPlan { int blocks; long chunk; bool ok; };
+static ThinWgradPlan plan_thin_wgrad(int Cd, int Cg, int T, long M, bool has_pro) {
+  ThinWgradPlan t;
+  t.ok = Cg == 1 && !has_pro && Cd <= 64 && (T == 1 || T == 9 || T == 27);   // kernel shape checked by the caller
+  long blocks = (M + 2047) / 2048;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  t.chunk = (M + blocks - 1) / blocks;
+  t.blocks = (int)((M + t.chunk - 1) / t.chunk);
+  // LDS: PL * (Cd*T + Cd) floats must fit 64 KiB
+  const int V = Cd % 4 == 0 ? 4 : 1;
+  const int CQ = (Cd + V - 1) / V;
+  const int PL = 256 / CQ;
+  if ((long)PL * (Cd * T + Cd) * 4 > 64 * 1024) t.ok = false;
+  return t;
+}
+
 struct WgradPlan {
   int BD, BG, nsplit, kw;
   long chunk;
@@ -681,7 +776,13 @@ extern "C" int64_t mpgan_conv_wgrad_workspace(const mpgan_conv_geom* g) {
   long M;
   wgrad_dims(g, Cd, Cg, T, M);
   WgradPlan pl = plan_wgrad(Cd, T * Cg, M);
-  return ((int64_t)pl.nsplit * pl.kw * Cd * T * Cg + (int64_t)pl.nsplit * Cd) * (int64_t)sizeof(float);
+  int64_t need = ((int64_t)pl.nsplit * pl.kw * Cd * T * Cg + (int64_t)pl.nsplit * Cd) * (int64_t)sizeof(float);
+  ThinWgradPlan tp = plan_thin_wgrad(Cd, Cg, T, M, false);
+  if (tp.ok) {
+    const int64_t tneed = ((int64_t)tp.blocks * Cd * T + (int64_t)tp.blocks * Cd) * (int64_t)sizeof(float);
+    if (tneed > need) need = tneed;
+  }
+  return need;
 }
 
 extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float* x, int32_t ldx,
@@ -727,6 +828,39 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
     p.pro = make_pro(nullptr);
     p.Mz = g->in_dhw[0]; p.My = g->in_dhw[1]; p.Mx = g->in_dhw[2];
     p.Gz = g->out_dhw[0]; p.Gy = g->out_dhw[1]; p.Gx = g->out_dhw[2];
+  }
+  p.fMx = make_fastdiv(p.Mx); p.fMy = make_fastdiv(p.My); p.fMz = make_fastdiv(p.Mz);
+  hipStream_t st0 = (hipStream_t)stream;
+  {
+    ThinWgradPlan tp = plan_thin_wgrad(Cd, Cg, T, M, p.pro.scale != nullptr);
+    const bool v4 = (p.Cd % 4 == 0) && (p.ldd % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.dense) & 15) == 0);
+    static const bool no_thin = getenv("MPGAN_DBG_NO_THIN") != nullptr;
+    const bool kshape = (T == 1) || (T == 9 && p.Kz == 1 && p.Ky == 3 && p.Kx == 3) ||
+                        (T == 27 && p.Kz == 3 && p.Ky == 3 && p.Kx == 3);
+    if (tp.ok && kshape && !no_thin) {
+      const int64_t tslab = (int64_t)tp.blocks * Cd * T;
+      MPGAN_CHECK_ARG(workspace_bytes >= (tslab + (int64_t)tp.blocks * Cd) * (int64_t)sizeof(float),
+                      "conv_backward_weight: workspace too small for the thin path");
+      p.chunk = tp.chunk;
+      p.bias_partial = dbias ? p.partial + tslab : nullptr;
+      const int V = v4 ? 4 : 1;
+      const int CQ = (Cd + V - 1) / V, PL = 256 / CQ;
+      const size_t smem = (size_t)PL * (Cd * T + Cd) * sizeof(float);
+      dim3 grid(tp.blocks);
+#define THIN_LAUNCH(VV, TT) hipLaunchKernelGGL((thin_wgrad_kernel<VV, TT>), grid, dim3(256), smem, st0, p)
+      if (v4) { if (T == 1) THIN_LAUNCH(4, 1); else if (T == 9) THIN_LAUNCH(4, 9); else THIN_LAUNCH(4, 27); }
+      else    { if (T == 1) THIN_LAUNCH(1, 1); else if (T == 9) THIN_LAUNCH(1, 9); else THIN_LAUNCH(1, 27); }
+#undef THIN_LAUNCH
+      int rc0 = check_launch("thin_wgrad");
+      if (rc0) return rc0;
+      const long total0 = (long)Cd * Cg * T;
+      int blocks0 = (int)((total0 + 31) / 32);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks0), dim3(256), 0, st0, p.partial, dw, tp.blocks, Cd, Cg, T, beta);
+      if (dbias)
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Cd + 3) / 4), dim3(256), 0, st0, p.bias_partial, tp.blocks,
+                           Cd, dbias, beta);
+      return check_launch("thin_wgrad_reduce");
+    }
   }
   const bool vd = (p.Cd % 4 == 0) && (p.ldd % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.dense) & 15) == 0);
   const bool vg = (p.Cg % 4 == 0) && (p.ldg % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.gath) & 15) == 0) &&

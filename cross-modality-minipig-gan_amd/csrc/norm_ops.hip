@@ -583,6 +583,32 @@ extern "C" int mpgan_copy_slice(const float* src, int32_t lds_, float* dst, int3
   return check_launch("copy_slice");
 }
 
+// eval-mode BatchNorm: scale/shift from the running statistics (inferrence.py:97-110 runs the
+// generator under .eval()); mean/invstd are filled too so the vectors are complete.
+__global__ void norm_from_running_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         const float* __restrict__ rm, const float* __restrict__ rv, float eps, int c,
+                                         float* __restrict__ scale, float* __restrict__ shift,
+                                         float* __restrict__ mean, float* __restrict__ invstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const float istd = 1.f / sqrtf(rv[i] + eps);
+  const float sc = (gamma ? gamma[i] : 1.f) * istd;
+  scale[i] = sc;
+  shift[i] = (beta ? beta[i] : 0.f) - rm[i] * sc;
+  mean[i] = rm[i];
+  invstd[i] = istd;
+}
+
+extern "C" int mpgan_norm_from_running(const float* gamma, const float* beta, const float* running_mean,
+                                       const float* running_var, float eps, int32_t c, float* scale, float* shift,
+                                       float* mean, float* invstd, void* stream) {
+  MPGAN_CHECK_ARG(running_mean && running_var && scale && shift && mean && invstd && c > 0,
+                  "norm_from_running: bad argument");
+  hipLaunchKernelGGL(norm_from_running_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, c, scale, shift, mean, invstd);
+  return check_launch("norm_from_running");
+}
+
 extern "C" int32_t mpgan_tap_l1_partials(void) { return 3 * 1024; }
 
 extern "C" int mpgan_tap_l1(const float* za, int32_t lda, const mpgan_prologue* pa, const float* zb, int32_t ldb,

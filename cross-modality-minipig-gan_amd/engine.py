@@ -342,10 +342,18 @@ def emit_norm_stats(prog, z, nb: NormBuf, norm_mod, partials, eps=1e-5, momentum
              keep=(norm_mod.weight, norm_mod.bias, rm, rv, nbt, nb))
 
 
-def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod, partials, pro=None):
+def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod, partials, pro=None, training=True):
     """Conv whose raw output feeds a norm layer: BatchNorm statistics come out of the
     conv's own epilogue when the MFMA kernel serves it (one finalize launch follows);
-    InstanceNorm and the thin VALU kernels take the separate statistics pass."""
+    InstanceNorm and the thin VALU kernels take the separate statistics pass.  In eval
+    mode BatchNorm's scale/shift come from the running statistics instead."""
+    if not training and not nb.instance:
+        emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro)
+        prog.add("norm_from_running", lib().mpgan_norm_from_running, _p(norm_mod.weight), _p(norm_mod.bias),
+                 norm_mod.running_mean.data_ptr(), norm_mod.running_var.data_ptr(), float(norm_mod.eps), g.cout,
+                 nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
+                 keep=(norm_mod.weight, norm_mod.bias, norm_mod.running_mean, norm_mod.running_var, nb))
+        return
     rows = 0 if nb.instance else ops.conv_stats_rows(g, pro is not None)
     if rows == 0:
         emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro)
@@ -451,8 +459,9 @@ class UNetPlan:
     """Forward/backward programs of one residual U-Net for a fixed input shape."""
 
     def __init__(self, unet, store: ParamStore, n: int, spatial: Sequence[int], x_in, y_out, *, tanh_out: bool,
-                 instance: bool, want_backward: bool, gbufs: Optional[dict], scratch: Scratch):
+                 instance: bool, want_backward: bool, gbufs: Optional[dict], scratch: Scratch, training: bool = True):
         self.unet, self.store, self.n = unet, store, n
+        self.training = training
         dims = unet.dimensions
         self.dims = dims
         dev = x_in.device
@@ -581,6 +590,7 @@ class UNetPlan:
         R, prelu_pro = a["R"], a["prelu_pro"]
         chans, L, sizes, cats = a["chans"], a["L"], a["sizes"], a["cats"]
         x_in, y_out = a["x_in"], a["y_out"]
+        tr = self.training
         bt = a["bottom"]
         wp, wpb = store.wp, store.wp_bwd
 
@@ -588,26 +598,27 @@ class UNetPlan:
         for l in range(L - 1):
             s = down_state[l]
             (cv0, N0, A0), (cv1, N1, A1) = s["ru"].units
-            emit_conv_fwd_norm(f, s["g0"], s["xin"], wp(R(cv0)), cv0.bias, s["z0"], s["nb0"], N0, part)
+            emit_conv_fwd_norm(f, s["g0"], s["xin"], wp(R(cv0)), cv0.bias, s["z0"], s["nb0"], N0, part, training=tr)
             emit_conv_fwd(f, s["gr"], s["xin"], wp(R(s["ru"].res)), s["ru"].res.bias, s["r"])
             emit_conv_fwd_norm(f, s["g1"], s["z0"], wp(R(cv1)), cv1.bias, s["z1"], s["nb1"], N1, part,
-                               pro=prelu_pro(s["nb0"], A0))
+                               pro=prelu_pro(s["nb0"], A0), training=tr)
             emit_norm_act_add(f, s["z1"], prelu_pro(s["nb1"], A1), s["r"], None, cats[l][..., :s["c"]])
         d_last = cats[L - 2][..., :bt["cb_in"]]
         emit_conv_fwd_norm(f, bt["gb0"], d_last, wp(R(bt["bc0"])), bt["bc0"].bias, bt["zb0"], bt["nbb0"], bt["BN0"],
-                           part)
+                           part, training=tr)
         emit_conv_fwd(f, bt["gbr"], d_last, wp(R(bt["res"])), bt["res"].bias, bt["rb"])
         emit_conv_fwd_norm(f, bt["gb1"], bt["zb0"], wp(R(bt["bc1"])), bt["bc1"].bias, bt["zb1"], bt["nbb1"],
-                           bt["BN1"], part, pro=prelu_pro(bt["nbb0"], bt["BA0"]))
+                           bt["BN1"], part, pro=prelu_pro(bt["nbb0"], bt["BA0"]), training=tr)
         emit_norm_act_add(f, bt["zb1"], prelu_pro(bt["nbb1"], bt["BA1"]), bt["rb"], None,
                           cats[L - 2][..., bt["cb_in"]:])
         for l in range(L - 2, -1, -1):
             u = up_state[l]
-            emit_conv_fwd_norm(f, u["gt"], cats[l], wp(R(u["ct"])), u["ct"].bias, u["zt"], u["nbt"], u["NT"], part)
+            emit_conv_fwd_norm(f, u["gt"], cats[l], wp(R(u["ct"])), u["ct"].bias, u["zt"], u["nbt"], u["NT"], part,
+                               training=tr)
             pt = prelu_pro(u["nbt"], u["AT"])
             if "zu" in u:
                 emit_conv_fwd_norm(f, u["gu"], u["zt"], wp(R(u["cu"])), u["cu"].bias, u["zu"], u["nbu"], u["NU"], part,
-                                   pro=pt)
+                                   pro=pt, training=tr)
                 dst = cats[l - 1][..., chans[l - 1]:] if l > 0 else y_out
                 emit_norm_act_add(f, u["zu"], prelu_pro(u["nbu"], u["AU"]), u["zt"], pt, dst,
                                   tanh=(a["tanh_out"] and l == 0))
@@ -688,7 +699,7 @@ class GeneratorPlan:
     """CasNet: chain of U-Nets + Tanh (code/GAN/GAN_final.py:92-122)."""
 
     def __init__(self, gen, store: ParamStore, n: int, spatial: Sequence[int], *, want_backward: bool,
-                 want_input_grad: bool, instance: bool):
+                 want_input_grad: bool, instance: bool, training: bool = True):
         unets = [m for m in gen.model if not isinstance(m, nn.Tanh)]
         dims = unets[0].dimensions
         dev = store.flat.device
@@ -730,7 +741,7 @@ class GeneratorPlan:
                 g["g_x"] = self.g_acts[u % 2] if (u > 0 or want_input_grad) else None
             self.unet_plans.append(UNetPlan(unet, store, n, spatial, self.acts[u], self.acts[u + 1],
                                             tanh_out=(u == nU - 1), instance=instance, want_backward=want_backward,
-                                            gbufs=g, scratch=self.scratch))
+                                            gbufs=g, scratch=self.scratch, training=training))
         self.scratch.alloc()
         for p in self.unet_plans:
             p.emit()

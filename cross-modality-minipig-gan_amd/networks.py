@@ -194,11 +194,11 @@ class _GenFn(torch.autograd.Function):
         need_bwd = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         spatial = _spatial(x, gen.dimensions)
         n = x.shape[0]
-        key = (n, spatial, need_bwd, bool(ctx.needs_input_grad[0]))
+        key = (n, spatial, need_bwd, bool(ctx.needs_input_grad[0]), gen.training)
         store = gen.store
         plan = gen._acquire(key, lambda: GeneratorPlan(gen, store, n, spatial, want_backward=need_bwd,
                                                       want_input_grad=bool(ctx.needs_input_grad[0]),
-                                                      instance=(gen.norm == "instance")))
+                                                      instance=(gen.norm == "instance"), training=gen.training))
         lease = _Lease(plan)
         plan.x_in.view(-1).copy_(x.reshape(-1))     # C == 1: NC(D)HW and channels-last coincide
         plan.fwd.run()
@@ -237,11 +237,14 @@ class CasNetGenerator(_EngineModule):
             self.to(device)
 
     def forward(self, x):
-        if not self.training:
-            raise NotImplementedError("eval-mode (running-statistics) inference is not built yet; the reference "
-                                      "trains with modules in train mode throughout (SURVEY.md Appendix B)")
+        """Train mode: batch statistics + running-stat updates (what the reference's training
+        loop runs).  Eval mode (code/GAN/inferrence.py:97-110,169-170: `.eval()`, `no_grad`):
+        BatchNorm uses its running statistics; no gradients are offered in eval mode."""
         store = self.store
-        self._anchor.requires_grad_(torch.is_grad_enabled() and self._params_require_grad())
+        if not self.training and torch.is_grad_enabled() and (x.requires_grad or self._params_require_grad()):
+            with torch.no_grad():
+                return _GenFn.apply(x.contiguous(), self._anchor.detach(), self)
+        self._anchor.requires_grad_(self.training and torch.is_grad_enabled() and self._params_require_grad())
         return _GenFn.apply(x.contiguous(), self._anchor, self)
 
 

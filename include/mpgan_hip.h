@@ -176,6 +176,12 @@ int mpgan_norm_finalize(const float* partials, int32_t n, int32_t chunks, int32_
                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
                         float* scale, float* shift, float* mean, float* invstd, void* stream);
 
+/* Eval-mode BatchNorm (module.eval(), code/GAN/inferrence.py:97-110,169-170): scale/shift
+ * from the running statistics; nothing is updated. */
+int mpgan_norm_from_running(const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, int32_t c,
+                            float* scale, float* shift, float* mean, float* invstd, void* stream);
+
 /* out = act(z*scale+shift) [+ r]   where r is either a plain tensor or itself
  * act(zr*scale_r+shift_r); optional tanh on the sum.  (ResidualUnit.forward's
  * "cx + res" and the generator's final Tanh, GAN_final.py:117.) */
@@ -264,6 +270,18 @@ int mpgan_scale_by_device_scalar(const float* x, const float* scalar, int64_t nu
 int32_t mpgan_l1_partials(void);
 int mpgan_l1_loss(const float* a, const float* b, int64_t numel, float grad_scale,
                   float* partials, float* loss, float* grad_a, void* stream);
+
+/* ---- evaluation metrics (next-row N2: inferrence.py:188-204, metrics.py:213-223,
+ *      psnr_ssim_metric.py:88-106) ---------------------------------------------------- */
+/* y = clip(round((x-min)/(max-min)*(b_max-b_min)+b_min)): ScaleIntensityRangePercentiles(0,100,0,255)
+ * + np.round as the inference script applies before writing / scoring; minmax2 receives (min,max).
+ * partials >= mpgan_metric_partials() floats. */
+int32_t mpgan_metric_partials(void);
+int mpgan_rescale_minmax(const float* x, int64_t numel, float b_min, float b_max, int32_t do_round,
+                         float* partials, float* minmax2, float* y, void* stream);
+/* out3 = (MAE, MSE, PSNR = 10 log10(data_range^2 / MSE)) between two tensors. */
+int mpgan_image_errors(const float* a, const float* b, int64_t numel, float data_range,
+                       float* partials, float* out3, void* stream);
 
 /* ---- optimiser ------------------------------------------------------------ */
 /* torch.optim.Adam.step over one flat buffer (GAN_final.py:306-307):

@@ -191,3 +191,29 @@ def test_missing_library_or_cpu_tensor_fails_loudly():
     g = CasNetGenerator((1, 32, 32), 1, dimensions=2)     # parameters on the CPU
     with pytest.raises(RuntimeError, match="no CPU path"):
         g(torch.zeros(1, 1, 32, 32))
+
+
+def test_generator_eval_mode_uses_running_statistics():
+    """inferrence.py:97-110,169-170: model.eval(), no_grad, batch 1 -- BatchNorm
+    normalises with its running statistics and updates nothing."""
+    R = _oracle()
+    from mpgan_amd.networks import CasNetGenerator
+    ref = R.CasNetGenerator((1, 64, 64), 2, dimensions=2)
+    R.closed_form_fill_(ref)
+    ours = CasNetGenerator((1, 64, 64), 2, dimensions=2)
+    ours.load_state_dict(ref.state_dict())
+    ours.cuda()
+    gen = torch.Generator().manual_seed(3)
+    warm = torch.rand(2, 1, 64, 64, generator=gen) * 2 - 1
+    ref.train(); ours.train()
+    with torch.no_grad():                       # one train-mode pass so running stats are non-trivial
+        ref(warm); ours(warm.cuda())
+    ref.eval(); ours.eval()
+    x = torch.rand(1, 1, 64, 64, generator=gen) * 2 - 1
+    before = {k: v.clone() for k, v in ours.state_dict().items()}
+    with torch.no_grad():
+        y_ref, y = ref(x), ours(x.cuda())
+    assert_close(y, y_ref, rtol=0, atol=5e-4, what="eval-mode G output")
+    assert (y.cpu() - y_ref).abs().mean().item() < 1e-4
+    after = ours.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before), "eval forward must not touch parameters or buffers"

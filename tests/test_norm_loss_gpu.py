@@ -200,3 +200,26 @@ def test_patch_gather_is_bit_exact_and_scatter_is_its_adjoint():
     dvol = torch.zeros_like(vol, device="cuda")
     ops.patch_scatter_add(gp.cuda(), c_dev, S, (roi,) * 3, dvol)
     assert_close(dvol.cpu(), v.grad, rtol=1e-6, what="scatter-add")
+
+
+def test_eval_metrics_match_numpy_restatement():
+    """inferrence.py:188-204 / psnr_ssim_metric.py:88-106 restated in numpy: min/max rescale to
+    0..255, round, MAE; MSE and PSNR with data_range 256."""
+    from mpgan_amd import metrics
+    gen = torch.Generator().manual_seed(2)
+    a = torch.rand(1, 1, 40, 48, 44, generator=gen) * 2 - 1
+    b = (a + 0.1 * torch.randn(a.shape, generator=gen)).clamp(-1, 1)
+
+    def rescale(x):
+        x = x.numpy().astype(np.float64)
+        lo, hi = np.percentile(x, 0), np.percentile(x, 100)
+        return np.round(np.clip((x - lo) / (hi - lo) * 255.0, 0, 255))
+
+    ra, rb = rescale(a), rescale(b)
+    got = metrics.rescale_0_255(a.cuda()).cpu().numpy()
+    assert (np.abs(got - ra) > 0).mean() < 1e-4          # .5 ties may round differently in fp32
+    s = metrics.score_volume(a.cuda(), b.cuda())
+    mse = ((ra - rb) ** 2).mean()
+    np.testing.assert_allclose(s["mae"].item(), np.abs(ra - rb).mean(), rtol=1e-3)
+    np.testing.assert_allclose(s["mse"].item(), mse, rtol=1e-3)
+    np.testing.assert_allclose(s["psnr"].item(), 10 * np.log10(256.0 ** 2 / mse), rtol=1e-4)

@@ -676,7 +676,7 @@ static WgradPlan plan_wgrad(int Cd, int NC, long M) {
   pl.tiles_d = (Cd + pl.BD - 1) / pl.BD;
   long tiles = (long)pl.tiles_c * pl.tiles_d;
   long want = (1024 + tiles - 1) / tiles;          // ~4 blocks per CU in total
-  long maxsplit = M / 1024;                        // at least 32 K-steps per split
+  long maxsplit = M / 256;                         // at least 8 K-steps per split (small maps need the blocks)
   if (maxsplit < 1) maxsplit = 1;
   long ns = want < maxsplit ? want : maxsplit;
   if (ns < 1) ns = 1;

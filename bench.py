@@ -93,6 +93,7 @@ def main():
                     help="2: BASELINE configs C3/C4 (256x256 slices); 3: config C5's shape (the reference's own "
                          "3-D graph, e.g. --dims 3 --size 128 --batch 4; fp32 -- bf16 storage is not built)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gfwd", action="store_true", help="skip the side measurement of the G forward (clean profiles)")
     ap.add_argument("--lr", type=float, default=1e-6,
                     help="Adam lr for both nets.  The reference's 5e-4 drives the 952,576-input Linear head into "
                          "sigmoid saturation within ONE step (its own checkpoints show g_loss=100.03, d_loss=45.00), "
@@ -167,16 +168,18 @@ def main():
                     "avg_launch_ms": summ["ms"] / max(summ["calls"], 1),
                     "avg_launch_gflop": summ["flops"] / max(summ["calls"], 1) / 1e9}
         # G-forward-only (config C2) on the side: not part of `value`
+        g_fwd_ms = float("nan")
         with torch.no_grad():
-            for _ in range(2):
+            for _ in range(0 if args.no_gfwd else 2):
                 gan.generator(batch["t1w"])
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            reps = 10
+            reps = 0 if args.no_gfwd else 10
             for _ in range(reps):
                 gan.generator(batch["t1w"])
             torch.cuda.synchronize()
-            g_fwd_ms = (time.perf_counter() - t1) / reps * 1e3
+            if reps:
+                g_fwd_ms = (time.perf_counter() - t1) / reps * 1e3
         # algorithmic FLOPs per sample: 2-D 256^2: G 7.2423 GF, step 298.0 GF; 3-D 128^3: 145.131 GF, 16.64 TF
         if args.dims == 2:
             g_flops_sample, step_flops_sample = 7.2423e9 * (args.size / 256.0) ** 2, 298.0e9 * (args.size / 256.0) ** 2

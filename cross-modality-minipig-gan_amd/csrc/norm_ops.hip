@@ -124,25 +124,71 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, Peer pr, ReduceGeom g,
                                                               float* __restrict__ partials) {
+  extern __shared__ float red[];  // [R][3][C]
   const float slope = pro_slope(p);
   const bool leaky = p.act == MPGAN_ACT_LEAKY;
   float cz = 0.f, cy = 0.f, ca = 0.f;
   if (pr.coef) { cz = pr.coef[0]; cy = pr.coef[1]; ca = pr.coef[2]; }
-  chunk_reduce<V, 3>(g, partials, [&](int n, int c, long row, float (&acc)[3][V]) {
-    float zv[V], gv[V];
-    Vec<V>::load(z + row * ldz + c, zv);
-    Vec<V>::load(gr + row * ldg + c, gv);
+  const int tid = threadIdx.x;
+  const int q = tid % g.CG, r = tid / g.CG;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int c = q * V;
+  const long per = (g.P + g.chunks - 1) / g.chunks;
+  const long beg = (long)chunk * per;
+  const long end = beg + per < g.P ? beg + per : g.P;
+  float acc[3][V];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[a][e] = 0.f;
+  if (r < g.R) {
+    // per-channel parameters of this thread's columns: loaded once, not per pixel
     const int si = n * p.n_stride + c;
+    float sc[V], sh[V], mu[V], is[V], psc[V], psh[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      const float y = zv[e] * p.scale[si + e] + p.shift[si + e];
-      const float zh = (zv[e] - mean[si + e]) * invstd[si + e];
-      const TapGrad t = tap_grad(gv[e], zv[e], y, leaky, slope, pr, row, c + e, c + e, cz, cy, ca);
-      acc[0][e] += t.gy;
-      acc[1][e] += t.gy * zh;
-      acc[2][e] += t.slope_term;
+      sc[e] = p.scale[si + e]; sh[e] = p.shift[si + e]; mu[e] = mean[si + e]; is[e] = invstd[si + e];
+      psc[e] = pr.coef ? pr.scale[c + e] : 0.f;
+      psh[e] = pr.coef ? pr.shift[c + e] : 0.f;
     }
-  });
+    for (long pix = beg + r; pix < end; pix += g.R) {
+      const long row = (long)n * g.P + pix;
+      float zv[V], gv[V], zp[V];
+      Vec<V>::load(z + row * ldz + c, zv);
+      Vec<V>::load(gr + row * ldg + c, gv);
+      if (pr.coef) Vec<V>::load(pr.z + row * pr.ld + c, zp);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float y = zv[e] * sc[e] + sh[e];
+        const float zh = (zv[e] - mu[e]) * is[e];
+        float ga = gv[e], gy_extra = 0.f;
+        if (pr.coef) {
+          const float yp = zp[e] * psc[e] + psh[e];
+          const float ap = (leaky && yp < 0.f) ? yp * slope : yp;
+          const float a = (leaky && y < 0.f) ? y * slope : y;
+          ga -= ca * sgn(ap - a);
+          gy_extra = -cy * sgn(yp - y);
+        }
+        const bool neg = leaky && y < 0.f;
+        const float gy = (neg ? ga * slope : ga) + gy_extra;
+        acc[0][e] += gy;
+        acc[1][e] += gy * zh;
+        acc[2][e] += neg ? ga * y : 0.f;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int e = 0; e < V; ++e) red[(r * 3 + a) * g.C + c + e] = acc[a][e];
+  }
+  __syncthreads();
+  float* out = partials + ((long)n * g.chunks + chunk) * 3 * g.C;
+  for (int i = tid; i < 3 * g.C; i += blockDim.x) {
+    float sm = 0.f;
+    for (int rr = 0; rr < g.R; ++rr) sm += red[rr * 3 * g.C + i];
+    out[i] = sm;
+  }
+  (void)cz;
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -281,36 +327,30 @@ __global__ __launch_bounds__(256) void norm_act_add_kernel(const float* __restri
                                                            const float* __restrict__ r, int ldr, Pro pr, long rows,
                                                            long P, int C, int tanh_out, float* __restrict__ out,
                                                            int ldo) {
-  const int CG = C / V;
-  const long total = rows * CG;
+  const int CG = C / V, R = 256 / CG;
+  const int q = threadIdx.x % CG, rr = threadIdx.x / CG;
+  if (rr >= R) return;
+  const int n = blockIdx.y, c = q * V;
   const float sz = pro_slope(pz), sr = pro_slope(pr);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long row = i / CG;
-    const int c = (int)(i - row * CG) * V;
-    const int n = (int)(row / P);
+  float zsc[V], zsh[V], rsc[V], rsh[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    zsc[e] = pz.scale ? pz.scale[n * pz.n_stride + c + e] : 1.f;
+    zsh[e] = pz.scale ? pz.shift[n * pz.n_stride + c + e] : 0.f;
+    rsc[e] = pr.scale ? pr.scale[n * pr.n_stride + c + e] : 1.f;
+    rsh[e] = pr.scale ? pr.shift[n * pr.n_stride + c + e] : 0.f;
+  }
+  for (long pix = (long)blockIdx.x * R + rr; pix < P; pix += (long)gridDim.x * R) {
+    const long row = (long)n * P + pix;
     float v[V], o[V];
     Vec<V>::load(z + row * ldz + c, v);
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      float y = v[e];
-      if (pz.scale) {
-        const int si = n * pz.n_stride + c + e;
-        y = act_apply(y * pz.scale[si] + pz.shift[si], pz.act, sz);
-      }
-      o[e] = y;
-    }
+    for (int e = 0; e < V; ++e) o[e] = pz.scale ? act_apply(v[e] * zsc[e] + zsh[e], pz.act, sz) : v[e];
     if (r) {
       float rv[V];
       Vec<V>::load(r + row * ldr + c, rv);
 #pragma unroll
-      for (int e = 0; e < V; ++e) {
-        float y = rv[e];
-        if (pr.scale) {
-          const int si = n * pr.n_stride + c + e;
-          y = act_apply(y * pr.scale[si] + pr.shift[si], pr.act, sr);
-        }
-        o[e] += y;
-      }
+      for (int e = 0; e < V; ++e) o[e] += pr.scale ? act_apply(rv[e] * rsc[e] + rsh[e], pr.act, sr) : rv[e];
     }
     if (tanh_out) {
 #pragma unroll
@@ -318,9 +358,11 @@ __global__ __launch_bounds__(256) void norm_act_add_kernel(const float* __restri
     }
     Vec<V>::store(out + row * ldo + c, o);
   }
+  (void)rows;
 }
 
 // gr and dz may alias (in-place): every element is read before it is written by the same thread.
+// Thread = fixed V columns (per-channel parameters hoisted), rows strided; grid = (row blocks, samples).
 template <int V>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* gr, int ldg,
                                                              const float* __restrict__ z, int ldz, Pro p,
@@ -329,29 +371,48 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* gr, in
                                                              const float* __restrict__ c1,
                                                              const float* __restrict__ c2, Peer pr, long rows, long P,
                                                              int C, float* dz, int lddz) {
-  const int CG = C / V;
-  const long total = rows * CG;
+  const int CG = C / V, R = 256 / CG;
+  const int q = threadIdx.x % CG, r = threadIdx.x / CG;
+  if (r >= R) return;
+  const int n = blockIdx.y, c = q * V;
   const float slope = pro_slope(p);
   const bool leaky = p.act == MPGAN_ACT_LEAKY;
   float cz = 0.f, cy = 0.f, ca = 0.f;
   if (pr.coef) { cz = pr.coef[0]; cy = pr.coef[1]; ca = pr.coef[2]; }
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long row = i / CG;
-    const int c = (int)(i - row * CG) * V;
-    const int n = (int)(row / P);
-    const int si = n * p.n_stride + c;
-    float zv[V], gv[V], o[V];
+  const int si = n * p.n_stride + c;
+  float sc[V], sh[V], mu[V], is[V], k1[V], k2[V], psc[V], psh[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    sc[e] = p.scale[si + e]; sh[e] = p.shift[si + e]; mu[e] = mean[si + e]; is[e] = invstd[si + e];
+    k1[e] = c1[si + e]; k2[e] = c2[si + e];
+    psc[e] = pr.coef ? pr.scale[c + e] : 0.f;
+    psh[e] = pr.coef ? pr.shift[c + e] : 0.f;
+  }
+  for (long pix = (long)blockIdx.x * R + r; pix < P; pix += (long)gridDim.x * R) {
+    const long row = (long)n * P + pix;
+    float zv[V], gv[V], zp[V], o[V];
     Vec<V>::load(z + row * ldz + c, zv);
     Vec<V>::load(gr + row * ldg + c, gv);
+    if (pr.coef) Vec<V>::load(pr.z + row * pr.ld + c, zp);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      const float y = zv[e] * p.scale[si + e] + p.shift[si + e];
-      const float zh = (zv[e] - mean[si + e]) * invstd[si + e];
-      const TapGrad t = tap_grad(gv[e], zv[e], y, leaky, slope, pr, row, c + e, c + e, cz, cy, ca);
-      o[e] = p.scale[si + e] * (t.gy - c1[si + e] - zh * c2[si + e]) + t.dz_extra;
+      const float y = zv[e] * sc[e] + sh[e];
+      const float zh = (zv[e] - mu[e]) * is[e];
+      float ga = gv[e], gy_extra = 0.f, dz_extra = 0.f;
+      if (pr.coef) {
+        const float yp = zp[e] * psc[e] + psh[e];
+        const float ap = (leaky && yp < 0.f) ? yp * slope : yp;
+        const float a = (leaky && y < 0.f) ? y * slope : y;
+        ga -= ca * sgn(ap - a);
+        gy_extra = -cy * sgn(yp - y);
+        dz_extra = -cz * sgn(zp[e] - zv[e]);
+      }
+      const float gy = ((leaky && y < 0.f) ? ga * slope : ga) + gy_extra;
+      o[e] = sc[e] * (gy - k1[e] - zh * k2[e]) + dz_extra;
     }
     Vec<V>::store(dz + row * lddz + c, o);
   }
+  (void)rows;
 }
 
 // Perceptual-loss value of one conv+norm+act layer: sums of |z-z'|, |y-y'|, |a-a'| (block partials).
@@ -495,12 +556,19 @@ extern "C" int mpgan_norm_act_add(const float* z, int32_t ldz, const mpgan_prolo
                    (!r || ((ldr % 4 == 0) && aligned16(r)));
   const long rows = (long)n * P;
   Pro a = make_pro(pz), b = make_pro(pr);
+  const int CGa = vec ? c / 4 : c;
+  MPGAN_UNSUPPORTED(CGa > 256, "norm_act_add: C=%d too wide", c);
+  const int Ra = 256 / CGa;
+  long gxa = (P + Ra - 1) / Ra;
+  const long capa = 4096 / n > 1 ? 4096 / n : 1;
+  if (gxa > capa) gxa = capa;
+  dim3 grida((unsigned)gxa, (unsigned)n);
   if (vec)
-    hipLaunchKernelGGL(norm_act_add_kernel<4>, dim3(ew_blocks(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream, z,
-                       ldz, a, r, ldr, b, rows, (long)P, c, tanh_out, out, ldo);
+    hipLaunchKernelGGL(norm_act_add_kernel<4>, grida, dim3(256), 0, (hipStream_t)stream, z, ldz, a, r, ldr, b, rows,
+                       (long)P, c, tanh_out, out, ldo);
   else
-    hipLaunchKernelGGL(norm_act_add_kernel<1>, dim3(ew_blocks(rows * c)), dim3(256), 0, (hipStream_t)stream, z, ldz, a,
-                       r, ldr, b, rows, (long)P, c, tanh_out, out, ldo);
+    hipLaunchKernelGGL(norm_act_add_kernel<1>, grida, dim3(256), 0, (hipStream_t)stream, z, ldz, a, r, ldr, b, rows,
+                       (long)P, c, tanh_out, out, ldo);
   return check_launch("norm_act_add");
 }
 
@@ -553,12 +621,19 @@ extern "C" int mpgan_norm_bwd_apply(const float* g, int32_t ldg, const float* z,
   const long rows = (long)n * P;
   Pro pp = make_pro(p);
   Peer pe = make_peer(peer);
+  const int CGa = vec ? c / 4 : c;
+  MPGAN_UNSUPPORTED(CGa > 256, "norm_bwd_apply: C=%d too wide", c);
+  const int Ra = 256 / CGa;
+  long gxa = (P + Ra - 1) / Ra;
+  const long capa = 4096 / n > 1 ? 4096 / n : 1;
+  if (gxa > capa) gxa = capa;
+  dim3 grida((unsigned)gxa, (unsigned)n);
   if (vec)
-    hipLaunchKernelGGL(norm_bwd_apply_kernel<4>, dim3(ew_blocks(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream, g,
-                       ldg, z, ldz, pp, mean, invstd, c1, c2, pe, rows, (long)P, c, dz, lddz);
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<4>, grida, dim3(256), 0, (hipStream_t)stream, g, ldg, z, ldz, pp, mean,
+                       invstd, c1, c2, pe, rows, (long)P, c, dz, lddz);
   else
-    hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, dim3(ew_blocks(rows * c)), dim3(256), 0, (hipStream_t)stream, g, ldg,
-                       z, ldz, pp, mean, invstd, c1, c2, pe, rows, (long)P, c, dz, lddz);
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, grida, dim3(256), 0, (hipStream_t)stream, g, ldg, z, ldz, pp, mean,
+                       invstd, c1, c2, pe, rows, (long)P, c, dz, lddz);
   return check_launch("norm_bwd_apply");
 }
 

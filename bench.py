@@ -10,9 +10,10 @@ A "step" = Lightning's per-batch loop of the reference (G step then D step:
 G fwd x2, G bwd, D fwd x3, D bwd x3, two fused Adam steps) on one synthetic
 batch already resident in HBM.  Rank 0 prints ONE JSON line.
 
-  roofline     : the dominant kernel (the BN=128 fp32-MFMA implicit-GEMM conv,
-                 all of D's dense layers forward + backward-data) timed live with
-                 HIP events on the launch stream during the timed steps;
+  roofline     : the dominant kernel (the BN=128 fp32-MFMA implicit-GEMM conv with the
+                 BatchNorm+LeakyReLU load prologue: D's three dense layers, 9 forward
+                 launches per step) timed live with HIP events on the launch stream
+                 during the timed steps;
                  achieved = algorithmic FLOPs of those launches / their time,
                  against the 157.3 TFLOP/s fp32 matrix peak.
   cpu_baseline : the CPU oracle (plain torch restatement, oracle/) timed on this
@@ -32,7 +33,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
-DOMINANT = "gather_conv_pipe_kernel<BN=128>"
+DOMINANT = "gather_conv_pipe_kernel<128, 2, 2, 2, 1, 1>"   # as rocprofv3 names it (D's dense layers, forward)
 
 
 def note(msg):
@@ -93,6 +94,8 @@ def main():
                     help="2: BASELINE configs C3/C4 (256x256 slices); 3: config C5's shape (the reference's own "
                          "3-D graph, e.g. --dims 3 --size 128 --batch 4; fp32 -- bf16 storage is not built)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                                                      "the N>1 code path where ranks must share one GPU)")
     ap.add_argument("--no-gfwd", action="store_true", help="skip the side measurement of the G forward (clean profiles)")
     ap.add_argument("--lr", type=float, default=1e-6,
                     help="Adam lr for both nets.  The reference's 5e-4 drives the 952,576-input Linear head into "
@@ -106,11 +109,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % max(ndev, 1))
+    dev = torch.device("cuda", local_rank % max(ndev, 1))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from mpgan_amd import engine
     from mpgan_amd.gan import GAN
@@ -162,13 +169,17 @@ def main():
     if rank == 0:
         summ = probe.summary().get(DOMINANT, dict(calls=0, ms=0.0, flops=0.0))
         achieved = summ["flops"] / (summ["ms"] * 1e-3) / 1e12 if summ["ms"] > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(tp) and args.dims == 2 and args.size == 256 and args.batch == 16:
+            traffic = json.load(open(tp)).get(DOMINANT, {}).get("hbm_bytes_per_launch")
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None, "kernel": DOMINANT,
+                    "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "kernel": DOMINANT,
                     "launches_per_step": summ["calls"] / max(args.steps, 1),
                     "avg_launch_ms": summ["ms"] / max(summ["calls"], 1),
                     "avg_launch_gflop": summ["flops"] / max(summ["calls"], 1) / 1e9}
         # G-forward-only (config C2) on the side: not part of `value`
-        g_fwd_ms = float("nan")
+        g_fwd_ms = None
         with torch.no_grad():
             for _ in range(0 if args.no_gfwd else 2):
                 gan.generator(batch["t1w"])
@@ -198,11 +209,12 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "adam_lr": args.lr},
             "roofline": roofline,
             "step_mfma_frac": (step_flops_sample * args.batch) / (dt / args.steps) / 1e12 / PEAK_FP32_TFLOPS,
-            "g_forward": {"ms": g_fwd_ms, "slices_per_s": args.batch / (g_fwd_ms * 1e-3),
-                          "mfma_frac": g_fwd_flops / (g_fwd_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
+            "g_forward": None if g_fwd_ms is None else {
+                "ms": g_fwd_ms, "slices_per_s": args.batch / (g_fwd_ms * 1e-3),
+                "mfma_frac": g_fwd_flops / (g_fwd_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
             "losses": losses,
         }
-        note(f"G forward {g_fwd_ms:.2f} ms")
+        note(f"G forward {g_fwd_ms} ms")
         if world == 1 and not args.no_cpu_baseline and args.dims == 2:
             out["cpu_baseline"] = cpu_baseline_leg(gan, spatial)
             note("cpu baseline done")

@@ -523,14 +523,34 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
 
 // dW[cd][cg][t] = beta*dW + sum_split partial[split][cd][t*Cg+cg]
 // block = 32 consecutive elements x 8 split lanes; lanes sum their splits in
-// order, then the 8 lane sums are added in order: deterministic.
+// order, then the 8 lane sums are added in order: deterministic.  The trailing
+// `bias_blocks` blocks reduce the fused bias-gradient partials the same way
+// (db[c] = beta*db[c] + sum_split bp[split][c]) -- one launch instead of two.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                           int nsplit, int Cd, int Cg, int T, float beta) {
+                                                           int nsplit, int Cd, int Cg, int T, float beta,
+                                                           const float* __restrict__ bp, int bsplit,
+                                                           float* __restrict__ db, int bias_blocks) {
   __shared__ float sh[8][33];
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int main_blocks = (int)gridDim.x - bias_blocks;
+  if ((int)blockIdx.x >= main_blocks) {
+    const int c = ((int)blockIdx.x - main_blocks) * 32 + e;
+    float s = 0.f;
+    if (c < Cd)
+      for (int k = sl; k < bsplit; k += 8) s += bp[(long)k * Cd + c];
+    sh[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && c < Cd) {
+      float t = sh[0][e];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += sh[k][e];
+      db[c] = beta != 0.f ? beta * db[c] + t : t;
+    }
+    return;
+  }
   const long total = (long)Cd * Cg * T;
   const long NC = (long)T * Cg;
-  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  for (long base = (long)blockIdx.x * 32; base < total; base += (long)gridDim.x * 32) {
+  for (long base = (long)blockIdx.x * 32; base < total; base += (long)main_blocks * 32) {
     const long i = base + e;
     float s = 0.f;
     if (i < total)
@@ -855,10 +875,9 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
       if (rc0) return rc0;
       const long total0 = (long)Cd * Cg * T;
       int blocks0 = (int)((total0 + 31) / 32);
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks0), dim3(256), 0, st0, p.partial, dw, tp.blocks, Cd, Cg, T, beta);
-      if (dbias)
-        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Cd + 3) / 4), dim3(256), 0, st0, p.bias_partial, tp.blocks,
-                           Cd, dbias, beta);
+      const int bb0 = dbias ? (Cd + 31) / 32 : 0;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks0 + bb0), dim3(256), 0, st0, p.partial, dw, tp.blocks, Cd, Cg,
+                         T, beta, p.bias_partial, tp.blocks, dbias, bb0);
       return check_launch("thin_wgrad_reduce");
     }
   }
@@ -883,9 +902,8 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
   const long total = (long)Cd * Cg * T;
   int blocks = (int)((total + 31) / 32);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, pl.nsplit * pl.kw, Cd, Cg, T, beta);
-  if (dbias)
-    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Cd + 3) / 4), dim3(256), 0, st, p.bias_partial, pl.nsplit, Cd,
-                       dbias, beta);
+  const int bb = dbias ? (Cd + 31) / 32 : 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + bb), dim3(256), 0, st, p.partial, dw, pl.nsplit * pl.kw, Cd, Cg,
+                     T, beta, p.bias_partial, pl.nsplit, dbias, bb);
   return check_launch("wgrad_reduce");
 }

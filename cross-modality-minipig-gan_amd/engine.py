@@ -111,8 +111,9 @@ def conv_macs(g: ConvGeom) -> int:
     return g.n * grid[0] * grid[1] * grid[2] * g.cin * g.cout * g.taps
 
 
-def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool) -> str:
-    """Label of the kernel the C dispatcher picks for this conv (mpgan_conv_variant)."""
+def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_sample_norm: bool = False) -> str:
+    """The kernel symbol (as rocprofv3 prints it, minus `void mpgan::` and the argument list)
+    the C dispatcher picks for this conv (mpgan_conv_variant + launch_gather's rules)."""
     gc = g.c()
     v = int(lib().mpgan_conv_variant(C.byref(gc), int(backward_data), int(has_pro)))
     if v == 1:
@@ -120,9 +121,11 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool) -> str:
     if v == 2:
         return "thin_cout1_kernel"
     cin_eff = g.cout if backward_data else g.cin
-    if cin_eff % 32 == 0 or cin_eff == 16:
-        return f"gather_conv_pipe_kernel<BN={v}>"      # software-pipelined main kernel
-    return f"gather_conv_kernel<BN={v},{'vec4' if cin_eff % 4 == 0 else 'scalar'}>"
+    tm, tn, wn = {128: (2, 2, 2), 64: (1, 2, 1), 32: (1, 1, 1)}[v]
+    if cin_eff % 32 == 0 or cin_eff == 16:      # software-pipelined main kernel <BN, TM, TN, WN, WRAPS, PRO>
+        pro = 0 if not has_pro else (2 if per_sample_norm else 1)
+        return f"gather_conv_pipe_kernel<{v}, {tm}, {tn}, {wn}, {1 if cin_eff % 32 == 0 else 2}, {pro}>"
+    return f"gather_conv_kernel<{v}, {tm}, {tn}, {wn}, {'false' if cin_eff % 4 == 0 else 'true'}>"
 
 
 def _ld(t):
@@ -282,7 +285,7 @@ def emit_conv_fwd(prog, g: ConvGeom, x, wp, bias, y, pro=None, resid=None, tanh=
     pc = pro.c() if pro is not None else None
     prog.add("conv_forward", lib().mpgan_conv_forward, C.byref(gc), x.data_ptr(), _ld(x), wp.data_ptr(), _p(bias),
              C.byref(pc) if pc is not None else None, _p(resid), _ld(resid), int(tanh), _p(stats), y.data_ptr(), _ld(y),
-             keep=(gc, pc, x, wp, bias, y, resid, pro), tag=(gather_kernel_name(g, False, pro is not None), 2.0 * conv_macs(g)))
+             keep=(gc, pc, x, wp, bias, y, resid, pro), tag=(gather_kernel_name(g, False, pro is not None, bool(pro is not None and pro.n_stride)), 2.0 * conv_macs(g)))
 
 
 def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):

@@ -168,7 +168,7 @@ int mpgan_channel_stats(const float* z, int32_t ldz, int32_t n, int64_t pixels_p
  * (momentum, UNBIASED variance) when running_mean != null.
  * instance = 0: one set per channel (stats over n and pixels);
  * instance = 1: one set per (n, c).
- * With instance = 0 and more than 512 partial rows the rows are folded first, into scratch
+ * With instance = 0 and more than 4096 partial rows the rows are folded first, into scratch
  * that must follow them in the same buffer: capacity >= (n*chunks + 32) * 2 * c floats. */
 int mpgan_norm_finalize(const float* partials, int32_t n, int32_t chunks, int32_t c,
                         int64_t pixels_per_sample, int32_t instance,

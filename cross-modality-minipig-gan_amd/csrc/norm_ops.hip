@@ -11,7 +11,8 @@
 namespace mpgan {
 
 static inline int stats_chunks_host(long pixels_per_sample) {
-  long c = pixels_per_sample / 1024;
+  // >= 256 rows per chunk: these passes are latency-bound per block, so they want ~4 blocks per CU
+  long c = pixels_per_sample / 256;
   if (c < 1) c = 1;
   if (c > 256) c = 256;
   return (int)c;

@@ -85,6 +85,10 @@ def lib():
     """Return the loaded library; raise loudly when it has not been built."""
     global _lib
     if _lib is None:
+        # torch ships its own HIP runtime (torch/lib/libamdhip64.so): import it FIRST so this
+        # library's libamdhip64 dependency binds to the runtime torch initialises.  Loaded the
+        # other way round the process holds two runtimes and our launches see "no ROCm-capable device".
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP hot path has not been built "

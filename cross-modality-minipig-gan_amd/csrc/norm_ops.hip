@@ -93,32 +93,9 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
   });
 }
 
-// Gradient w.r.t. the norm output for one element, including the perceptual-loss taps of a
-// peer pass when present (test_runs/GAN.py:288-298: L1 between the two passes' activations):
-//   g_a = g - ca*sign(a_peer - a),  gy = g_a*act'(y) - cy*sign(y_peer - y)
-// and the extra dz term -cz*sign(z_peer - z) that bypasses the norm.
-struct TapGrad { float gy, dz_extra, slope_term; };
-__device__ __forceinline__ TapGrad tap_grad(float g, float z, float y, bool leaky, float slope, const Peer& pr,
-                                            long prow, int c, int si_peer, float cz, float cy, float ca) {
-  TapGrad t;
-  t.dz_extra = 0.f;
-  float ga = g;
-  float gy_extra = 0.f;
-  if (pr.coef) {
-    const float zp = pr.z[prow * pr.ld + c];
-    const float yp = zp * pr.scale[si_peer] + pr.shift[si_peer];
-    const float ap = (leaky && yp < 0.f) ? yp * slope : yp;
-    const float a = (leaky && y < 0.f) ? y * slope : y;
-    ga -= ca * sgn(ap - a);
-    gy_extra = -cy * sgn(yp - y);
-    t.dz_extra = -cz * sgn(zp - z);
-  }
-  const bool neg = leaky && y < 0.f;
-  t.gy = (neg ? ga * slope : ga) + gy_extra;
-  t.slope_term = neg ? ga * y : 0.f;
-  return t;
-}
-
+// Perceptual-loss taps of a peer pass (test_runs/GAN.py:288-298: L1 between the two passes'
+// activations) enter the backward as:  g_a = g - ca*sign(a_peer - a),
+// gy = g_a*act'(y) - cy*sign(y_peer - y), and a dz term -cz*sign(z_peer - z) that bypasses the norm.
 template <int V>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ gr, int ldg,
                                                               const float* __restrict__ z, int ldz, Pro p,

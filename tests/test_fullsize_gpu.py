@@ -1,0 +1,105 @@
+"""Parity at BASELINE.json's full sizes, where the CPU oracle is too slow to be the
+checker for every tensor: (1) the reference's own 128^3 discriminator fixture (its real
+`Discriminator`, GAN_final.py:159-209, run by oracle/make_golden.py), (2) size-independent
+properties of the conv kernels at the C3 shapes (256x256, bs 16): the three kernels of one
+layer are each other's adjoints, and the forward is linear."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_discriminator_128cubed_matches_reference_fixture(golden_dir):
+    """Variant-A D at the reference's true shape (1,1,128,128,128): validity, BCE, input /
+    parameter gradient summaries produced by the REFERENCE's code."""
+    from mpgan_amd.gan import adversarial_loss
+    from mpgan_amd.networks import Discriminator
+    from oracle import refmodel as R
+    from oracle.make_golden import summarize
+    fx = np.load(os.path.join(golden_dir, "disc_variant_a_128.npz"))
+    shell = R.Discriminator((1, 128, 128, 128))           # only to produce the closed-form weights
+    R.closed_form_fill_(shell)
+    d = Discriminator((1, 128, 128, 128))
+    d.load_state_dict(shell.state_dict())
+    d.cuda().train()
+    g = torch.Generator().manual_seed(int(fx["seed"]))
+    x = (torch.rand(1, 1, 128, 128, 128, generator=g) * 2 - 1).cuda().requires_grad_(True)
+    v = d(x)
+    np.testing.assert_allclose(v.detach().cpu().numpy(), fx["validity"], atol=2e-6)
+    loss = adversarial_loss(v, torch.full_like(v, 0.9))
+    np.testing.assert_allclose(loss.item(), float(fx["loss"]), rtol=1e-5)
+    loss.backward()
+    got = summarize(x.grad.cpu())
+    # sums over 2M gradient values cancel heavily: compare abs-sum, head and strided samples
+    np.testing.assert_allclose(got[1], fx["grad_x"][1], rtol=5e-3)
+    np.testing.assert_allclose(got[3:], fx["grad_x"][3:], rtol=2e-2, atol=2e-2 * np.abs(fx["grad_x"][3:]).max())
+    for name, p in d.named_parameters():
+        if name in ("model_conv.0.bias", "model_conv.3.bias", "model_conv.6.bias", "model_conv.9.bias"):
+            continue
+        want = fx["grad__" + name]
+        got = summarize(p.grad.cpu())
+        np.testing.assert_allclose(got[1], want[1], rtol=2e-2, err_msg=name)          # sum of |grad|
+        np.testing.assert_allclose(got[3:], want[3:], rtol=5e-2, atol=5e-2 * np.abs(want[3:]).max(), err_msg=name)
+    for name, b in d.named_buffers():
+        np.testing.assert_allclose(summarize(b.float().cpu()), fx["buf__" + name], rtol=1e-4, atol=1e-5, err_msg=name)
+
+
+FULL = [  # (cin, cout, k, stride, pad, hw, transposed) at bs 16: D's dense layers and two G layers
+    (64, 128, 3, 1, 0, 254, False), (128, 256, 4, 2, 0, 252, False), (256, 256, 4, 2, 0, 125, False),
+    (16, 16, 3, 1, 1, 128, False), (64, 16, 3, 2, 1, 64, True)]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,hw,tr", FULL, ids=lambda v: str(v))
+def test_conv_kernels_are_mutual_adjoints_and_linear_at_full_size(cin, cout, k, s, p, hw, tr):
+    """<conv(x;w), dy> = <x, dgrad(dy;w)> = <w, wgrad(x,dy)> and conv(a*x1 + x2) = a*conv(x1) + conv(x2)."""
+    from mpgan_amd import ops
+    n = 16
+    g = ops.ConvGeom(n, (1, hw, hw), cin, cout, (1, k, k), (1, s, s), (0, p, p), tr, (0, s - 1, s - 1) if tr else (0, 0, 0))
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(n, 1, hw, hw, cin, device="cuda", generator=gen) * 2 - 1
+    x2 = torch.rand(n, 1, hw, hw, cin, device="cuda", generator=gen) * 2 - 1
+    dy = torch.rand(n, *g.out_dhw, cout, device="cuda", generator=gen) * 2 - 1
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = (torch.rand(wshape, device="cuda", generator=gen) - 0.5) / (cin * k * k) ** 0.5
+    y = torch.empty(n, *g.out_dhw, cout, device="cuda")
+    ops.conv_forward(g, x, ops.pack_weight(w, transposed=tr), None, y)
+    dx = torch.empty_like(x)
+    ops.conv_backward_data(g, dy, ops.pack_weight(w, transposed=tr, for_dgrad=True), dx)
+    dw = torch.empty_like(w)
+    ws = torch.empty(ops.conv_wgrad_workspace(g) // 4, device="cuda")
+    ops.conv_backward_weight(g, x, dy, dw, ws)
+    a = (y.double() * dy.double()).sum().item()
+    b = (x.double() * dx.double()).sum().item()
+    c = (w.double() * dw.double()).sum().item()
+    scale = (y.double().abs() * dy.double().abs()).sum().item()
+    assert abs(a - b) <= 2e-6 * scale and abs(a - c) <= 2e-6 * scale, (a, b, c, scale)
+    y2, y12 = torch.empty_like(y), torch.empty_like(y)
+    ops.conv_forward(g, x2, ops.pack_weight(w, transposed=tr), None, y2)
+    ops.conv_forward(g, 0.5 * x + x2, ops.pack_weight(w, transposed=tr), None, y12)
+    err = (y12 - (0.5 * y + y2)).abs().max().item()
+    assert err <= 1e-5 * (y.abs().max().item() + y2.abs().max().item()), err
+
+
+def test_batchnorm_statistics_at_full_size_are_normalised():
+    """Fused-epilogue statistics of D.conv2 at 256x256, bs 16 (7,938 partial rows, folded):
+    the normalised output has per-channel mean 0 and variance 1."""
+    from mpgan_amd import ops
+    n, hw, cin, cout = 16, 254, 64, 128
+    g = ops.ConvGeom(n, (1, hw, hw), cin, cout, (1, 3, 3), (1, 1, 1), (0, 0, 0))
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    x = torch.rand(n, 1, hw, hw, cin, device="cuda", generator=gen) * 2 - 1
+    w = (torch.rand(cout, cin, 3, 3, device="cuda", generator=gen) - 0.5) / 24.0
+    b = torch.rand(cout, device="cuda", generator=gen) - 0.5
+    rows = ops.conv_stats_rows(g, False)
+    part = torch.empty((rows + 32) * 2 * cout, device="cuda")
+    z = torch.empty(n, *g.out_dhw, cout, device="cuda")
+    ops.conv_forward(g, x, ops.pack_weight(w), b, z, stats_partials=part)
+    scale, shift, mean, invstd = (torch.empty(cout, device="cuda") for _ in range(4))
+    P = n * g.out_dhw[1] * g.out_dhw[2]
+    ops.norm_finalize(part, 1, rows, cout, P, False, None, None, 1e-5, 0.1, None, None, None, scale, shift, mean, invstd)
+    y = z.view(-1, cout).double() * scale.double() + shift.double()
+    assert y.mean(0).abs().max().item() < 1e-4
+    assert (y.var(0, unbiased=False) - 1).abs().max().item() < 1e-3

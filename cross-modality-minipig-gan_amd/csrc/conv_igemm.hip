@@ -903,6 +903,376 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
   return check_launch("thin_cout1");
 }
 
+// ---------------------------------------------------------------------------
+// Patch kernel: 2-D layers with <= 32 output channels and 16/32/64 gathered channels
+// (the U-Net's stride-1 units, its stride-2 down convs up to 32 channels, the transposed
+// convs and every backward-data gather that lands on <= 32 channels).  Their K is short
+// (<= 9 taps x 16..64 channels), so the K-stepped kernel above spends its time on the
+// prologue, per-step barriers and re-fetching each input pixel once per tap.  Here a
+// block stages the INPUT PATCH of an 8 x 16 tile of m-positions (halo included,
+// normalise + activation applied once per element) and all weights of the phase in
+// LDS with one round of global loads, then runs the whole contraction from LDS:
+// one barrier, every input element fetched from HBM/L2 once per tile.
+// Rows: wave w owns tile rows 2w, 2w+1; lane operand maps as in the kernels above.
+// ---------------------------------------------------------------------------
+constexpr int PT_H = 8, PT_W = 16;
+
+struct PatchLaunch {
+  int tiles_x, tiles_y;
+  int patch_floats;      // LDS floats reserved for the input patch (max over phases)
+  FastDiv fCout;         // the staging loops are VALU-bound: no software divides in them
+  FastDiv fPW[8], fNx[8];
+};
+
+template <int CIN, int PRO, bool NARROW>
+__global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, const PatchLaunch pl) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int PC = CIN + 4;
+  constexpr int CQ = CIN / 4;
+  constexpr int LU = CIN == 16 ? 3 : (CIN == 32 ? 6 : 12);   // patch chunks per thread in flight
+  constexpr int WU = CIN == 16 ? 3 : (CIN == 32 ? 9 : 8);    // weight chunks per thread in flight
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const unsigned wblk = xcd_remap(blockIdx.x, gridDim.x);
+  // phase fastest: the phases of one tile read the same input patch and run back to back on one XCD
+  const int phase = (int)(wblk % (unsigned)p.nphase);
+  unsigned q = wblk / (unsigned)p.nphase;
+  const int tx = (int)(q % (unsigned)pl.tiles_x);
+  q /= (unsigned)pl.tiles_x;
+  const int ty = (int)(q % (unsigned)pl.tiles_y);
+  const int n = (int)(q / (unsigned)pl.tiles_y);
+  const Phase& ph = p.ph[phase];
+  const int Cout = p.Cout;
+  const int my0 = ty * PT_H, mx0 = tx * PT_W;
+  const int My = ph.Mz > 0 ? ph.My : 0, Mx = ph.Mx;
+  if (my0 >= My || mx0 >= Mx) {
+    if (p.stats && tid < Cout) {
+      float* row = p.stats + (long)wblk * 2 * Cout;
+      row[tid] = 0.f;
+      row[Cout + tid] = 0.f;
+    }
+    return;
+  }
+  const int Hi = p.Hi, Wi = p.Wi, ldi = p.ldi;
+  const int isy = p.istride[1], isx = p.istride[2];
+  const int dsy = p.dstep[1], dsx = p.dstep[2];
+  const int ny = ph.nz > 0 ? ph.ny : 0, nx = ph.nx;
+  const int ye = ph.dy0 + dsy * (ny > 0 ? ny - 1 : 0), xe = ph.dx0 + dsx * (nx > 0 ? nx - 1 : 0);
+  const int ylo = ph.dy0 < ye ? ph.dy0 : ye, yhi = ph.dy0 < ye ? ye : ph.dy0;
+  const int xlo = ph.dx0 < xe ? ph.dx0 : xe, xhi = ph.dx0 < xe ? xe : ph.dx0;
+  const int PH = (PT_H - 1) * isy + (yhi - ylo) + 1, PW = (PT_W - 1) * isx + (xhi - xlo) + 1;
+  const int y0 = my0 * isy + ylo, x0 = mx0 * isx + xlo;
+  float* patch = lds;
+  float* wl = lds + pl.patch_floats;
+  const float* __restrict__ gin = p.in + (long)n * Hi * Wi * ldi;
+  const float* __restrict__ gw = p.wp;
+
+  // ---- stage patch + weights: every global load of the first round is issued before any
+  //      LDS store, so a block pays ONE memory round trip ----
+  {
+    const int cq = tid & (CQ - 1);                   // 256 % CQ == 0: a thread keeps its channel chunk
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float slope = 1.f;
+    int act = 0;
+    if constexpr (PRO != 0) {
+      sc = *reinterpret_cast<const float4*>(p.pro.scale + 4 * cq);
+      sh = *reinterpret_cast<const float4*>(p.pro.shift + 4 * cq);
+      slope = pro_slope(p.pro);
+      act = p.pro.act;
+    }
+    const int total = PH * PW * CQ;
+    const FastDiv fPW = pl.fPW[phase], fNx = pl.fNx[phase], fCout = pl.fCout;
+    const int ntaps = ny * nx;
+    const int wtotal = ntaps * Cout * CQ;
+    const int Ktot = p.Kz * p.Ky * p.Kx * CIN;
+    float4 pv[LU], wv[WU];
+    unsigned pok;
+
+    auto load_patch = [&](int base) {
+      pok = 0;
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        const int idx = base + u * 256 + tid;
+        const unsigned pix = (unsigned)idx / (unsigned)CQ;
+        unsigned py, px;
+        fdivmod(pix, fPW, py, px);
+        const int iy = y0 + (int)py, ix = x0 + (int)px;
+        const unsigned ok = (idx < total ? 1u : 0u) & ((unsigned)iy < (unsigned)Hi ? 1u : 0u) &
+                            ((unsigned)ix < (unsigned)Wi ? 1u : 0u);
+        const long off = ok ? ((long)iy * Wi + ix) * ldi + 4 * cq : 0;
+        pv[u] = *reinterpret_cast<const float4*>(gin + off);
+        pok |= ok << u;
+      }
+    };
+    auto store_patch = [&](int base) {
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        const int idx = base + u * 256 + tid;
+        float4 x = pv[u];
+        if constexpr (PRO != 0) {
+          x.x = act_apply(x.x * sc.x + sh.x, act, slope);
+          x.y = act_apply(x.y * sc.y + sh.y, act, slope);
+          x.z = act_apply(x.z * sc.z + sh.z, act, slope);
+          x.w = act_apply(x.w * sc.w + sh.w, act, slope);
+        }
+        const bool ok = (pok >> u) & 1u;
+        x.x = ok ? x.x : 0.f; x.y = ok ? x.y : 0.f; x.z = ok ? x.z : 0.f; x.w = ok ? x.w : 0.f;
+        if (idx < total) *reinterpret_cast<float4*>(patch + (idx / CQ) * PC + 4 * cq) = x;
+      }
+    };
+    // weights of this phase: LDS rows [tap][co] at pitch PC
+    auto load_w = [&](int base) {
+#pragma unroll
+      for (int u = 0; u < WU; ++u) {
+        const int idx = base + u * 256 + tid;
+        const unsigned row = idx < wtotal ? (unsigned)idx / (unsigned)CQ : 0u;
+        unsigned t, co, jy, jx;
+        fdivmod(row, fCout, t, co);
+        fdivmod(t, fNx, jy, jx);
+        const int ky = ph.ky0 + p.kstep[1] * (int)jy, kx = ph.kx0 + p.kstep[2] * (int)jx;
+        const int tapflat = (ph.kz0 * p.Ky + ky) * p.Kx + kx;
+        wv[u] = *reinterpret_cast<const float4*>(gw + ((int)co * Ktot + tapflat * CIN + 4 * cq));
+      }
+    };
+    auto store_w = [&](int base) {
+#pragma unroll
+      for (int u = 0; u < WU; ++u) {
+        const int idx = base + u * 256 + tid;
+        if (idx < wtotal) *reinterpret_cast<float4*>(wl + (idx / CQ) * PC + 4 * cq) = wv[u];
+      }
+    };
+    load_patch(0);
+    if (wtotal > 0) load_w(0);
+    store_patch(0);
+    if (wtotal > 0) store_w(0);
+    for (int base = 256 * LU; base < total; base += 256 * LU) {
+      load_patch(base);
+      store_patch(base);
+    }
+    for (int base = 256 * WU; base < wtotal; base += 256 * WU) {
+      load_w(base);
+      store_w(base);
+    }
+  }
+  __syncthreads();
+
+  const float* gres = p.resid;
+  float* gout = p.out;
+  const int ldo = p.ldo, ldr = p.ldr, tanh_out = p.tanh_out;
+  const int osy = p.ostride[1], osx = p.ostride[2];
+  float sm = 0.f, sq = 0.f;
+  int scol;          // statistics column of this lane
+  bool swrite;       // lane that publishes the wave's column sums
+
+  if constexpr (!NARROW) {
+    // ---- 32x32x2 tiles: wave = 2 tile rows x 16 columns of m-positions, 32 output channels ----
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+      const int tyl = 2 * wid + (li >> 4), txl = li & 15;
+      const float* Arow = patch + ((tyl * isy - ylo) * PW + (txl * isx - xlo)) * PC + 4 * lh;
+      const float* Brow = wl + (li < Cout ? li : 0) * PC + 4 * lh;
+      for (int jy = 0; jy < ny; ++jy) {
+        const int dy = ph.dy0 + dsy * jy;
+        for (int jx = 0; jx < nx; ++jx) {
+          const int dx = ph.dx0 + dsx * jx;
+          const float* A = Arow + (dy * PW + dx) * PC;
+          const float* B = Brow + (jy * nx + jx) * Cout * PC;
+#pragma unroll
+          for (int g = 0; g < CIN / 8; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(A + 8 * g);
+            const float4 b = *reinterpret_cast<const float4*>(B + 8 * g);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+          }
+        }
+      }
+    }
+    const int co = li;
+    const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;      // row inside the wave's 32
+      const int my = my0 + 2 * wid + (rl >> 4), mx = mx0 + (rl & 15);
+      const int oy = my * osy + ph.oy, ox = mx * osx + ph.ox;
+      const bool ok = my < My && mx < Mx && oy < p.Ho && ox < p.Wo && co < Cout;
+      if (ok) {
+        const long pix = ((long)n * p.Ho + oy) * p.Wo + ox;
+        float v = acc[r] + bv;
+        sm += v;
+        sq += v * v;
+        if (gres) v += gres[pix * ldr + co];
+        if (tanh_out) v = tanhf(v);
+        gout[pix * ldo + co] = v;
+      }
+    }
+    sm += __shfl_xor(sm, 32, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    scol = li;
+    swrite = lh == 0;
+  } else {
+    // ---- <= 16 output channels: 16x16x4 tiles (no padded columns); wave = 2 tile rows, one
+    //      accumulator per row; lane (c = lane & 15, kq = lane >> 4) feeds channels 4*kq..4*kq+3
+    //      of each 16-channel group through the four MFMAs of a quad ----
+    const int l16 = lane & 15, kq = lane >> 4;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    {
+      const float* A0row = patch + (((2 * wid) * isy - ylo) * PW + (l16 * isx - xlo)) * PC + 4 * kq;
+      const float* A1row = A0row + isy * PW * PC;
+      const float* Brow = wl + (l16 < Cout ? l16 : 0) * PC + 4 * kq;
+      for (int jy = 0; jy < ny; ++jy) {
+        const int dy = ph.dy0 + dsy * jy;
+        for (int jx = 0; jx < nx; ++jx) {
+          const int dx = ph.dx0 + dsx * jx;
+          const int aoff = (dy * PW + dx) * PC;
+          const float* B = Brow + (jy * nx + jx) * Cout * PC;
+#pragma unroll
+          for (int g = 0; g < CIN / 16; ++g) {
+            const float4 a0 = *reinterpret_cast<const float4*>(A0row + aoff + 16 * g);
+            const float4 a1 = *reinterpret_cast<const float4*>(A1row + aoff + 16 * g);
+            const float4 b = *reinterpret_cast<const float4*>(B + 16 * g);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc1, 0, 0, 0);
+          }
+        }
+      }
+    }
+    const int co = l16;
+    const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int my = my0 + 2 * wid + mt, mx = mx0 + 4 * kq + r;
+        const int oy = my * osy + ph.oy, ox = mx * osx + ph.ox;
+        const bool ok = my < My && mx < Mx && oy < p.Ho && ox < p.Wo && co < Cout;
+        if (ok) {
+          const long pix = ((long)n * p.Ho + oy) * p.Wo + ox;
+          float v = (mt == 0 ? acc0[r] : acc1[r]) + bv;
+          sm += v;
+          sq += v * v;
+          if (gres) v += gres[pix * ldr + co];
+          if (tanh_out) v = tanhf(v);
+          gout[pix * ldo + co] = v;
+        }
+      }
+    sm += __shfl_xor(sm, 16, 64);
+    sq += __shfl_xor(sq, 16, 64);
+    sm += __shfl_xor(sm, 32, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    scol = l16;
+    swrite = kq == 0;
+  }
+
+  if (p.stats) {
+    __syncthreads();                         // the patch is dead: reuse its head for the wave partials
+    float* st = lds;                         // [4 waves][2][32]
+    if (swrite) {
+      st[(wid * 2 + 0) * 32 + scol] = sm;
+      st[(wid * 2 + 1) * 32 + scol] = sq;
+    }
+    __syncthreads();
+    if (tid < Cout) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a += st[(w * 2 + 0) * 32 + tid];
+        b += st[(w * 2 + 1) * 32 + tid];
+      }
+      float* row = p.stats + (long)wblk * 2 * Cout;
+      row[tid] = a;
+      row[Cout + tid] = b;
+    }
+  }
+}
+
+// Geometry test for the patch kernel (pointer alignment is checked at launch).
+static bool patch_plan(const GatherConv& p, PatchLaunch* out, int* smem_bytes) {
+  static const bool off = getenv("MPGAN_DBG_NO_PATCH") != nullptr;
+  if (off) return false;
+  if (p.Di != 1 || p.Do != 1 || p.Kz != 1) return false;
+  if (!(p.Cin == 16 || p.Cin == 32 || p.Cin == 64)) return false;
+  if (p.Cout < 2 || p.Cout > 32) return false;
+  if (p.pro.scale && p.pro.n_stride != 0) return false;
+  if (p.ksplit > 1) return false;
+  int maxMy = 0, maxMx = 0, maxpix = 0, maxtaps = 0;
+  for (int i = 0; i < p.nphase; ++i) {
+    const Phase& ph = p.ph[i];
+    if (ph.nz > 1) return false;
+    const int ny = ph.nz > 0 ? ph.ny : 0, nx = ph.nx;
+    if (ny * nx > 9) return false;
+    const int ys = (ny > 0 ? ny - 1 : 0) * abs(p.dstep[1]), xs = (nx > 0 ? nx - 1 : 0) * abs(p.dstep[2]);
+    const int PH = (PT_H - 1) * p.istride[1] + ys + 1, PW = (PT_W - 1) * p.istride[2] + xs + 1;
+    if (PH * PW > maxpix) maxpix = PH * PW;
+    if (ny * nx > maxtaps) maxtaps = ny * nx;
+    if (out) {
+      out->fPW[i] = make_fastdiv((unsigned)PW);
+      out->fNx[i] = make_fastdiv((unsigned)(nx > 0 ? nx : 1));
+    }
+    if (ph.Mz > 0 && ph.My > maxMy) maxMy = ph.My;
+    if (ph.Mx > maxMx) maxMx = ph.Mx;
+  }
+  if (maxMy == 0 || maxMx == 0) return false;
+  const int PC = p.Cin + 4;
+  int patch_floats = maxpix * PC;
+  if (patch_floats < 256) patch_floats = 256;              // the statistics partials reuse the head
+  const long bytes = ((long)patch_floats + (long)maxtaps * p.Cout * PC) * 4;
+  if (bytes > 96 * 1024) return false;
+  if (out) {
+    out->tiles_x = (maxMx + PT_W - 1) / PT_W;
+    out->tiles_y = (maxMy + PT_H - 1) / PT_H;
+    out->patch_floats = patch_floats;
+    out->fCout = make_fastdiv((unsigned)p.Cout);
+  }
+  if (smem_bytes) *smem_bytes = (int)bytes;
+  return true;
+}
+
+template <int CIN, int PRO, bool NARROW>
+static int launch_patch_variant(const GatherConv& p, const PatchLaunch& pl, int smem, hipStream_t st) {
+  auto kern = gather_patch_kernel<CIN, PRO, NARROW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) {
+      set_error("gather_patch: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(pl.tiles_x * pl.tiles_y * p.N * p.nphase));
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p, pl);
+  return check_launch("gather_patch");
+}
+
+template <int CIN>
+static int launch_patch_cin(const GatherConv& p, const PatchLaunch& pl, int smem, hipStream_t st) {
+  const bool pro = p.pro.scale != nullptr;
+  if (p.Cout <= 16)
+    return pro ? launch_patch_variant<CIN, 1, true>(p, pl, smem, st) : launch_patch_variant<CIN, 0, true>(p, pl, smem, st);
+  return pro ? launch_patch_variant<CIN, 1, false>(p, pl, smem, st) : launch_patch_variant<CIN, 0, false>(p, pl, smem, st);
+}
+
+static int launch_patch(const GatherConv& p, const PatchLaunch& pl, int smem, hipStream_t st) {
+  switch (p.Cin) {
+    case 16: return launch_patch_cin<16>(p, pl, smem, st);
+    case 32: return launch_patch_cin<32>(p, pl, smem, st);
+    default: return launch_patch_cin<64>(p, pl, smem, st);
+  }
+}
+
 template <int BN, int TM, int TN, int WN, bool SCALAR>
 static int launch_variant(const GatherConv& p, long maxM, hipStream_t st) {
   auto kern = gather_conv_kernel<BN, TM, TN, WN, SCALAR>;
@@ -928,7 +1298,8 @@ static int launch_variant(const GatherConv& p, long maxM, hipStream_t st) {
 }
 
 // Kernel selection, shared by the launcher and mpgan_conv_variant():
-//   1 = thin_cin1, 2 = thin_cout1, 32/64/128 = gather_conv_kernel<BN>.
+//   1 = thin_cin1, 2 = thin_cout1, 32/64/128 = gather_conv_kernel<BN>; mpgan_conv_variant() adds
+//   16 = gather_patch_kernel (see patch_plan).
 static long max_phase_pixels(const GatherConv& p) {
   long maxM = 0;
   for (int i = 0; i < p.nphase; ++i) {
@@ -1001,6 +1372,19 @@ static int launch_gather(const GatherConv& p, hipStream_t st) {
   MPGAN_CHECK_ARG((long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx < (1L << 31), "gather_conv: weight larger than 2^31");
   const int variant = select_variant(p, maxM, thin_cin1_ok(p), thin_cout1_ok(p));
   if (variant <= 2) return launch_thin(p, maxM, st);
+  {
+    PatchLaunch pl;
+    int smem = 0;
+    if (patch_plan(p, &pl, &smem)) {
+      const bool aligned = (p.ldi % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0) &&
+                           ((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0) &&
+                           (!p.pro.scale || ((reinterpret_cast<uintptr_t>(p.pro.scale) |
+                                              reinterpret_cast<uintptr_t>(p.pro.shift)) & 15) == 0);
+      if (aligned) return launch_patch(p, pl, smem, st);
+      MPGAN_UNSUPPORTED(p.stats != nullptr, "gather_conv: fused statistics of a patch-kernel geometry need 16-byte "
+                                            "aligned operands (the partial-row count differs otherwise)");
+    }
+  }
   const bool vec = (p.Cin % 4 == 0) && (p.ldi % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0) &&
                    (!p.pro.scale || (((reinterpret_cast<uintptr_t>(p.pro.scale) |
@@ -1122,6 +1506,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // (the variant-B head Linear(512*8^3 -> 64): 7 pixel tiles, 8192 K-steps).
 static int plan_ksplit(const GatherConv& p) {
   if (!(p.Cin % 32 == 0) || p.Cout == 1 || p.nphase != 1) return 1;
+  if (patch_plan(p, nullptr, nullptr)) return 1;
   const long maxM = max_phase_pixels(p);
   const int variant = select_variant(p, maxM, false, false);
   const long blocks = (maxM + BM - 1) / BM * ((p.Cout + variant - 1) / variant) * p.nphase;
@@ -1145,9 +1530,14 @@ extern "C" int64_t mpgan_conv_splitk_workspace(const mpgan_conv_geom* g) {
 
 extern "C" int32_t mpgan_conv_stats_rows(const mpgan_conv_geom* g, int32_t has_prologue) {
   const int v = mpgan_conv_variant(g, 0, has_prologue);
-  if (v < 32) return 0;   // thin VALU kernels (or invalid geometry): no fused statistics
+  if (v < 16) return 0;   // thin VALU kernels (or invalid geometry): no fused statistics
   GatherConv p{};
   build_for_forward(p, g);
+  if (v == 16) {          // patch kernel: one partial row per block
+    PatchLaunch pl;
+    patch_plan(p, &pl, nullptr);
+    return (int32_t)(pl.tiles_x * pl.tiles_y * p.N * p.nphase);
+  }
   return (int32_t)((max_phase_pixels(p) + BM - 1) / BM) * p.nphase;
 }
 
@@ -1242,10 +1632,13 @@ extern "C" int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward
     else build_transposed(p, g->n, gd, cg, pd, cp, g->k, g->stride, g->pad);
   }
   p.ldi = cg;
+  if (has_prologue == 2) p.pro.n_stride = cg;   // per-(sample, channel) scale/shift (InstanceNorm)
   const int T = p.Kz * p.Ky * p.Kx;
   const bool t1 = p.Cin == 1 && !p.pro.scale && (long)T * ((p.Cout + 3) / 4 * 4) * 4 <= 48 * 1024;
   const int lanes = p.Cin / 4;
   const bool t2 = p.Cout == 1 && !p.pro.scale && p.Cin % 4 == 0 && lanes >= 1 && lanes <= 64 &&
                   (lanes & (lanes - 1)) == 0 && (long)T * p.Cin * 4 <= 48 * 1024;
-  return select_variant(p, max_phase_pixels(p), t1, t2);
+  const int v = select_variant(p, max_phase_pixels(p), t1, t2);
+  if (v > 2 && patch_plan(p, nullptr, nullptr)) return 16;
+  return v;
 }

@@ -34,8 +34,9 @@ class KernelProbe:
     """HIP-event timing of tagged launches (bench.py's live roofline figure):
     events are recorded on the stream the kernels are launched on."""
 
-    def __init__(self, want=None):
+    def __init__(self, want=None, detail=False):
         self.want = want            # None = every tagged call, else a set of kernel names
+        self.detail = detail        # True: time EVERY call, keyed "<c entry point> <geometry>" (tools/profile_step.py)
         self.samples = []           # (kernel, flops, ev0, ev1)
 
     def summary(self):
@@ -59,25 +60,28 @@ def set_probe(p: Optional[KernelProbe]):
 
 class Program:
     """A frozen list of C calls; `run` appends the stream and checks status."""
-    __slots__ = ("calls", "keep", "names", "tags")
+    __slots__ = ("calls", "keep", "names", "tags", "descs")
 
     def __init__(self):
         self.calls = []
         self.keep = []
         self.names = []
         self.tags = []
+        self.descs = []
 
-    def add(self, name, fn, *args, keep=(), tag=None):
+    def add(self, name, fn, *args, keep=(), tag=None, desc=""):
         self.calls.append((fn, args))
         self.names.append(name)
         self.keep.append(keep)
         self.tags.append(tag)
+        self.descs.append(desc)
 
     def extend(self, other: "Program"):
         self.calls += other.calls
         self.names += other.names
         self.keep += other.keep
         self.tags += other.tags
+        self.descs += other.descs
 
     def run(self, stream=None):
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
@@ -90,6 +94,8 @@ class Program:
             return
         for i, (fn, args) in enumerate(self.calls):
             tag = self.tags[i]
+            if probe.detail:
+                tag = (f"{self.names[i]} {self.descs[i]}".strip(), tag[1] if tag else 0.0)
             timed = tag is not None and (probe.want is None or tag[0] in probe.want)
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -115,12 +121,15 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
     """The kernel symbol (as rocprofv3 prints it, minus `void mpgan::` and the argument list)
     the C dispatcher picks for this conv (mpgan_conv_variant + launch_gather's rules)."""
     gc = g.c()
-    v = int(lib().mpgan_conv_variant(C.byref(gc), int(backward_data), int(has_pro)))
+    v = int(lib().mpgan_conv_variant(C.byref(gc), int(backward_data), (2 if per_sample_norm else 1) if has_pro else 0))
     if v == 1:
         return "thin_cin1_kernel"
     if v == 2:
         return "thin_cout1_kernel"
     cin_eff = g.cout if backward_data else g.cin
+    if v == 16:
+        cout_eff = g.cin if backward_data else g.cout
+        return f"gather_patch_kernel<{cin_eff}, {1 if has_pro else 0}, {'true' if cout_eff <= 16 else 'false'}>"
     tm, tn, wn = {128: (2, 2, 2), 64: (1, 2, 1), 32: (1, 1, 1)}[v]
     if cin_eff % 32 == 0 or cin_eff == 16:      # software-pipelined main kernel <BN, TM, TN, WN, WRAPS, PRO>
         pro = 0 if not has_pro else (2 if per_sample_norm else 1)
@@ -279,13 +288,19 @@ class NormBuf:
         return Prologue(self.scale, self.shift, self.c if self.instance else 0, act, slope, slope_t)
 
 
+def _gdesc(g: ConvGeom) -> str:
+    return (f"{g.cin}->{g.cout} k{'x'.join(map(str, g.k))} s{g.stride[-1]}{'T' if g.transposed else ''} "
+            f"in{'x'.join(map(str, g.in_dhw))}")
+
+
 def emit_conv_fwd(prog, g: ConvGeom, x, wp, bias, y, pro=None, resid=None, tanh=False, stats=None):
     ops._check_in_out(g, x, y, "plan conv_forward")
     gc = g.c()
     pc = pro.c() if pro is not None else None
     prog.add("conv_forward", lib().mpgan_conv_forward, C.byref(gc), x.data_ptr(), _ld(x), wp.data_ptr(), _p(bias),
              C.byref(pc) if pc is not None else None, _p(resid), _ld(resid), int(tanh), _p(stats), y.data_ptr(), _ld(y),
-             keep=(gc, pc, x, wp, bias, y, resid, pro), tag=(gather_kernel_name(g, False, pro is not None, bool(pro is not None and pro.n_stride)), 2.0 * conv_macs(g)))
+             keep=(gc, pc, x, wp, bias, y, resid, pro), desc=_gdesc(g),
+             tag=(gather_kernel_name(g, False, pro is not None, bool(pro is not None and pro.n_stride)), 2.0 * conv_macs(g)))
 
 
 def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):
@@ -293,7 +308,7 @@ def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):
     gc = g.c()
     prog.add("conv_backward_data", lib().mpgan_conv_backward_data, C.byref(gc), dy.data_ptr(), _ld(dy),
              wp_bwd.data_ptr(), _p(resid), _ld(resid), dx.data_ptr(), _ld(dx), keep=(gc, dy, wp_bwd, dx, resid),
-             tag=(gather_kernel_name(g, True, False), 2.0 * conv_macs(g)))
+             desc=_gdesc(g), tag=(gather_kernel_name(g, True, False), 2.0 * conv_macs(g)))
 
 
 def emit_conv_wgrad(prog, g: ConvGeom, x, dy, dw, ws, pro=None, dbias=None):
@@ -305,7 +320,7 @@ def emit_conv_wgrad(prog, g: ConvGeom, x, dy, dw, ws, pro=None, dbias=None):
     assert ws.numel() * 4 >= need, "wgrad workspace too small"
     prog.add("conv_backward_weight", lib().mpgan_conv_backward_weight, C.byref(gc), x.data_ptr(), _ld(x),
              C.byref(pc) if pc is not None else None, dy.data_ptr(), _ld(dy), dw.data_ptr(), _p(dbias), 1.0,
-             ws.data_ptr(), ws.numel() * 4, keep=(gc, pc, x, dy, dw, dbias, ws, pro),
+             ws.data_ptr(), ws.numel() * 4, keep=(gc, pc, x, dy, dw, dbias, ws, pro), desc=_gdesc(g),
              tag=("wgrad_kernel", 2.0 * conv_macs(g)))
 
 

@@ -110,8 +110,10 @@ int mpgan_conv_backward_data(const mpgan_conv_geom* g, const float* dy, int32_t 
                              float* dx, int32_t lddx, void* stream);
 
 /* Which kernel serves this geometry (for profiling labels): 1 = thin Cin==1 VALU
- * stencil, 2 = thin Cout==1 VALU stencil, 32/64/128 = fp32-MFMA implicit GEMM with
- * that output-channel tile. */
+ * stencil, 2 = thin Cout==1 VALU stencil, 16 = fp32-MFMA patch kernel (2-D, <= 32
+ * output channels, input patch + weights staged once in LDS), 32/64/128 = fp32-MFMA
+ * K-stepped implicit GEMM with that output-channel tile.
+ * has_prologue: 0 none, 1 per-channel scale/shift, 2 per-(sample, channel). */
 int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward_data, int32_t has_prologue);
 
 /* Weight gradient: dW (torch layout, (Cout,Cin,k..) or (Cin,Cout,k..) for a

@@ -239,3 +239,95 @@ def test_fused_batchnorm_statistics_from_conv_epilogue(cin, cout, k, s, p, spati
     assert_close(y, y_ref, rtol=1e-4, what="normalised output")
     assert_close(rmd.cpu(), rm, what="running_mean")
     assert_close(rvd.cpu(), rv, rtol=1e-4, what="running_var")
+
+
+# ---- patch kernel (2-D, <= 32 output channels, 16/32/64 gathered channels) ----------------
+PATCH_CASES = [
+    # cin, cout, k, s, p, spatial, transposed
+    (16, 16, 3, 1, 1, (37, 29), False),     # ragged tiles on both axes
+    (32, 32, 3, 1, 1, (16, 48), False),
+    (64, 32, 2, 1, 0, (11, 19), False),     # even kernel, no padding (3x3 at 64->32 exceeds the LDS budget: K-stepped kernel)
+    (16, 32, 3, 2, 1, (26, 34), False),     # stride-2 patch (input stride inside LDS)
+    (32, 24, 1, 1, 0, (9, 17), False),      # 1x1, Cout not a power of two
+    (64, 16, 3, 2, 1, (13, 9), True),       # transposed: 4 phases, odd extents
+    (32, 8, 3, 2, 1, (8, 16), True),
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: "{}to{}_k{}s{}p{}_{}".format(c[0], c[1], c[2], c[3], c[4], "T" if c[6] else "F"))
+def test_patch_kernel_forward_stats_prologue_and_dgrad(case):
+    """Layers the dispatcher hands to gather_patch_kernel: forward with the producer's
+    BatchNorm+PReLU prologue and fused statistics, plain forward + residual + tanh, and the
+    backward-data gather of a conv whose INPUT has <= 32 channels."""
+    import ctypes
+    from mpgan_amd import ops
+    from mpgan_amd._lib import lib
+    cin, cout, k, s, p, spatial, tr = case
+    n = 3
+    gen = torch.Generator().manual_seed(4242 + cin * 3 + cout)
+    z = torch.rand(n, cin, *spatial, generator=gen) * 2 - 1
+    sc, sh = torch.rand(cin, generator=gen) + 0.5, torch.rand(cin, generator=gen) - 0.5
+    alpha = 0.25
+    a = z * sc[None, :, None, None] + sh[None, :, None, None]
+    a = torch.where(a > 0, a, alpha * a)
+    if tr:
+        w = (torch.rand(cin, cout, k, k, generator=gen) * 2 - 1) / (cin * k * k) ** 0.5
+    else:
+        w = (torch.rand(cout, cin, k, k, generator=gen) * 2 - 1) / (cin * k * k) ** 0.5
+    b = torch.rand(cout, generator=gen) - 0.5
+    conv = (lambda t: F.conv_transpose2d(t, w, b, stride=s, padding=p, output_padding=s - 1)) if tr else \
+           (lambda t: F.conv2d(t, w, b, stride=s, padding=p))
+    g = _geom(2, n, cin, cout, k, s, p, spatial, transposed=tr)
+    gc = g.c()
+    assert lib().mpgan_conv_variant(ctypes.byref(gc), 0, 1) == 16, "expected the patch kernel for this geometry"
+    wp = ops.pack_weight(w.cuda(), transposed=tr)
+
+    # (1) prologue + fused statistics
+    y_ref = conv(a)
+    rows = ops.conv_stats_rows(g, True)
+    assert rows > 0
+    part = torch.full(((rows + 32) * 2 * cout,), float("nan"), device="cuda")
+    y = torch.full((n, *g.out_dhw, cout), float("nan"), device="cuda")
+    pro = ops.Prologue(sc.cuda(), sh.cuda(), 0, ops.ACT_LEAKY, 1.0, torch.tensor([alpha], device="cuda"))
+    ops.conv_forward(g, to_cl(z), wp, b.cuda(), y, pro=pro, stats_partials=part)
+    assert_close(from_cl(y, 2), y_ref, what="patch forward (prologue)")
+    sums = part[:rows * 2 * cout].reshape(rows, 2, cout).double().sum(0).cpu()
+    ref64 = y_ref.double()
+    assert_close(sums[0].float(), ref64.sum((0, 2, 3)).float(), rtol=1e-4, what="fused sum")
+    assert_close(sums[1].float(), (ref64 ** 2).sum((0, 2, 3)).float(), rtol=1e-4, what="fused sum of squares")
+
+    # (2) no prologue, residual + tanh, output into a channel slice
+    y0 = conv(z)
+    r = torch.rand(y0.shape, generator=gen) * 2 - 1
+    ybuf = torch.full((n, *g.out_dhw, cout + 8), float("nan"), device="cuda")
+    ops.conv_forward(g, to_cl(z), wp, b.cuda(), ybuf[..., 4:4 + cout], resid=to_cl(r), tanh_out=True)
+    assert_close(from_cl(ybuf[..., 4:4 + cout], 2), torch.tanh(y0 + r), what="patch forward (resid+tanh)")
+    assert torch.isnan(ybuf[..., :4]).all() and torch.isnan(ybuf[..., 4 + cout:]).all()
+
+    # (3) backward-data of the mirrored layer (gathers `cin` channels of dy, lands on `cout`)
+    if tr:
+        # dgrad of a ConvNd(cout -> cin, stride s) is this transposed gather
+        wf = ((torch.rand(cin, cout, k, k, generator=gen) * 2 - 1) / (cout * k * k) ** 0.5)
+        gf = _geom(2, n, cout, cin, k, s, p, g.out_dhw[1:])
+        if gf.out_dhw[1:] != tuple(spatial):
+            return
+        xf = torch.rand(n, cout, *g.out_dhw[1:], generator=gen).requires_grad_(True)
+        gy = torch.rand(n, cin, *spatial, generator=gen) * 2 - 1
+        F.conv2d(xf, wf, None, stride=s, padding=p).backward(gy)
+        gfc = gf.c()
+        assert lib().mpgan_conv_variant(ctypes.byref(gfc), 1, 0) == 16
+        dx = torch.full((n, *gf.in_dhw, cout), float("nan"), device="cuda")
+        ops.conv_backward_data(gf, to_cl(gy), ops.pack_weight(wf.cuda(), for_dgrad=True), dx)
+        assert_close(from_cl(dx, 2), xf.grad, what="patch dgrad (strided conv)")
+    elif s == 1:
+        wf = ((torch.rand(cin, cout, k, k, generator=gen) * 2 - 1) / (cout * k * k) ** 0.5)   # ConvNd(cout -> cin)
+        osp = tuple(v + 2 * p - k + 1 for v in spatial)
+        gf = _geom(2, n, cout, cin, k, 1, p, spatial)
+        xf = torch.rand(n, cout, *spatial, generator=gen).requires_grad_(True)
+        gy = torch.rand(n, cin, *osp, generator=gen) * 2 - 1
+        F.conv2d(xf, wf, None, stride=1, padding=p).backward(gy)
+        gfc = gf.c()
+        assert lib().mpgan_conv_variant(ctypes.byref(gfc), 1, 0) == 16
+        dx = torch.full((n, *gf.in_dhw, cout), float("nan"), device="cuda")
+        ops.conv_backward_data(gf, to_cl(gy), ops.pack_weight(wf.cuda(), for_dgrad=True), dx)
+        assert_close(from_cl(dx, 2), xf.grad, what="patch dgrad (stride 1)")

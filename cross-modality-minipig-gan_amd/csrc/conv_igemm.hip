@@ -119,46 +119,57 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
   const float* gres = p.resid;
   float* gout = p.out;
   const int ldo = p.ldo, ldr = p.ldr, tanh_out = p.tanh_out;
+  float bv[TN];
+  int cov[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    cov[tn] = n0 + (wn * TN + tn) * 32 + li;
+    bv[tn] = (p.bias && cov[tn] < Cout) ? p.bias[cov[tn]] : 0.f;
+  }
+  // row-major walk: the 64-bit pixel offset is formed once per row, not once per element
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int co = n0 + (wn * TN + tn) * 32 + li;
-      if (co >= Cout) continue;
-      const float bv = p.bias ? p.bias[co] : 0.f;
+    for (int r = 0; r < 16; ++r) {
+      const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int pix = rowpix[row];
+      if (pix < 0) continue;
+      float* orow = gout + (long)pix * ldo;
+      const float* rrow = gres ? gres + (long)pix * ldr : nullptr;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int pix = rowpix[row];
-        if (pix < 0) continue;
-        float v = acc[tm][tn][r] + bv;
-        if (gres) v += gres[(long)pix * ldr + co];
+      for (int tn = 0; tn < TN; ++tn) {
+        if (cov[tn] >= Cout) continue;
+        float v = acc[tm][tn][r] + bv[tn];
+        if (rrow) v += rrow[cov[tn]];
         if (tanh_out) v = tanhf(v);
-        gout[(long)pix * ldo + co] = v;
+        orow[cov[tn]] = v;
       }
     }
   if (p.stats) {
-    // Fused BatchNorm statistics: column sums of z = acc + bias over this tile's valid
-    // rows -- registers, then the two half-waves (shuffle), then the WM waves that share
-    // a column range (LDS, fixed order): deterministic, no atomics.
+    // Fused BatchNorm statistics of z = acc + bias over this tile's valid rows.  Rows without
+    // an output pixel carry acc == 0 exactly (their A rows are zero-filled), so the raw column
+    // sums S1 = sum(acc), S2 = sum(acc^2) need no row test; the bias enters in closed form,
+    //   sum(z) = S1 + nv*b,  sum(z^2) = S2 + 2*b*S1 + nv*b^2   (nv = rows with a pixel).
+    // Registers, then the two half-waves (shuffle), then the WM waves sharing a column range
+    // (LDS, fixed order): deterministic, no atomics.
     constexpr int WM = 4 / WN;
     float* st = lds + 1024;                 // [WM][2][BN], clear of rowpix
+    int* nvp = reinterpret_cast<int*>(lds) + 512;
+    if (tid < BM) {
+      const unsigned long long b = __ballot(rowpix[tid] >= 0);
+      if (lane == 0) nvp[wid] = __popcll(b);
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int col = (wn * TN + tn) * 32 + li;
-      const int co = n0 + col;
-      const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
       float sm = 0.f, sq = 0.f;
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (rowpix[row] >= 0) {
-            const float v = acc[tm][tn][r] + bv;
-            sm += v;
-            sq += v * v;
-          }
+          const float v = acc[tm][tn][r];
+          sm += v;
+          sq = fmaf(v, v, sq);
         }
       sm += __shfl_xor(sm, 32, 64);
       sq += __shfl_xor(sq, 32, 64);
@@ -175,9 +186,11 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
         sm += st[(w * 2 + 0) * BN + tid];
         sq += st[(w * 2 + 1) * BN + tid];
       }
+      const float nv = (float)(nvp[0] + nvp[1]);
+      const float b = p.bias ? p.bias[n0 + tid] : 0.f;
       float* row = p.stats + (long)stats_row * 2 * Cout;
-      row[n0 + tid] = sm;
-      row[Cout + n0 + tid] = sq;
+      row[n0 + tid] = sm + nv * b;
+      row[Cout + n0 + tid] = sq + b * (2.f * sm + nv * b);
     }
   }
 }
@@ -463,7 +476,8 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
 // normalise/mask + LDS stores with the MFMAs of group 3 (sched_group_barrier),
 // so a wave keeps the matrix pipe fed without relying on a partner wave.
 //   WRAPS : taps crossed per K-step (1 for Cin % 32 == 0, 32/Cin below 32)
-//   PRO   : 0 none, 1 per-channel scale/shift (BatchNorm), 2 per-(n,c) (InstanceNorm)
+//   PRO   : 0 none, 1 per-channel scale/shift (BatchNorm), 2 per-(n,c) (InstanceNorm),
+//           3 per-channel + LeakyReLU whose slope the host knows to lie in [0, 1]
 // ---------------------------------------------------------------------------
 template <int BN, int TM, int TN, int WN, int WRAPS, int PRO>
 __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv p) {
@@ -506,7 +520,11 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
   const float slope = PRO ? pro_slope(p.pro) : 1.f;
 
   const int cc = tid & 7, r0 = tid >> 3;
-  int rn[4], rz[4], ry[4], rx[4], rbase[4];
+  // Gathered rows of this thread.  All global addressing below is "uniform base + unsigned
+  // 32-bit BYTE offset" (host guarantees < 4 GiB per operand): one add per address, no
+  // 64-bit multiplies in the K-step.
+  int rn[4], rz[4], ry[4], rx[4];
+  unsigned rbB[4];                       // byte offset of (row pixel, channel 0)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const unsigned m = (unsigned)m0 + r0 + 32 * i;
@@ -524,42 +542,57 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
       rn[i] = 0;
       rz[i] = ry[i] = rx[i] = -(1 << 28);
     }
-    rbase[i] = ((rn[i] * Di + rz[i]) * Hi + ry[i]) * Wi + rx[i];
+    rbB[i] = (unsigned)(((rn[i] * Di + rz[i]) * Hi + ry[i]) * Wi + rx[i]) * (unsigned)ldi * 4u;
   }
-  // B rows of this thread: element offsets of (co, k = 0), clamped for co >= Cout
-  int wrow[BROWS];                       // packed weights hold < 2^31 floats (host-checked)
+  // B rows of this thread: byte offsets of (co, k = 0), clamped for co >= Cout
+  unsigned wrowB[BROWS];
   unsigned bvalid = 0;
 #pragma unroll
   for (int i = 0; i < BROWS; ++i) {
     const int co = n0 + r0 + 32 * i;
     const bool ok = co < Cout;
-    wrow[i] = ok ? co * (int)Ktot : 0;
+    wrowB[i] = ok ? (unsigned)co * (unsigned)Ktot * 4u : 0u;
     bvalid |= (ok ? 1u : 0u) << i;
   }
   const int ksz = p.kstep[0], ksy = p.kstep[1], ksx = p.kstep[2];
   const int dsz = p.dstep[0], dsy = p.dstep[1], dsx = p.dstep[2];
   const int Ky = p.Ky, Kx = p.Kx;
+  const char* __restrict__ ginb = reinterpret_cast<const char*>(gin);
+  const char* __restrict__ gwb = reinterpret_cast<const char*>(gw);
+  const char* __restrict__ gscb = reinterpret_cast<const char*>(gscale);
+  const char* __restrict__ gshb = reinterpret_cast<const char*>(gshift);
 
-  // cursor (branch-free advance)
-  int ci, jz, jy, jx, dz, dy, dx, delta, woff;
-  int cvalid;                             // 0/1 -- all predicates below are bitwise so the K-step stays ONE basic block
+  // K cursor.  WRAPS == 1 (Cin % 32 == 0): a K-step lies inside ONE tap, so the tap walk
+  // is wave-uniform and lives in scalar registers (SALU); only the channel differs per
+  // thread (uci + 4*cc).  WRAPS > 1: taps differ between the threads of a K-step.
+  constexpr bool UCUR = (WRAPS == 1);
+  int ci, jz, jy, jx, dz, dy, dx, woff;
+  int cmask;                              // -1 while the tap index is inside this phase's tap list, else 0
+  unsigned deltaB;                        // byte offset of the tap relative to the row's base pixel
   auto place = [&]() {
-    cvalid = jz < ph.nz ? 1 : 0;
+    cmask = jz < ph.nz ? -1 : 0;
     const int kz = ph.kz0 + ksz * jz, ky = ph.ky0 + ksy * jy, kx = ph.kx0 + ksx * jx;
     woff = ((kz * Ky + ky) * Kx + kx) * Cin;
     dz = ph.dz0 + dsz * jz;
     dy = ph.dy0 + dsy * jy;
     dx = ph.dx0 + dsx * jx;
-    delta = (dz * Hi + dy) * Wi + dx;
+    deltaB = (unsigned)((dz * Hi + dy) * Wi + dx) * (unsigned)ldi * 4u;
   };
   {
-    const int kidx = kt_begin * BK + cc * 4;
-    const int tap = kidx / Cin;
+    int kidx = kt_begin * BK;
+    if constexpr (!UCUR) kidx += cc * 4;
+    int tap = kidx / Cin;
     ci = kidx - tap * Cin;
     jx = tap % ph.nx;
     const int tq = tap / ph.nx;
     jy = tq % ph.ny;
     jz = tq / ph.ny;
+    if constexpr (UCUR) {                 // computed from block-uniform values: pin them to SGPRs
+      ci = __builtin_amdgcn_readfirstlane(ci);
+      jx = __builtin_amdgcn_readfirstlane(jx);
+      jy = __builtin_amdgcn_readfirstlane(jy);
+      jz = __builtin_amdgcn_readfirstlane(jz);
+    }
     place();
   }
   auto advance = [&]() {
@@ -567,13 +600,13 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
     for (int w = 0; w < WRAPS; ++w) {
       ci += BK / WRAPS;
       const int wc = ci >= Cin ? 1 : 0;
-      ci -= wc * Cin;
+      ci -= (-wc) & Cin;
       jx += wc;
       const int wx = jx == ph.nx ? 1 : 0;
-      jx -= wx * ph.nx;
+      jx -= (-wx) & ph.nx;
       jy += wx;
       const int wy = jy == ph.ny ? 1 : 0;
-      jy -= wy * ph.ny;
+      jy -= (-wy) & ph.ny;
       jz += wy;
     }
     place();
@@ -595,30 +628,31 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
     auto& rsc = S.rsc;
     auto& rsh = S.rsh;
     unsigned amask = 0;
-    S.kvalid = cvalid;
-    const int cis = cvalid * ci;          // clamp to channel 0 past the last tap (scale/shift/weight reads stay in range)
+    S.kvalid = cmask;
+    const int tci = UCUR ? ci + 4 * cc : ci;                 // this thread's channel
+    const unsigned cisB = (unsigned)(tci & cmask) * 4u;      // channel 0 past the last tap: reads stay in range
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int iz = rz[i] + dz, iy = ry[i] + dy, ix = rx[i] + dx;
-      const int ok = cvalid & ((unsigned)iz < (unsigned)Di ? 1 : 0) & ((unsigned)iy < (unsigned)Hi ? 1 : 0) &
-                     ((unsigned)ix < (unsigned)Wi ? 1 : 0);
-      const int pix = ok * (rbase[i] + delta);
-      const long off = (long)pix * ldi + ok * ci;
-      ra[i] = *reinterpret_cast<const float4*>(gin + off);
-      amask |= (unsigned)ok << i;
+      const int ok = ((unsigned)iz < (unsigned)Di ? cmask : 0) & ((unsigned)iy < (unsigned)Hi ? -1 : 0) &
+                     ((unsigned)ix < (unsigned)Wi ? -1 : 0);           // 0 / -1
+      const unsigned boff = (rbB[i] + deltaB + (unsigned)tci * 4u) & (unsigned)ok;
+      ra[i] = *reinterpret_cast<const float4*>(ginb + boff);
+      amask |= ((unsigned)ok & 1u) << i;
       if constexpr (PRO == 2) {
-        const int si = rn[i] * nstride + cis;
-        rsc[i] = *reinterpret_cast<const float4*>(gscale + si);
-        rsh[i] = *reinterpret_cast<const float4*>(gshift + si);
+        const unsigned sb = (unsigned)(rn[i] * nstride) * 4u + cisB;
+        rsc[i] = *reinterpret_cast<const float4*>(gscb + sb);
+        rsh[i] = *reinterpret_cast<const float4*>(gshb + sb);
       }
     }
-    if constexpr (PRO == 1) {
-      rsc[0] = *reinterpret_cast<const float4*>(gscale + cis);
-      rsh[0] = *reinterpret_cast<const float4*>(gshift + cis);
+    if constexpr (PRO == 1 || PRO == 3) {
+      rsc[0] = *reinterpret_cast<const float4*>(gscb + cisB);
+      rsh[0] = *reinterpret_cast<const float4*>(gshb + cisB);
     }
-    const int wk = cvalid * (woff + ci);
+    const unsigned wkB = (unsigned)(woff + tci) * 4u;
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const float4*>(gw + (cvalid * wrow[i] + wk));
+    for (int i = 0; i < BROWS; ++i)
+      rb[i] = *reinterpret_cast<const float4*>(gwb + ((wrowB[i] + wkB) & (unsigned)cmask));
     S.amask = amask;
     advance();
   };
@@ -635,7 +669,12 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = ra[i];
-      if constexpr (PRO != 0) {
+      if constexpr (PRO == 3) {           // LeakyReLU with a host-known slope in [0, 1]: max(y, slope*y), exact
+        const float4 sc = rsc[0], sh = rsh[0];
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
+        v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+      } else if constexpr (PRO != 0) {
         const float4 sc = rsc[PRO == 2 ? i : 0], sh = rsh[PRO == 2 ? i : 0];
         v.x = act_apply(v.x * sc.x + sh.x, act, slope);
         v.y = act_apply(v.y * sc.y + sh.y, act, slope);
@@ -649,7 +688,7 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
       float4 v = rb[i];
-      const bool ok = (kvalid & (int)((bvalid >> i) & 1u)) != 0;
+      const bool ok = (kvalid & (int)((bvalid >> i) & 1u)) != 0;   // kvalid is 0 / -1
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
       *reinterpret_cast<float4*>(Bs + (r0 + 32 * i) * PITCH + cc * 4) = v;
     }
@@ -1359,6 +1398,9 @@ static int launch_pipe_bn(const GatherConv& p, int variant, long maxM, hipStream
 template <int WRAPS>
 static int launch_pipe_pro(const GatherConv& p, int variant, long maxM, hipStream_t st) {
   if (!p.pro.scale) return launch_pipe_bn<WRAPS, 0>(p, variant, maxM, st);
+  if (p.pro.n_stride == 0 && p.pro.act == MPGAN_ACT_LEAKY && !p.pro.slope_ptr && p.pro.slope >= 0.f &&
+      p.pro.slope <= 1.f)
+    return launch_pipe_bn<WRAPS, 3>(p, variant, maxM, st);
   if (p.pro.n_stride == 0) return launch_pipe_bn<WRAPS, 1>(p, variant, maxM, st);
   return launch_pipe_bn<WRAPS, 2>(p, variant, maxM, st);
 }
@@ -1391,7 +1433,11 @@ static int launch_gather(const GatherConv& p, hipStream_t st) {
                                        reinterpret_cast<uintptr_t>(p.pro.shift)) & 15) == 0 &&
                                      p.pro.n_stride % 4 == 0));
   static const bool no_pipe = getenv("MPGAN_DBG_NO_PIPE") != nullptr;
-  if (vec && !no_pipe) {
+  // the pipelined kernel addresses each operand as base + unsigned 32-bit byte offset
+  const bool small = (long)p.N * p.Di * p.Hi * p.Wi * p.ldi * 4 < (1L << 32) &&
+                     (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 4 < (1L << 32) &&
+                     (long)p.N * (p.pro.n_stride > 0 ? p.pro.n_stride : 0) * 4 < (1L << 31);
+  if (vec && !no_pipe && small) {
     if (p.Cin % 32 == 0) return launch_pipe_pro<1>(p, variant, maxM, st);
     if (p.Cin == 16) return launch_pipe_pro<2>(p, variant, maxM, st);
   }

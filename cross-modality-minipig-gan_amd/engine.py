@@ -117,7 +117,8 @@ def conv_macs(g: ConvGeom) -> int:
     return g.n * grid[0] * grid[1] * grid[2] * g.cin * g.cout * g.taps
 
 
-def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_sample_norm: bool = False) -> str:
+def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_sample_norm: bool = False,
+                       fast_leaky: bool = False) -> str:
     """The kernel symbol (as rocprofv3 prints it, minus `void mpgan::` and the argument list)
     the C dispatcher picks for this conv (mpgan_conv_variant + launch_gather's rules)."""
     gc = g.c()
@@ -132,7 +133,7 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
         return f"gather_patch_kernel<{cin_eff}, {1 if has_pro else 0}, {'true' if cout_eff <= 16 else 'false'}>"
     tm, tn, wn = {128: (2, 2, 2), 64: (1, 2, 1), 32: (1, 1, 1)}[v]
     if cin_eff % 32 == 0 or cin_eff == 16:      # software-pipelined main kernel <BN, TM, TN, WN, WRAPS, PRO>
-        pro = 0 if not has_pro else (2 if per_sample_norm else 1)
+        pro = 0 if not has_pro else (2 if per_sample_norm else (3 if fast_leaky else 1))
         return f"gather_conv_pipe_kernel<{v}, {tm}, {tn}, {wn}, {1 if cin_eff % 32 == 0 else 2}, {pro}>"
     return f"gather_conv_kernel<{v}, {tm}, {tn}, {wn}, {'false' if cin_eff % 4 == 0 else 'true'}>"
 
@@ -288,6 +289,13 @@ class NormBuf:
         return Prologue(self.scale, self.shift, self.c if self.instance else 0, act, slope, slope_t)
 
 
+def _fast_leaky(pro) -> bool:
+    """launch_pipe_pro's rule for the max(y, slope*y) form: per-channel norm + LeakyReLU whose slope the
+    host knows (no device PReLU weight) to lie in [0, 1]."""
+    return bool(pro is not None and not pro.n_stride and pro.act == ACT_LEAKY and pro.slope_t is None
+                and 0.0 <= pro.slope <= 1.0)
+
+
 def _gdesc(g: ConvGeom) -> str:
     return (f"{g.cin}->{g.cout} k{'x'.join(map(str, g.k))} s{g.stride[-1]}{'T' if g.transposed else ''} "
             f"in{'x'.join(map(str, g.in_dhw))}")
@@ -300,7 +308,8 @@ def emit_conv_fwd(prog, g: ConvGeom, x, wp, bias, y, pro=None, resid=None, tanh=
     prog.add("conv_forward", lib().mpgan_conv_forward, C.byref(gc), x.data_ptr(), _ld(x), wp.data_ptr(), _p(bias),
              C.byref(pc) if pc is not None else None, _p(resid), _ld(resid), int(tanh), _p(stats), y.data_ptr(), _ld(y),
              keep=(gc, pc, x, wp, bias, y, resid, pro), desc=_gdesc(g),
-             tag=(gather_kernel_name(g, False, pro is not None, bool(pro is not None and pro.n_stride)), 2.0 * conv_macs(g)))
+             tag=(gather_kernel_name(g, False, pro is not None, bool(pro is not None and pro.n_stride),
+                                     _fast_leaky(pro)), 2.0 * conv_macs(g)))
 
 
 def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):

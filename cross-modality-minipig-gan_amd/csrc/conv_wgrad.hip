@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // tile kt+2 is loaded under the MFMAs of group 0, tile kt+1 goes to LDS under
 // group 3 (two register stages), exactly as gather_conv_pipe_kernel does.
 // ---------------------------------------------------------------------------
-template <int BD, int BG, int TM, int TN, int WN, int PRO>
+template <int BD, int BG, int TM, int TN, int WN, int PRO, bool PAD>
 __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int STAGE = WBK * (BD + BG);
@@ -298,6 +298,11 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
   constexpr int DLOADS = (WBK * DCH) / 256, GLOADS = (WBK * GCH) / 256;
   constexpr int DROWSTEP = 256 / DCH, GROWSTEP = 256 / GCH;
   constexpr int NMF = 4 * TM * TN;
+  // Row table (2 x 32 entries behind the two tile stages): for each of the 32 pixels of a
+  // K-step, the byte offset of its tap-(0,0,0) gathered pixel and (PAD) its gathered
+  // coordinates / (!PAD) its validity.  Filled once per row and K-step under the MFMAs of
+  // group 1; the 256 loaders then need one LDS read, one add and one mask per address.
+  int4* rtab = reinterpret_cast<int4*>(lds + 2 * STAGE);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -314,85 +319,93 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
   const int nk = mbeg < mend ? (int)((mend - mbeg + WBK - 1) / WBK) : 0;
   const float slope = PRO ? pro_slope(p.pro) : 1.f;
   const int act = p.pro.act;
-  const float* __restrict__ gd = p.dense;
-  const float* __restrict__ gg = p.gath;
-  const int ldd = p.ldd, ldg = p.ldg, Gz = p.Gz, Gy = p.Gy, Gx = p.Gx, Mx = p.Mx, My = p.My, Mz = p.Mz;
+  const char* __restrict__ gdb = reinterpret_cast<const char*>(p.dense);   // base + unsigned 32-bit byte offsets
+  const char* __restrict__ ggb = reinterpret_cast<const char*>(p.gath);    // (host: operands < 4 GiB)
+  const int ldd = p.ldd, ldg = p.ldg, Gz = p.Gz, Gy = p.Gy, Gx = p.Gx;
 
   // gathered operand: this thread's column chunk (tap, channel) is fixed for the block
   const int gcc = tid % GCH, grow0 = tid / GCH;
-  int gci, gkz, gky, gkx, gok;
+  int gci, gkz, gky, gkx, gokm;
   {
     const int col = c0 + gcc * 4;
-    gok = col < NC ? 1 : 0;
-    const int t = gok ? col / p.Cg : 0;
-    gci = gok ? col - t * p.Cg : 0;
+    gokm = col < NC ? -1 : 0;
+    const int t = gokm ? col / p.Cg : 0;
+    gci = gokm ? col - t * p.Cg : 0;
     gkx = t % p.Kx;
     const int q = t / p.Kx;
     gky = q % p.Ky;
     gkz = q / p.Ky;
   }
+  const unsigned tapB = (unsigned)(((gkz * Gy + gky) * Gx + gkx) * ldg + gci) * 4u;
   float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (PRO == 1) {          // per-channel scale/shift of this thread's channels: loaded once
+  if constexpr (PRO != 0) {          // per-channel scale/shift of this thread's channels: loaded once
     psc = *reinterpret_cast<const float4*>(p.pro.scale + gci);
     psh = *reinterpret_cast<const float4*>(p.pro.shift + gci);
   }
   const int dcc = tid % DCH, drow0 = tid / DCH;
   const int dcol = d0 + dcc * 4;
-  const int dok = dcol < p.Cd ? 1 : 0;
-
-  int cn[GLOADS], cz[GLOADS], cy[GLOADS], cx[GLOADS];
-#pragma unroll
-  for (int i = 0; i < GLOADS; ++i) {
-    const unsigned um = (unsigned)(mbeg + grow0 + GROWSTEP * i), uMx = Mx, uMy = My, uMz = Mz;
-    cx[i] = (int)(um % uMx);
-    unsigned q = um / uMx;
-    cy[i] = (int)(q % uMy);
-    q /= uMy;
-    cz[i] = (int)(q % uMz);
-    cn[i] = (int)(q / uMz);
-  }
-  int mrow = (int)(mbeg - 0);        // first pixel of the tile being loaded (32-bit: M < 2^31)
+  const int dokm = dcol < p.Cd ? -1 : 0;
   const int imend = (int)mend;
+  int mrow = (int)mbeg;              // first pixel of the tile being loaded (32-bit: M < 2^31)
+  unsigned dB = (unsigned)(((int)mbeg + drow0) * ldd + dcol) * 4u;
+  const unsigned dstepB = (unsigned)(WBK * ldd) * 4u, drowB = (unsigned)(DROWSTEP * ldd) * 4u;
+
+  auto fill_table = [&](int buf, int mt) {
+    const int r = tid & 31;          // 8 threads write the same entry with the same value
+    const unsigned m = (unsigned)(mt + r);
+    unsigned q, ux, uy, uz;
+    fdivmod_nb(m, p.fMx, q, ux);
+    fdivmod_nb(q, p.fMy, q, uy);
+    fdivmod_nb(q, p.fMz, q, uz);
+    const int iz0 = (int)uz * p.sz - p.pz, iy0 = (int)uy * p.sy - p.py, ix0 = (int)ux * p.sx - p.px;
+    const bool valid = (int)m < imend;
+    int4 e;
+    e.x = (int)((unsigned)((((int)q * Gz + iz0) * Gy + iy0) * Gx + ix0) * (unsigned)ldg * 4u);
+    if constexpr (PAD) {
+      e.y = valid ? iz0 : -(1 << 28);
+      e.z = iy0;
+      e.w = ix0;
+    } else {
+      e.y = valid ? -1 : 0;
+      e.z = 0;
+      e.w = 0;
+    }
+    rtab[buf * 32 + r] = e;
+  };
 
   struct Stage {
     float4 rd[DLOADS], rg[GLOADS];
-    unsigned gmask;
+    unsigned gmask, dmask;
   };
   Stage SX, SY;
   float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto issue_loads = [&](Stage& S) {
+  auto issue_loads = [&](Stage& S, int buf) {
+    unsigned dm = 0;
 #pragma unroll
     for (int i = 0; i < DLOADS; ++i) {
-      const int m = mrow + drow0 + DROWSTEP * i;
-      const int ok = (m < imend ? 1 : 0) & dok;
-      S.rd[i] = *reinterpret_cast<const float4*>(gd + ((long)(ok * m) * ldd + ok * dcol));
-      // rows past the chunk / channels past Cd are zeroed at the LDS store; bias sums use the masked value there
-      if (!ok) S.rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int ok = (mrow + drow0 + DROWSTEP * i) < imend ? dokm : 0;
+      S.rd[i] = *reinterpret_cast<const float4*>(gdb + ((dB + (unsigned)i * drowB) & (unsigned)ok));
+      dm |= ((unsigned)ok & 1u) << i;
     }
     unsigned gm = 0;
 #pragma unroll
     for (int i = 0; i < GLOADS; ++i) {
-      const int m = mrow + grow0 + GROWSTEP * i;
-      const int iz = cz[i] * p.sz - p.pz + gkz, iy = cy[i] * p.sy - p.py + gky, ix = cx[i] * p.sx - p.px + gkx;
-      const int ok = (m < imend ? 1 : 0) & gok & ((unsigned)iz < (unsigned)Gz ? 1 : 0) &
-                     ((unsigned)iy < (unsigned)Gy ? 1 : 0) & ((unsigned)ix < (unsigned)Gx ? 1 : 0);
-      const int pix = ok * (((cn[i] * Gz + iz) * Gy + iy) * Gx + ix);
-      S.rg[i] = *reinterpret_cast<const float4*>(gg + ((long)pix * ldg + ok * gci));
-      gm |= (unsigned)ok << i;
-      // advance the cursor by one K-step (32 pixels <= Mx: at most one carry per level)
-      cx[i] += WBK;
-      const int wx = cx[i] >= Mx ? 1 : 0;
-      cx[i] -= wx * Mx;
-      cy[i] += wx;
-      const int wy = cy[i] == My ? 1 : 0;
-      cy[i] -= wy * My;
-      cz[i] += wy;
-      const int wz = cz[i] == Mz ? 1 : 0;
-      cz[i] -= wz * Mz;
-      cn[i] += wz;
+      const int4 e = rtab[buf * 32 + grow0 + GROWSTEP * i];
+      int ok;
+      if constexpr (PAD) {
+        const int iz = e.y + gkz, iy = e.z + gky, ix = e.w + gkx;
+        ok = ((unsigned)iz < (unsigned)Gz ? gokm : 0) & ((unsigned)iy < (unsigned)Gy ? -1 : 0) &
+             ((unsigned)ix < (unsigned)Gx ? -1 : 0);
+      } else {
+        ok = e.y & gokm;
+      }
+      S.rg[i] = *reinterpret_cast<const float4*>(ggb + (((unsigned)e.x + tapB) & (unsigned)ok));
+      gm |= ((unsigned)ok & 1u) << i;
     }
     S.gmask = gm;
+    S.dmask = dm;
+    dB += dstepB;
     mrow += WBK;
   };
 
@@ -401,14 +414,20 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
     float* Gs = Ds + WBK * BD;
 #pragma unroll
     for (int i = 0; i < DLOADS; ++i) {
-      const float4 v = S.rd[i];
+      float4 v = S.rd[i];
+      const bool ok = (S.dmask >> i) & 1u;       // rows past the chunk / channels past Cd
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
       bacc.x += v.x; bacc.y += v.y; bacc.z += v.z; bacc.w += v.w;
       *reinterpret_cast<float4*>(Ds + (drow0 + DROWSTEP * i) * BD + dcc * 4) = v;
     }
 #pragma unroll
     for (int i = 0; i < GLOADS; ++i) {
       float4 v = S.rg[i];
-      if constexpr (PRO == 1) {
+      if constexpr (PRO == 3) {          // LeakyReLU, host-known slope in [0, 1]: max(y, slope*y), exact
+        v.x = v.x * psc.x + psh.x; v.y = v.y * psc.y + psh.y; v.z = v.z * psc.z + psh.z; v.w = v.w * psc.w + psh.w;
+        v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
+        v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+      } else if constexpr (PRO == 1) {
         v.x = act_apply(v.x * psc.x + psh.x, act, slope);
         v.y = act_apply(v.y * psc.y + psh.y, act, slope);
         v.z = act_apply(v.z * psc.z + psh.z, act, slope);
@@ -428,13 +447,21 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  int mtab = (int)mbeg + 3 * WBK;     // tile whose table entry the next K-step writes
   if (nk > 0) {
-    issue_loads(SX);
+    fill_table(0, (int)mbeg);
+    fill_table(1, (int)mbeg + WBK);
+    __syncthreads();
+    issue_loads(SX, 0);
     store_tile(0, SX);
-    issue_loads(SX);
+    issue_loads(SX, 1);
+    __syncthreads();                  // table 0 has been read by everyone
+    fill_table(0, (int)mbeg + 2 * WBK);
   }
   __syncthreads();
 
+  // K-step kt (LDS buffer cb = kt & 1): loads tile kt+2 through table[cb], writes the table of
+  // tile kt+3 into table[cb ^ 1] (last read one barrier ago).
   auto step = [&](int cb, Stage& Sn, const Stage& Sp) {
     const float* Ds = lds + cb * STAGE + wm * TM * 32 + li;
     const float* Gs = lds + cb * STAGE + WBK * BD + wn * TN * 32 + li;
@@ -455,7 +482,8 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
     for (int g = 0; g < 4; ++g) {
       const int sl = g & 1;
       if (g < 3) read_group(g + 1, sl ^ 1);
-      if (g == 0) issue_loads(Sn);
+      if (g == 0) issue_loads(Sn, cb);
+      if (g == 1) { fill_table(cb ^ 1, mtab); mtab += WBK; }
       if (g == 3) store_tile(cb ^ 1, Sp);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -469,14 +497,21 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
 #pragma unroll
         for (int i = 0; i < NMF; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x006, 13, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
+      } else if (g == 1) {
+#pragma unroll
+        for (int i = 0; i < NMF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);                     // row-table arithmetic
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
       } else if (g == 3) {
 #pragma unroll
         for (int i = 0; i < NMF; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x006, 11, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 9, 0);
           __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
       } else {
@@ -729,10 +764,10 @@ static int launch_wgrad_variant(const WgradParams& p, const WgradPlan& pl, hipSt
   return check_launch("wgrad");
 }
 
-template <int BD, int BG, int TM, int TN, int WN, int PRO>
+template <int BD, int BG, int TM, int TN, int WN, int PRO, bool PAD>
 static int launch_wgrad_pipe_variant(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
-  auto kern = wgrad_pipe_kernel<BD, BG, TM, TN, WN, PRO>;
-  constexpr int smem = 2 * WBK * (BD + BG) * (int)sizeof(float);
+  auto kern = wgrad_pipe_kernel<BD, BG, TM, TN, WN, PRO, PAD>;
+  constexpr int smem = 2 * WBK * (BD + BG) * (int)sizeof(float) + 2 * 32 * 16;   // + the row tables
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -748,16 +783,22 @@ static int launch_wgrad_pipe_variant(const WgradParams& p, const WgradPlan& pl, 
   return check_launch("wgrad_pipe");
 }
 
-// returns 1 if no pipelined instance covers this plan
+// PRO: 0 none, 1 per-channel norm + activation, 3 per-channel norm + LeakyReLU with a host-known
+// slope in [0, 1] (the discriminator's layers; 128 x 128 tiles only, as is the pad-free variant).
 template <int PRO>
 static int dispatch_wgrad_pipe(const WgradParams& p, const WgradPlan& pl, hipStream_t st, bool& handled) {
   handled = true;
-  if (pl.BD == 128 && pl.BG == 128) return launch_wgrad_pipe_variant<128, 128, 2, 2, 2, PRO>(p, pl, st);
-  if (pl.BD == 128 && pl.BG == 64) return launch_wgrad_pipe_variant<128, 64, 1, 2, 1, PRO>(p, pl, st);
-  if (pl.BD == 64 && pl.BG == 128) return launch_wgrad_pipe_variant<64, 128, 2, 1, 4, PRO>(p, pl, st);
-  if (pl.BD == 64 && pl.BG == 64) return launch_wgrad_pipe_variant<64, 64, 1, 1, 2, PRO>(p, pl, st);
-  if (pl.BD == 32 && pl.BG == 128) return launch_wgrad_pipe_variant<32, 128, 1, 1, 4, PRO>(p, pl, st);
-  if (pl.BD == 128 && pl.BG == 32) return launch_wgrad_pipe_variant<128, 32, 1, 1, 1, PRO>(p, pl, st);
+  const bool nopad = (p.pz | p.py | p.px) == 0;
+  constexpr int P1 = PRO == 3 ? 1 : PRO;
+  if (pl.BD == 128 && pl.BG == 128) {
+    if (nopad) return launch_wgrad_pipe_variant<128, 128, 2, 2, 2, PRO, false>(p, pl, st);
+    return launch_wgrad_pipe_variant<128, 128, 2, 2, 2, P1, true>(p, pl, st);
+  }
+  if (pl.BD == 128 && pl.BG == 64) return launch_wgrad_pipe_variant<128, 64, 1, 2, 1, P1, true>(p, pl, st);
+  if (pl.BD == 64 && pl.BG == 128) return launch_wgrad_pipe_variant<64, 128, 2, 1, 4, P1, true>(p, pl, st);
+  if (pl.BD == 64 && pl.BG == 64) return launch_wgrad_pipe_variant<64, 64, 1, 1, 2, P1, true>(p, pl, st);
+  if (pl.BD == 32 && pl.BG == 128) return launch_wgrad_pipe_variant<32, 128, 1, 1, 4, P1, true>(p, pl, st);
+  if (pl.BD == 128 && pl.BG == 32) return launch_wgrad_pipe_variant<128, 32, 1, 1, 1, P1, true>(p, pl, st);
   handled = false;
   return MPGAN_OK;
 }
@@ -890,8 +931,14 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
   int rc = MPGAN_OK;
   bool handled = false;
   static const bool no_pipe = getenv("MPGAN_DBG_NO_PIPE") != nullptr;
-  if (vd && vg && pl.kw == 1 && p.Mx >= WBK && p.pro.n_stride == 0 && !no_pipe) {
-    rc = p.pro.scale ? dispatch_wgrad_pipe<1>(p, pl, st, handled) : dispatch_wgrad_pipe<0>(p, pl, st, handled);
+  // the pipelined kernel addresses each operand as base + unsigned 32-bit byte offset
+  const bool small = (long)M * p.ldd * 4 < (1L << 32) && (long)p.N * p.Gz * p.Gy * p.Gx * p.ldg * 4 < (1L << 32);
+  if (vd && vg && pl.kw == 1 && small && p.pro.n_stride == 0 && !no_pipe) {
+    const bool fast_leaky = p.pro.scale && p.pro.act == MPGAN_ACT_LEAKY && !p.pro.slope_ptr && p.pro.slope >= 0.f &&
+                            p.pro.slope <= 1.f;
+    rc = !p.pro.scale ? dispatch_wgrad_pipe<0>(p, pl, st, handled)
+         : fast_leaky ? dispatch_wgrad_pipe<3>(p, pl, st, handled)
+                      : dispatch_wgrad_pipe<1>(p, pl, st, handled);
   }
   if (handled) { /* done */ }
   else if (vd && vg) rc = dispatch_wgrad<false, false>(p, pl, st);

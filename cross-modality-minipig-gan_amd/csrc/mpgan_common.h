@@ -112,6 +112,13 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
   const unsigned t = __umulhi(f.mul, n);
   return (((n - t) >> 1) + t) >> f.sh;
 }
+// branch-free form (keeps a software-pipelined K-step one basic block)
+__device__ __forceinline__ void fdivmod_nb(unsigned n, const FastDiv& f, unsigned& q, unsigned& r) {
+  const unsigned t = __umulhi(f.mul, n);
+  const unsigned qq = (((n - t) >> 1) + t) >> f.sh;
+  q = f.d == 1 ? n : qq;
+  r = n - q * f.d;
+}
 __device__ __forceinline__ void fdivmod(unsigned n, const FastDiv& f, unsigned& q, unsigned& r) {
   q = fdiv(n, f);
   r = n - q * f.d;

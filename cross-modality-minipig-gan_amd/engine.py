@@ -17,6 +17,7 @@ discriminator follows code/GAN/GAN_final.py:159-209.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -58,9 +59,30 @@ def set_probe(p: Optional[KernelProbe]):
     _PROBE = p
 
 
+_SIDE = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """The second HIP stream of this device: weight-gradient kernels of the generator run here,
+    next to the (latency-bound) norm-backward / backward-data chain on the caller's stream."""
+    key = torch.device(device).index or 0
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+_SINGLE_STREAM = bool(os.environ.get("MPGAN_SINGLE_STREAM"))
+
+
 class Program:
-    """A frozen list of C calls; `run` appends the stream and checks status."""
-    __slots__ = ("calls", "keep", "names", "tags", "descs")
+    """A frozen list of C calls; `run` appends the stream and checks status.
+
+    Calls carry a lane: 0 = the caller's stream, 1 = the side stream.  A lane-1 call first makes
+    the side stream wait for everything enqueued so far on the caller's stream (event), so it
+    may read anything produced before it; `join()` makes the caller's stream wait for the side
+    stream.  The emitter must place a join before any buffer a lane-1 call reads is rewritten
+    and before its results are consumed."""
+    __slots__ = ("calls", "keep", "names", "tags", "descs", "lanes", "events")
 
     def __init__(self):
         self.calls = []
@@ -68,13 +90,21 @@ class Program:
         self.names = []
         self.tags = []
         self.descs = []
+        self.lanes = []
+        self.events = {}
 
-    def add(self, name, fn, *args, keep=(), tag=None, desc=""):
+    def add(self, name, fn, *args, keep=(), tag=None, desc="", lane=0):
         self.calls.append((fn, args))
         self.names.append(name)
         self.keep.append(keep)
         self.tags.append(tag)
         self.descs.append(desc)
+        self.lanes.append(lane)
+
+    def join(self):
+        if self.calls and self.calls[-1][0] is None:
+            return
+        self.add("join", None)
 
     def extend(self, other: "Program"):
         self.calls += other.calls
@@ -82,30 +112,57 @@ class Program:
         self.keep += other.keep
         self.tags += other.tags
         self.descs += other.descs
+        self.lanes += other.lanes
+
+    def _event(self, i):
+        ev = self.events.get(i)
+        if ev is None:
+            ev = self.events[i] = torch.cuda.Event()
+        return ev
 
     def run(self, stream=None):
-        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        main = torch.cuda.current_stream()
+        s = main.cuda_stream if stream is None else stream
         probe = _PROBE
-        if probe is None:
-            for i, (fn, args) in enumerate(self.calls):
-                rc = fn(*args, s)
-                if rc:
-                    raise RuntimeError(f"{self.names[i]} failed (status {rc}): {lib().mpgan_last_error().decode()}")
-            return
+        lanes = self.lanes
+        multi = (stream is None and not _SINGLE_STREAM and not (probe is not None and probe.detail)
+                 and any(lanes))
+        side = side_stream(main.device) if multi else None
+        s1 = side.cuda_stream if multi else s
+        side_busy = False
         for i, (fn, args) in enumerate(self.calls):
+            if fn is None:                         # join
+                if side_busy:
+                    ev = self._event(i)
+                    ev.record(side)
+                    main.wait_event(ev)
+                    side_busy = False
+                continue
+            on_side = multi and lanes[i] == 1
+            if on_side:
+                ev = self._event(i)
+                ev.record(main)
+                side.wait_event(ev)
+                side_busy = True
             tag = self.tags[i]
-            if probe.detail:
-                tag = (f"{self.names[i]} {self.descs[i]}".strip(), tag[1] if tag else 0.0)
-            timed = tag is not None and (probe.want is None or tag[0] in probe.want)
+            timed = False
+            if probe is not None:
+                if probe.detail:
+                    tag = (f"{self.names[i]} {self.descs[i]}".strip(), tag[1] if tag else 0.0)
+                timed = tag is not None and (probe.want is None or tag[0] in probe.want) and not on_side
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            rc = fn(*args, s)
+            rc = fn(*args, s1 if on_side else s)
             if rc:
                 raise RuntimeError(f"{self.names[i]} failed (status {rc}): {lib().mpgan_last_error().decode()}")
             if timed:
                 e1.record()
                 probe.samples.append((tag[0], tag[1], e0, e1))
+        if side_busy:                              # never leave work un-joined behind a program
+            ev = self._event(-1)
+            ev.record(side)
+            main.wait_event(ev)
 
     def __len__(self):
         return len(self.calls)
@@ -301,7 +358,7 @@ def _gdesc(g: ConvGeom) -> str:
             f"in{'x'.join(map(str, g.in_dhw))}")
 
 
-def emit_conv_fwd(prog, g: ConvGeom, x, wp, bias, y, pro=None, resid=None, tanh=False, stats=None):
+def emit_conv_fwd(prog, g: ConvGeom, x, wp, bias, y, pro=None, resid=None, tanh=False, stats=None, lane=0):
     ops._check_in_out(g, x, y, "plan conv_forward")
     gc = g.c()
     pc = pro.c() if pro is not None else None
@@ -309,7 +366,7 @@ def emit_conv_fwd(prog, g: ConvGeom, x, wp, bias, y, pro=None, resid=None, tanh=
              C.byref(pc) if pc is not None else None, _p(resid), _ld(resid), int(tanh), _p(stats), y.data_ptr(), _ld(y),
              keep=(gc, pc, x, wp, bias, y, resid, pro), desc=_gdesc(g),
              tag=(gather_kernel_name(g, False, pro is not None, bool(pro is not None and pro.n_stride),
-                                     _fast_leaky(pro)), 2.0 * conv_macs(g)))
+                                     _fast_leaky(pro)), 2.0 * conv_macs(g)), lane=lane)
 
 
 def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):
@@ -320,7 +377,7 @@ def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):
              desc=_gdesc(g), tag=(gather_kernel_name(g, True, False), 2.0 * conv_macs(g)))
 
 
-def emit_conv_wgrad(prog, g: ConvGeom, x, dy, dw, ws, pro=None, dbias=None):
+def emit_conv_wgrad(prog, g: ConvGeom, x, dy, dw, ws, pro=None, dbias=None, lane=0):
     """dW += wgrad; for a ConvNd, dbias += colsum(dy) rides along in the same kernel."""
     ops._check_in_out(g, x, dy, "plan conv_backward_weight")
     gc = g.c()
@@ -330,7 +387,7 @@ def emit_conv_wgrad(prog, g: ConvGeom, x, dy, dw, ws, pro=None, dbias=None):
     prog.add("conv_backward_weight", lib().mpgan_conv_backward_weight, C.byref(gc), x.data_ptr(), _ld(x),
              C.byref(pc) if pc is not None else None, dy.data_ptr(), _ld(dy), dw.data_ptr(), _p(dbias), 1.0,
              ws.data_ptr(), ws.numel() * 4, keep=(gc, pc, x, dy, dw, dbias, ws, pro), desc=_gdesc(g),
-             tag=("wgrad_kernel", 2.0 * conv_macs(g)))
+             tag=("wgrad_kernel", 2.0 * conv_macs(g)), lane=lane)
 
 
 def emit_bias_grad(prog, dy, db, partials):
@@ -626,6 +683,8 @@ class UNetPlan:
             s = down_state[l]
             (cv0, N0, A0), (cv1, N1, A1) = s["ru"].units
             emit_conv_fwd_norm(f, s["g0"], s["xin"], wp(R(cv0)), cv0.bias, s["z0"], s["nb0"], N0, part, training=tr)
+            # (the residual conv could run on the side stream; measured: the event hand-offs cost more
+            #  than the ~20 us kernels they would overlap -- G forward 4.42 -> 4.56 ms)
             emit_conv_fwd(f, s["gr"], s["xin"], wp(R(s["ru"].res)), s["ru"].res.bias, s["r"])
             emit_conv_fwd_norm(f, s["g1"], s["z0"], wp(R(cv1)), cv1.bias, s["z1"], s["nb1"], N1, part,
                                pro=prelu_pro(s["nb0"], A0), training=tr)
@@ -658,6 +717,10 @@ class UNetPlan:
             return
 
         # ================= backward =================
+        # Weight gradients run on the side stream (lane 1): they only READ (activation, dz) pairs that
+        # nothing rewrites inside this U-Net's backward, and write parameter gradients / the shared
+        # split-K workspace that only lane 1 touches.  The gradient scratch below is shared with the
+        # next U-Net, hence the join at the end.
         G = a["gbufs"]                       # shared gradient scratch (see GeneratorPlan)
         gv = store.grad_view
         g_out, g_x = G["g_out"], G["g_x"]
@@ -670,16 +733,16 @@ class UNetPlan:
                 dzu, gta = G["dzu"][l], G["gta"][l]
                 emit_norm_bwd(b, g_u, u["zu"], u["nbu"], prelu_pro(u["nbu"], u["AU"]), dzu, part,
                               gv(u["NU"].weight), gv(u["NU"].bias), gv(u["AU"].weight))
-                emit_conv_wgrad(b, u["gu"], u["zt"], dzu, gv(u["cu"].weight), ws, pro=pt, dbias=gv(u["cu"].bias))
+                emit_conv_wgrad(b, u["gu"], u["zt"], dzu, gv(u["cu"].weight), ws, pro=pt, dbias=gv(u["cu"].bias), lane=1)
                 emit_conv_dgrad(b, u["gu"], dzu, wpb(R(u["cu"])), gta, resid=g_u)
             else:
                 gta = G["gta"][l]
-                emit_conv_wgrad(b, u["gu"], u["ua"], g_u, gv(u["cu"].weight), ws, dbias=gv(u["cu"].bias))
+                emit_conv_wgrad(b, u["gu"], u["ua"], g_u, gv(u["cu"].weight), ws, dbias=gv(u["cu"].bias), lane=1)
                 emit_conv_dgrad(b, u["gu"], g_u, wpb(R(u["cu"])), gta, resid=g_u)
             emit_norm_bwd(b, gta, u["zt"], u["nbt"], pt, gta, part, gv(u["NT"].weight), gv(u["NT"].bias),
                           gv(u["AT"].weight))
             emit_bias_grad(b, gta, gv(u["ct"].bias), part)
-            emit_conv_wgrad(b, u["gt"], cats[l], gta, gv(u["ct"].weight), ws)
+            emit_conv_wgrad(b, u["gt"], cats[l], gta, gv(u["ct"].weight), ws, lane=1)
             emit_conv_dgrad(b, u["gt"], gta, wpb(R(u["ct"])), G["gcat"][l])
         # ---- bottom ----
         gcat_last = G["gcat"][L - 2]
@@ -690,12 +753,12 @@ class UNetPlan:
         emit_norm_bwd(b, g_b, bt["zb1"], bt["nbb1"], prelu_pro(bt["nbb1"], bt["BA1"]), dzb1, part,
                       gv(bt["BN1"].weight), gv(bt["BN1"].bias), gv(bt["BA1"].weight))
         emit_conv_wgrad(b, bt["gb1"], bt["zb0"], dzb1, gv(bt["bc1"].weight), ws, pro=prelu_pro(bt["nbb0"], bt["BA0"]),
-                        dbias=gv(bt["bc1"].bias))
+                        dbias=gv(bt["bc1"].bias), lane=1)
         emit_conv_dgrad(b, bt["gb1"], dzb1, wpb(R(bt["bc1"])), gab0)
         emit_norm_bwd(b, gab0, bt["zb0"], bt["nbb0"], prelu_pro(bt["nbb0"], bt["BA0"]), gab0, part,
                       gv(bt["BN0"].weight), gv(bt["BN0"].bias), gv(bt["BA0"].weight))
-        emit_conv_wgrad(b, bt["gb0"], d_last, gab0, gv(bt["bc0"].weight), ws, dbias=gv(bt["bc0"].bias))
-        emit_conv_wgrad(b, bt["gbr"], d_last, g_b, gv(bt["res"].weight), ws, dbias=gv(bt["res"].bias))
+        emit_conv_wgrad(b, bt["gb0"], d_last, gab0, gv(bt["bc0"].weight), ws, dbias=gv(bt["bc0"].bias), lane=1)
+        emit_conv_wgrad(b, bt["gbr"], d_last, g_b, gv(bt["res"].weight), ws, dbias=gv(bt["res"].bias), lane=1)
         emit_conv_dgrad(b, bt["gb0"], gab0, wpb(R(bt["bc0"])), gd_last, resid=gd_last)
         emit_conv_dgrad(b, bt["gbr"], g_b, wpb(R(bt["res"])), gd_last, resid=gd_last)
         # ---- down path, bottom to top ----
@@ -707,12 +770,12 @@ class UNetPlan:
             emit_norm_bwd(b, g_d, s["z1"], s["nb1"], prelu_pro(s["nb1"], A1), dz1, part, gv(N1.weight), gv(N1.bias),
                           gv(A1.weight))
             emit_conv_wgrad(b, s["g1"], s["z0"], dz1, gv(cv1.weight), ws, pro=prelu_pro(s["nb0"], A0),
-                            dbias=gv(cv1.bias))
+                            dbias=gv(cv1.bias), lane=1)
             emit_conv_dgrad(b, s["g1"], dz1, wpb(R(cv1)), ga0)
             emit_norm_bwd(b, ga0, s["z0"], s["nb0"], prelu_pro(s["nb0"], A0), ga0, part, gv(N0.weight), gv(N0.bias),
                           gv(A0.weight))
-            emit_conv_wgrad(b, s["g0"], s["xin"], ga0, gv(cv0.weight), ws, dbias=gv(cv0.bias))
-            emit_conv_wgrad(b, s["gr"], s["xin"], g_d, gv(s["ru"].res.weight), ws, dbias=gv(s["ru"].res.bias))
+            emit_conv_wgrad(b, s["g0"], s["xin"], ga0, gv(cv0.weight), ws, dbias=gv(cv0.bias), lane=1)
+            emit_conv_wgrad(b, s["gr"], s["xin"], g_d, gv(s["ru"].res.weight), ws, dbias=gv(s["ru"].res.bias), lane=1)
             if l > 0:
                 tgt = G["gcat"][l - 1][..., :chans[l - 1]]
                 emit_conv_dgrad(b, s["g0"], ga0, wpb(R(cv0)), tgt, resid=tgt)
@@ -720,6 +783,7 @@ class UNetPlan:
             elif g_x is not None:
                 emit_conv_dgrad(b, s["g0"], ga0, wpb(R(cv0)), g_x)
                 emit_conv_dgrad(b, s["gr"], g_d, wpb(R(s["ru"].res)), g_x, resid=g_x)
+        b.join()
 
 
 class GeneratorPlan:
@@ -866,12 +930,13 @@ class DiscPlan:
             pro_in = lrelu(nbs[i - 1]) if i > 0 else None
             if want_param_grads:
                 emit_conv_wgrad(b, geoms[i], src, gas[i], gv(convs[i].weight), ws, pro=pro_in,
-                                dbias=gv(convs[i].bias))
+                                dbias=gv(convs[i].bias), lane=1)
             if i > 0:
                 emit_conv_dgrad(b, geoms[i], gas[i], store.wp_bwd(recs[i]), gas[i - 1])
             elif want_input_grad:
                 self.g_x = E(n, *dhw, 1)
                 emit_conv_dgrad(b, geoms[0], gas[0], store.wp_bwd(recs[0]), self.g_x)
+        b.join()
 
 
 # --------------------------------------------------------------------------

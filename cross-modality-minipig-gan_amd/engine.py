@@ -74,6 +74,15 @@ def side_stream(device) -> "torch.cuda.Stream":
 _SINGLE_STREAM = bool(os.environ.get("MPGAN_SINGLE_STREAM"))
 
 
+class Mark:
+    """A point on the side stream another program section can wait for."""
+    __slots__ = ("event", "armed")
+
+    def __init__(self):
+        self.event = torch.cuda.Event()
+        self.armed = False
+
+
 class Program:
     """A frozen list of C calls; `run` appends the stream and checks status.
 
@@ -102,9 +111,17 @@ class Program:
         self.lanes.append(lane)
 
     def join(self):
-        if self.calls and self.calls[-1][0] is None:
+        """The caller's stream waits for everything enqueued so far on the side stream."""
+        if self.calls and self.calls[-1] == (None, ("join",)):
             return
-        self.add("join", None)
+        self.add("join", None, "join")
+
+    def mark(self, m: "Mark"):
+        """Record `m` on the side stream here (a later `wait(m)` orders the caller's stream after it)."""
+        self.add("mark", None, "mark", m)
+
+    def wait(self, m: "Mark"):
+        self.add("wait", None, "wait", m)
 
     def extend(self, other: "Program"):
         self.calls += other.calls
@@ -130,20 +147,34 @@ class Program:
         side = side_stream(main.device) if multi else None
         s1 = side.cuda_stream if multi else s
         side_busy = False
+        main_dirty = True                          # the caller's stream has work the side stream has not waited for
         for i, (fn, args) in enumerate(self.calls):
-            if fn is None:                         # join
-                if side_busy:
-                    ev = self._event(i)
-                    ev.record(side)
-                    main.wait_event(ev)
-                    side_busy = False
+            if fn is None:                         # stream bookkeeping
+                kind = args[0]
+                if not multi:
+                    continue
+                if kind == "join":
+                    if side_busy:
+                        ev = self._event(i)
+                        ev.record(side)
+                        main.wait_event(ev)
+                        side_busy = False
+                elif kind == "mark":
+                    args[1].event.record(side)
+                    args[1].armed = True
+                elif args[1].armed:                # wait
+                    main.wait_event(args[1].event)
                 continue
             on_side = multi and lanes[i] == 1
             if on_side:
-                ev = self._event(i)
-                ev.record(main)
-                side.wait_event(ev)
+                if main_dirty:
+                    ev = self._event(i)
+                    ev.record(main)
+                    side.wait_event(ev)
+                    main_dirty = False
                 side_busy = True
+            else:
+                main_dirty = True
             tag = self.tags[i]
             timed = False
             if probe is not None:
@@ -543,7 +574,8 @@ class UNetPlan:
     """Forward/backward programs of one residual U-Net for a fixed input shape."""
 
     def __init__(self, unet, store: ParamStore, n: int, spatial: Sequence[int], x_in, y_out, *, tanh_out: bool,
-                 instance: bool, want_backward: bool, gbufs: Optional[dict], scratch: Scratch, training: bool = True):
+                 instance: bool, want_backward: bool, gbufs: Optional[dict], scratch: Scratch, training: bool = True,
+                 own_mark: Optional[Mark] = None, wait_mark: Optional[Mark] = None):
         self.unet, self.store, self.n = unet, store, n
         self.training = training
         dims = unet.dimensions
@@ -657,6 +689,7 @@ class UNetPlan:
             up_state.append(st)
         self._late = (down_state, up_state)
         self.scratch = scratch
+        self._marks = (own_mark, wait_mark)
         self._build_args = dict(x_in=x_in, y_out=y_out, tanh_out=tanh_out, want_backward=want_backward, gbufs=gbufs,
                                 chans=chans, L=L, sizes=sizes, in_ch=in_ch, sub_out=sub_out, cats=cats, R=R,
                                 bottom=dict(bc0=bc0, BN0=BN0, BA0=BA0, bc1=bc1, BN1=BN1, BA1=BA1, res=bottom.res,
@@ -717,10 +750,17 @@ class UNetPlan:
             return
 
         # ================= backward =================
-        # Weight gradients run on the side stream (lane 1): they only READ (activation, dz) pairs that
-        # nothing rewrites inside this U-Net's backward, and write parameter gradients / the shared
-        # split-K workspace that only lane 1 touches.  The gradient scratch below is shared with the
-        # next U-Net, hence the join at the end.
+        # Weight gradients run on the side stream (lane 1), all of them AFTER this U-Net's norm-backward /
+        # backward-data chain has been enqueued: they only read (activation, dz) pairs that nothing
+        # rewrites inside this U-Net's backward, and write parameter gradients / the split-K workspace
+        # that only lane 1 touches.  One event hands the whole batch over; it then runs next to the
+        # NEXT U-Net's chain, which works in the other set of gradient scratch (GeneratorPlan keeps two
+        # and rotates).  `wait_mark` orders this U-Net after the side-stream work of the U-Net that
+        # used the same set last.
+        own_mark, wait_mark = self._marks
+        bw = Program()
+        if wait_mark is not None:
+            b.wait(wait_mark)
         G = a["gbufs"]                       # shared gradient scratch (see GeneratorPlan)
         gv = store.grad_view
         g_out, g_x = G["g_out"], G["g_x"]
@@ -733,16 +773,16 @@ class UNetPlan:
                 dzu, gta = G["dzu"][l], G["gta"][l]
                 emit_norm_bwd(b, g_u, u["zu"], u["nbu"], prelu_pro(u["nbu"], u["AU"]), dzu, part,
                               gv(u["NU"].weight), gv(u["NU"].bias), gv(u["AU"].weight))
-                emit_conv_wgrad(b, u["gu"], u["zt"], dzu, gv(u["cu"].weight), ws, pro=pt, dbias=gv(u["cu"].bias), lane=1)
+                emit_conv_wgrad(bw, u["gu"], u["zt"], dzu, gv(u["cu"].weight), ws, pro=pt, dbias=gv(u["cu"].bias), lane=1)
                 emit_conv_dgrad(b, u["gu"], dzu, wpb(R(u["cu"])), gta, resid=g_u)
             else:
                 gta = G["gta"][l]
-                emit_conv_wgrad(b, u["gu"], u["ua"], g_u, gv(u["cu"].weight), ws, dbias=gv(u["cu"].bias), lane=1)
+                emit_conv_wgrad(bw, u["gu"], u["ua"], g_u, gv(u["cu"].weight), ws, dbias=gv(u["cu"].bias), lane=1)
                 emit_conv_dgrad(b, u["gu"], g_u, wpb(R(u["cu"])), gta, resid=g_u)
             emit_norm_bwd(b, gta, u["zt"], u["nbt"], pt, gta, part, gv(u["NT"].weight), gv(u["NT"].bias),
                           gv(u["AT"].weight))
             emit_bias_grad(b, gta, gv(u["ct"].bias), part)
-            emit_conv_wgrad(b, u["gt"], cats[l], gta, gv(u["ct"].weight), ws, lane=1)
+            emit_conv_wgrad(bw, u["gt"], cats[l], gta, gv(u["ct"].weight), ws, lane=1)
             emit_conv_dgrad(b, u["gt"], gta, wpb(R(u["ct"])), G["gcat"][l])
         # ---- bottom ----
         gcat_last = G["gcat"][L - 2]
@@ -752,13 +792,13 @@ class UNetPlan:
         dzb1, gab0 = G["dzb1"], G["gab0"]
         emit_norm_bwd(b, g_b, bt["zb1"], bt["nbb1"], prelu_pro(bt["nbb1"], bt["BA1"]), dzb1, part,
                       gv(bt["BN1"].weight), gv(bt["BN1"].bias), gv(bt["BA1"].weight))
-        emit_conv_wgrad(b, bt["gb1"], bt["zb0"], dzb1, gv(bt["bc1"].weight), ws, pro=prelu_pro(bt["nbb0"], bt["BA0"]),
+        emit_conv_wgrad(bw, bt["gb1"], bt["zb0"], dzb1, gv(bt["bc1"].weight), ws, pro=prelu_pro(bt["nbb0"], bt["BA0"]),
                         dbias=gv(bt["bc1"].bias), lane=1)
         emit_conv_dgrad(b, bt["gb1"], dzb1, wpb(R(bt["bc1"])), gab0)
         emit_norm_bwd(b, gab0, bt["zb0"], bt["nbb0"], prelu_pro(bt["nbb0"], bt["BA0"]), gab0, part,
                       gv(bt["BN0"].weight), gv(bt["BN0"].bias), gv(bt["BA0"].weight))
-        emit_conv_wgrad(b, bt["gb0"], d_last, gab0, gv(bt["bc0"].weight), ws, dbias=gv(bt["bc0"].bias), lane=1)
-        emit_conv_wgrad(b, bt["gbr"], d_last, g_b, gv(bt["res"].weight), ws, dbias=gv(bt["res"].bias), lane=1)
+        emit_conv_wgrad(bw, bt["gb0"], d_last, gab0, gv(bt["bc0"].weight), ws, dbias=gv(bt["bc0"].bias), lane=1)
+        emit_conv_wgrad(bw, bt["gbr"], d_last, g_b, gv(bt["res"].weight), ws, dbias=gv(bt["res"].bias), lane=1)
         emit_conv_dgrad(b, bt["gb0"], gab0, wpb(R(bt["bc0"])), gd_last, resid=gd_last)
         emit_conv_dgrad(b, bt["gbr"], g_b, wpb(R(bt["res"])), gd_last, resid=gd_last)
         # ---- down path, bottom to top ----
@@ -769,13 +809,13 @@ class UNetPlan:
             dz1, ga0 = G["dz1"][l], G["ga0"][l]
             emit_norm_bwd(b, g_d, s["z1"], s["nb1"], prelu_pro(s["nb1"], A1), dz1, part, gv(N1.weight), gv(N1.bias),
                           gv(A1.weight))
-            emit_conv_wgrad(b, s["g1"], s["z0"], dz1, gv(cv1.weight), ws, pro=prelu_pro(s["nb0"], A0),
+            emit_conv_wgrad(bw, s["g1"], s["z0"], dz1, gv(cv1.weight), ws, pro=prelu_pro(s["nb0"], A0),
                             dbias=gv(cv1.bias), lane=1)
             emit_conv_dgrad(b, s["g1"], dz1, wpb(R(cv1)), ga0)
             emit_norm_bwd(b, ga0, s["z0"], s["nb0"], prelu_pro(s["nb0"], A0), ga0, part, gv(N0.weight), gv(N0.bias),
                           gv(A0.weight))
-            emit_conv_wgrad(b, s["g0"], s["xin"], ga0, gv(cv0.weight), ws, dbias=gv(cv0.bias), lane=1)
-            emit_conv_wgrad(b, s["gr"], s["xin"], g_d, gv(s["ru"].res.weight), ws, dbias=gv(s["ru"].res.bias), lane=1)
+            emit_conv_wgrad(bw, s["g0"], s["xin"], ga0, gv(cv0.weight), ws, dbias=gv(cv0.bias), lane=1)
+            emit_conv_wgrad(bw, s["gr"], s["xin"], g_d, gv(s["ru"].res.weight), ws, dbias=gv(s["ru"].res.bias), lane=1)
             if l > 0:
                 tgt = G["gcat"][l - 1][..., :chans[l - 1]]
                 emit_conv_dgrad(b, s["g0"], ga0, wpb(R(cv0)), tgt, resid=tgt)
@@ -783,7 +823,11 @@ class UNetPlan:
             elif g_x is not None:
                 emit_conv_dgrad(b, s["g0"], ga0, wpb(R(cv0)), g_x)
                 emit_conv_dgrad(b, s["gr"], g_d, wpb(R(s["ru"].res)), g_x, resid=g_x)
-        b.join()
+        b.extend(bw)
+        if own_mark is not None:
+            b.mark(own_mark)
+        else:
+            b.join()
 
 
 class GeneratorPlan:
@@ -812,27 +856,32 @@ class GeneratorPlan:
                 sizes.append(tuple((s + 1) // 2 if i >= 3 - dims else s for i, s in enumerate(sizes[-1])))
             in_ch = [1] + chans[:L - 2]
             sub_out = [chans[l] for l in range(L - 2)] + [chans[L - 1]]
-            gb = dict(
-                gcat=[E(n, *sizes[l + 1], chans[l] + sub_out[l]) for l in range(L - 1)],
-                dzu=[E(n, *sizes[l], in_ch[l]) for l in range(L - 1)],
-                gta=[E(n, *sizes[l], in_ch[l]) for l in range(L - 1)],
-                dz1=[E(n, *sizes[l + 1], chans[l]) for l in range(L - 1)],
-                ga0=[E(n, *sizes[l + 1], chans[l]) for l in range(L - 1)],
-                dzb1=E(n, *sizes[L - 1], chans[L - 1]), gab0=E(n, *sizes[L - 1], chans[L - 1]))
-            self.g_acts = [E(n, *dhw, 1) for _ in range(2)]
+            def grad_scratch():
+                return dict(
+                    gcat=[E(n, *sizes[l + 1], chans[l] + sub_out[l]) for l in range(L - 1)],
+                    dzu=[E(n, *sizes[l], in_ch[l]) for l in range(L - 1)],
+                    gta=[E(n, *sizes[l], in_ch[l]) for l in range(L - 1)],
+                    dz1=[E(n, *sizes[l + 1], chans[l]) for l in range(L - 1)],
+                    ga0=[E(n, *sizes[l + 1], chans[l]) for l in range(L - 1)],
+                    dzb1=E(n, *sizes[L - 1], chans[L - 1]), gab0=E(n, *sizes[L - 1], chans[L - 1]))
+            # two sets, rotated: U-Net u's weight gradients (side stream) still read set u % 2 while
+            # U-Net u-1's chain fills the other one
+            gb = [grad_scratch(), grad_scratch()]
+            self.g_acts = [E(n, *dhw, 1) for _ in range(len(unets) + 1)]   # dL/d(acts[u]); never shared
             self.g_y = E(n, *dhw, 1)          # upstream gradient dL/dy is copied here
         self.unet_plans: List[UNetPlan] = []
         nU = len(unets)
+        marks = [Mark() for _ in range(nU)]
         for u, unet in enumerate(unets):
             g = None
             if want_backward:
-                g = dict(gb)
-                # ping-pong: U-Net u reads g_acts[(u+1)%2] (grad of its output), writes g_acts[u%2]
-                g["g_out"] = self.g_acts[(u + 1) % 2]
-                g["g_x"] = self.g_acts[u % 2] if (u > 0 or want_input_grad) else None
+                g = dict(gb[u % 2])
+                g["g_out"] = self.g_acts[u + 1]
+                g["g_x"] = self.g_acts[u] if (u > 0 or want_input_grad) else None
             self.unet_plans.append(UNetPlan(unet, store, n, spatial, self.acts[u], self.acts[u + 1],
                                             tanh_out=(u == nU - 1), instance=instance, want_backward=want_backward,
-                                            gbufs=g, scratch=self.scratch, training=training))
+                                            gbufs=g, scratch=self.scratch, training=training,
+                                            own_mark=marks[u], wait_mark=marks[u + 2] if u + 2 < nU else None))
         self.scratch.alloc()
         for p in self.unet_plans:
             p.emit()
@@ -843,11 +892,12 @@ class GeneratorPlan:
         self.bwd = Program()
         if want_backward:
             L_ = lib()
-            last = self.g_acts[nU % 2]        # = g_out of the last U-Net
+            last = self.g_acts[nU]            # = g_out of the last U-Net
             self.bwd.add("tanh_backward", L_.mpgan_tanh_backward, self.g_y.data_ptr(), self.y.data_ptr(),
                          self.y.numel(), last.data_ptr(), keep=(self.g_y, self.y, last))
             for p in reversed(self.unet_plans):
                 self.bwd.extend(p.bwd)
+            self.bwd.join()                   # parameter gradients are complete when the program returns
             self.g_x = self.g_acts[0] if want_input_grad else None
         self.busy = False
 

@@ -853,6 +853,68 @@ __global__ __launch_bounds__(256) void thin_cin1_kernel(const GatherConv p) {
     for (int e = 0; e < V && co + e < p.Cout; ++e) o[e] = acc[e];
 }
 
+// Cin == 1, Cout = 4*CQ <= 64: one thread = one output pixel x ALL output channels.  The input
+// sample of a tap is loaded once and meets the tap's whole weight row, read from LDS at a
+// wave-uniform address (broadcast); a thread stores 16*CQ contiguous bytes, a wave a contiguous run.
+template <int CQ>
+__global__ __launch_bounds__(256) void thin_cin1_full_kernel(const GatherConv p) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [T][4*CQ]
+  constexpr int CO = 4 * CQ;
+  const Phase ph = p.ph[blockIdx.z];
+  const int T = p.Kz * p.Ky * p.Kx;
+  for (int i = threadIdx.x; i < T * CO; i += 256) {
+    const int t = i / CO, co = i - t * CO;
+    wl[i] = p.wp[(long)co * T + t];
+  }
+  __syncthreads();
+  const unsigned Mtot = (unsigned)p.N * ph.Mz * ph.My * ph.Mx;
+  const unsigned m = blockIdx.x * 256u + threadIdx.x;
+  if (m >= Mtot) return;
+  const PixDecode d = decode_pixel(p, ph, m);
+  if (d.opix < 0) return;
+  float4 acc[CQ];
+#pragma unroll
+  for (int q = 0; q < CQ; ++q)
+    acc[q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* __restrict__ gin = p.in;
+  const int ldi = p.ldi;
+  for (int jz = 0; jz < ph.nz; ++jz) {
+    const int iz = d.bz + ph.dz0 + p.dstep[0] * jz, kz = ph.kz0 + p.kstep[0] * jz;
+    if ((unsigned)iz >= (unsigned)p.Di) continue;
+    for (int jy = 0; jy < ph.ny; ++jy) {
+      const int iy = d.by + ph.dy0 + p.dstep[1] * jy, ky = ph.ky0 + p.kstep[1] * jy;
+      if ((unsigned)iy >= (unsigned)p.Hi) continue;
+      const int rowbase = ((d.n * p.Di + iz) * p.Hi + iy) * p.Wi;
+      for (int jx = 0; jx < ph.nx; ++jx) {
+        const int ix = d.bx + ph.dx0 + p.dstep[2] * jx, kx = ph.kx0 + p.kstep[2] * jx;
+        if ((unsigned)ix >= (unsigned)p.Wi) continue;
+        const float x = gin[(long)(rowbase + ix) * ldi];
+        const float4* w = reinterpret_cast<const float4*>(wl + ((kz * p.Ky + ky) * p.Kx + kx) * CO);
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+          const float4 wv = w[q];
+          acc[q].x = fmaf(x, wv.x, acc[q].x);
+          acc[q].y = fmaf(x, wv.y, acc[q].y);
+          acc[q].z = fmaf(x, wv.z, acc[q].z);
+          acc[q].w = fmaf(x, wv.w, acc[q].w);
+        }
+      }
+    }
+  }
+  float* o = p.out + (long)d.opix * p.ldo;
+  const float* r = p.resid ? p.resid + (long)d.opix * p.ldr : nullptr;
+#pragma unroll
+  for (int q = 0; q < CQ; ++q) {
+    float4 v = acc[q];
+    if (r) {
+      const float4 rv = *reinterpret_cast<const float4*>(r + 4 * q);
+      v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+    }
+    if (p.tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+    *reinterpret_cast<float4*>(o + 4 * q) = v;
+  }
+}
+
 // Cout == 1: LANES = Cin/4 lanes share one output pixel (16-byte channel chunks,
 // coalesced rows), then a shuffle reduction.
 template <int LANES>
@@ -900,6 +962,77 @@ __global__ __launch_bounds__(256) void thin_cout1_kernel(const GatherConv p) {
   }
 }
 
+// ConvTranspose2d(Cin -> 1, k3 s2 p1, output_padding 1) forward -- the U-Net's last up-conv.
+// LANES = Cin/4 lanes share one INPUT pixel (y, x): its 2x2 neighbourhood is loaded once
+// (16-byte channel chunks, coalesced) and produces the 2x2 output quad (2y+a, 2x+b) = all
+// four phases; the lane partials are folded with a transposing butterfly (4-5 shuffles).
+template <int LANES>
+__global__ __launch_bounds__(256) void convt_quad_cout1_kernel(const GatherConv p) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [9][Cin]
+  const int Cin = p.Cin;
+  for (int i = threadIdx.x; i < 9 * Cin; i += 256) wl[i] = p.wp[i];
+  __syncthreads();
+  const Phase& ph = p.ph[0];                      // phase (0,0): m-grid == input grid
+  const unsigned Mtot = (unsigned)p.N * p.Hi * p.Wi;
+  const unsigned gi = blockIdx.x * 256u + threadIdx.x;
+  const unsigned m = gi / LANES;
+  const int l = (int)(gi % LANES);
+  const bool live = m < Mtot;
+  unsigned q, ux, uy;
+  fdivmod(live ? m : 0u, ph.fMx, q, ux);
+  fdivmod(q, ph.fMy, q, uy);
+  const int n = (int)q, y = (int)uy, x = (int)ux;
+  const float* base = p.in + ((long)(n * p.Hi + y) * p.Wi + x) * p.ldi + 4 * l;
+  const bool y1 = y + 1 < p.Hi, x1 = x + 1 < p.Wi;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 v00 = live ? *reinterpret_cast<const float4*>(base) : z4;
+  const float4 v01 = live && x1 ? *reinterpret_cast<const float4*>(base + p.ldi) : z4;
+  const float4 v10 = live && y1 ? *reinterpret_cast<const float4*>(base + (long)p.Wi * p.ldi) : z4;
+  const float4 v11 = live && y1 && x1 ? *reinterpret_cast<const float4*>(base + (long)(p.Wi + 1) * p.ldi) : z4;
+  auto W = [&](int ky, int kx) { return *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * Cin + 4 * l); };
+  auto dot = [](const float4& a, const float4& b, float acc) {
+    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); return fmaf(a.w, b.w, acc);
+  };
+  // out[o] = sum_k in[(o + 1 - k) / 2] * w[k]:  even o <- (i=o/2, k=1);  odd o <- (i+1, k=0) + (i, k=2)
+  float o00 = dot(v00, W(1, 1), 0.f);
+  float o01 = dot(v01, W(1, 0), dot(v00, W(1, 2), 0.f));
+  float o10 = dot(v10, W(0, 1), dot(v00, W(2, 1), 0.f));
+  float o11 = dot(v11, W(0, 0), dot(v10, W(0, 2), dot(v01, W(2, 0), dot(v00, W(2, 2), 0.f))));
+  // transposing butterfly: after it lane (l & 3) = 2*b + a holds output (2y+a, 2x+b) summed over all lanes
+  const bool b0 = l & 1, b1 = l & 2;
+  const float r0 = (b0 ? o10 : o00) + __shfl_xor(b0 ? o00 : o10, 1, 64);
+  const float r1 = (b0 ? o11 : o01) + __shfl_xor(b0 ? o01 : o11, 1, 64);
+  float t = (b1 ? r1 : r0) + __shfl_xor(b1 ? r0 : r1, 2, 64);
+#pragma unroll
+  for (int off = 4; off < LANES; off <<= 1) t += __shfl_xor(t, off, 64);
+  if (live && l < 4) {
+    const int oy = 2 * y + (l & 1), ox = 2 * x + (l >> 1);
+    if (oy < p.Ho && ox < p.Wo) {
+      const long pix = ((long)n * p.Ho + oy) * p.Wo + ox;
+      float v = t + (p.bias ? p.bias[0] : 0.f);
+      if (p.resid) v += p.resid[pix * p.ldr];
+      if (p.tanh_out) v = tanhf(v);
+      p.out[pix * p.ldo] = v;
+    }
+  }
+}
+
+static bool convt_quad_ok(const GatherConv& p) {
+  const int lanes = p.Cin / 4;
+  if (!(p.Cout == 1 && !p.pro.scale && p.Cin % 4 == 0 && p.ldi % 4 == 0 && (lanes == 4 || lanes == 8 || lanes == 16) &&
+        ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0)))
+    return false;
+  if (!(p.nphase == 4 && p.Di == 1 && p.Do == 1 && p.Kz == 1 && p.Ky == 3 && p.Kx == 3 && p.ostride[1] == 2 &&
+        p.ostride[2] == 2 && p.istride[1] == 1 && p.istride[2] == 1 && p.dstep[1] == -1 && p.dstep[2] == -1))
+    return false;
+  const Phase& a = p.ph[0];
+  const Phase& d = p.ph[3];
+  // k3 s2 p1: phase (0,0) = tap k=1 at offset 0; phase (1,1) = taps k=0 (offset +1), k=2 (offset 0)
+  return a.My == p.Hi && a.Mx == p.Wi && a.ny == 1 && a.nx == 1 && a.ky0 == 1 && a.kx0 == 1 && a.dy0 == 0 &&
+         a.dx0 == 0 && d.ny == 2 && d.nx == 2 && d.ky0 == 0 && d.kx0 == 0 && d.dy0 == 1 && d.dx0 == 1 &&
+         p.Ho <= 2 * p.Hi && p.Wo <= 2 * p.Wi;
+}
+
 static bool thin_cin1_ok(const GatherConv& p) {
   const int T = p.Kz * p.Ky * p.Kx;
   return p.Cin == 1 && !p.pro.scale && (long)T * ((p.Cout + 3) / 4 * 4) * 4 <= 48 * 1024;
@@ -917,6 +1050,17 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
   const int T = p.Kz * p.Ky * p.Kx;
   if (thin_cin1_ok(p)) {
     const bool v4 = (p.Cout % 4 == 0) && (p.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+    const bool full = v4 && (p.Cout == 16 || p.Cout == 32 || p.Cout == 64) &&
+                      (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) &&
+                      (!p.resid || ((p.ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0));
+    if (full) {
+      dim3 grid((unsigned)((maxM + 255) / 256), 1, (unsigned)p.nphase);
+      const size_t smem = (size_t)T * p.Cout * sizeof(float);
+      if (p.Cout == 16) hipLaunchKernelGGL(thin_cin1_full_kernel<4>, grid, dim3(256), smem, st, p);
+      else if (p.Cout == 32) hipLaunchKernelGGL(thin_cin1_full_kernel<8>, grid, dim3(256), smem, st, p);
+      else hipLaunchKernelGGL(thin_cin1_full_kernel<16>, grid, dim3(256), smem, st, p);
+      return check_launch("thin_cin1_full");
+    }
     const int V = v4 ? 4 : 1;
     const int CQ = (p.Cout + V - 1) / V;
     const long threads = maxM * CQ;
@@ -927,6 +1071,15 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
     return check_launch("thin_cin1");
   }
   const int lanes = p.Cin / 4;
+  if (convt_quad_ok(p)) {
+    const long qthreads = (long)p.N * p.Hi * p.Wi * lanes;
+    dim3 qgrid((unsigned)((qthreads + 255) / 256));
+    const size_t qsmem = (size_t)9 * p.Cin * sizeof(float);
+    if (lanes == 4) hipLaunchKernelGGL(convt_quad_cout1_kernel<4>, qgrid, dim3(256), qsmem, st, p);
+    else if (lanes == 8) hipLaunchKernelGGL(convt_quad_cout1_kernel<8>, qgrid, dim3(256), qsmem, st, p);
+    else hipLaunchKernelGGL(convt_quad_cout1_kernel<16>, qgrid, dim3(256), qsmem, st, p);
+    return check_launch("convt_quad_cout1");
+  }
   const long threads = maxM * lanes;
   dim3 grid((unsigned)((threads + 255) / 256), 1, (unsigned)p.nphase);
   const size_t smem = (size_t)T * p.Cin * sizeof(float);

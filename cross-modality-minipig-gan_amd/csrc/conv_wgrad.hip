@@ -689,9 +689,22 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p) {
   }
   __syncthreads();
   float* out = p.partial + (long)blockIdx.x * p.Cd * T;
+  // fold the PL lane rows: narrow rows (few channels) are first folded by G row groups in parallel
+  const int G = W < 128 ? 256 / W : 1;
+  if (G > 1) {
+    const int i = threadIdx.x % W, g = threadIdx.x / W;
+    const int GR = G < PL ? G : PL;
+    float s1 = 0.f;
+    if (g < GR)
+      for (int r = g; r < PL; r += GR) s1 += red[r * W + i];
+    __syncthreads();
+    if (g < GR) red[g * W + i] = s1;
+    __syncthreads();
+  }
+  const int rows = G > 1 ? (G < PL ? G : PL) : PL;
   for (int i = threadIdx.x; i < W; i += 256) {
     float s2 = 0.f;
-    for (int r = 0; r < PL; ++r) s2 += red[r * W + i];
+    for (int r = 0; r < rows; ++r) s2 += red[r * W + i];
     if (i < p.Cd * T) out[i] = s2;
     else if (p.bias_partial) p.bias_partial[(long)blockIdx.x * p.Cd + (i - p.Cd * T)] = s2;
   }
@@ -701,7 +714,10 @@ struct ThinWgradPlan { int blocks; long chunk; bool ok; };
 static ThinWgradPlan plan_thin_wgrad(int Cd, int Cg, int T, long M, bool has_pro) {
   ThinWgradPlan t;
   t.ok = Cg == 1 && !has_pro && Cd <= 64 && (T == 1 || T == 9 || T == 27);   // kernel shape checked by the caller
-  long blocks = (M + 2047) / 2048;
+  // latency-bound pixel walk: short chunks keep every CU busy, but each block pays a fixed LDS fold
+  // and adds a slab to the reducer (measured: 256-pixel chunks are slower than 2048-pixel ones)
+  const long per = Cd * T < 64 ? 2048 : 1024;    // a handful of outputs: fewer, longer walks
+  long blocks = (M + per - 1) / per;
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   t.chunk = (M + blocks - 1) / blocks;

@@ -36,6 +36,8 @@ CONVT_CASES = [
     (2, 192, 32, (6, 5), 2),
     (2, 64, 16, (10, 12), 2),
     (2, 32, 1, (12, 10), 3),
+    (2, 16, 1, (7, 9), 2),                 # quad kernel, 4 lanes per pixel, odd extents
+    (2, 64, 1, (5, 6), 2),                 # 16 lanes per pixel
     (3, 192, 32, (3, 4, 5), 1),
     (3, 32, 1, (5, 4, 6), 2),
 ]

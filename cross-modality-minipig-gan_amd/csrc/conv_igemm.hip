@@ -48,6 +48,7 @@ struct GatherConv {
   int ostride[3], istride[3], kstep[3], dstep[3];
   int nphase, tanh_out;
   int mtiles, ntiles;   // 1-D launch of ksplit*nphase*mtiles*ntiles blocks, XCD-remapped, n-tile fastest
+  int phase_outer;      // block order: 1 = phase slowest, 0 = phases of an m-tile adjacent (see conv_block_id)
   int ksplit;           // > 1: each block covers a K slice and leaves raw partial sums in kpartial
   float* kpartial;      // [ksplit][N*Do*Ho*Wo][Cout]
   Phase ph[8];
@@ -57,12 +58,24 @@ struct BlockId { int mt, nt, phase, split; };
 __device__ __forceinline__ BlockId conv_block_id(const GatherConv& p) {
   const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
   BlockId b;
+  // n-tile fastest, then phase, then m-tile: the phases of a strided backward-data gather read the
+  // SAME dy pixels (different taps), so they sit next to each other in the work order -- same XCD,
+  // same time, one fetch into its L2 instead of one per phase.
+  // When the whole weight tensor would crowd a 4 MiB L2 (each phase only touches its own taps'
+  // share of it) the phases run one after another instead (phase_outer).
   b.nt = (int)(w % (unsigned)p.ntiles);
   unsigned q = w / (unsigned)p.ntiles;
-  b.mt = (int)(q % (unsigned)p.mtiles);
-  q /= (unsigned)p.mtiles;
-  b.phase = (int)(q % (unsigned)p.nphase);
-  b.split = (int)(q / (unsigned)p.nphase);
+  if (p.phase_outer) {
+    b.mt = (int)(q % (unsigned)p.mtiles);
+    q /= (unsigned)p.mtiles;
+    b.phase = (int)(q % (unsigned)p.nphase);
+    b.split = (int)(q / (unsigned)p.nphase);
+  } else {
+    b.phase = (int)(q % (unsigned)p.nphase);
+    q /= (unsigned)p.nphase;
+    b.mt = (int)(q % (unsigned)p.mtiles);
+    b.split = (int)(q / (unsigned)p.mtiles);
+  }
   return b;
 }
 
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
   int cmask;                              // -1 while the tap index is inside this phase's tap list, else 0
   unsigned deltaB;                        // byte offset of the tap relative to the row's base pixel
   auto place = [&]() {
-    cmask = jz < ph.nz ? -1 : 0;
+    cmask = UCUR ? (ci < Cin ? -1 : 0) : (jz < ph.nz ? -1 : 0);
     const int kz = ph.kz0 + ksz * jz, ky = ph.ky0 + ksy * jy, kx = ph.kx0 + ksx * jx;
     woff = ((kz * Ky + ky) * Kx + kx) * Cin;
     dz = ph.dz0 + dsz * jz;
@@ -578,11 +591,22 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
     dx = ph.dx0 + dsx * jx;
     deltaB = (unsigned)((dz * Hi + dy) * Wi + dx) * (unsigned)ldi * 4u;
   };
+  // K order.  UCUR: channel-chunk major, taps inner -- the taps that re-read an input element
+  // ((ky,kx) neighbours, and the rows shared with the tile above/below) are then a few K-steps
+  // apart instead of Cin/32 times that, close enough for the 4 MiB per-XCD L2 to still hold them.
+  // Otherwise tap major (a K-step spans several taps).
   {
-    int kidx = kt_begin * BK;
-    if constexpr (!UCUR) kidx += cc * 4;
-    int tap = kidx / Cin;
-    ci = kidx - tap * Cin;
+    int tap;
+    if constexpr (UCUR) {
+      const int nt = ntaps > 0 ? ntaps : 1;
+      const int chunk = kt_begin / nt;
+      tap = kt_begin - chunk * nt;
+      ci = chunk * BK;
+    } else {
+      const int kidx = kt_begin * BK + cc * 4;
+      tap = kidx / Cin;
+      ci = kidx - tap * Cin;
+    }
     jx = tap % ph.nx;
     const int tq = tap / ph.nx;
     jy = tq % ph.ny;
@@ -596,6 +620,20 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
     place();
   }
   auto advance = [&]() {
+    if constexpr (UCUR) {
+      jx += 1;
+      const int wx = jx == ph.nx ? 1 : 0;
+      jx -= (-wx) & ph.nx;
+      jy += wx;
+      const int wy = jy == ph.ny ? 1 : 0;
+      jy -= (-wy) & ph.ny;
+      jz += wy;
+      const int wz = jz == ph.nz ? 1 : 0;
+      jz -= (-wz) & ph.nz;
+      ci += (-wz) & BK;
+      place();
+      return;
+    }
 #pragma unroll
     for (int w = 0; w < WRAPS; ++w) {
       ci += BK / WRAPS;
@@ -1483,6 +1521,7 @@ static int launch_variant(const GatherConv& p, long maxM, hipStream_t st) {
   GatherConv q = p;
   q.mtiles = (int)((maxM + BM - 1) / BM);
   q.ntiles = (p.Cout + BN - 1) / BN;
+  q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 4 > (3L << 20) ? 1 : 0;
   q.ksplit = 1;
   dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
@@ -1535,6 +1574,7 @@ static int launch_pipe_variant(const GatherConv& p, long maxM, hipStream_t st) {
   GatherConv q = p;
   q.mtiles = (int)((maxM + BM - 1) / BM);
   q.ntiles = (p.Cout + BN - 1) / BN;
+  q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 4 > (3L << 20) ? 1 : 0;
   if (q.ksplit < 1) q.ksplit = 1;
   dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase * q.ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);

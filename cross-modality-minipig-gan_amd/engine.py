@@ -968,6 +968,7 @@ class DiscPlan:
         self.g_prob = E(n)
         dlogit = E(n)
         gas = [E(*z.shape) for z in zs]
+        self.zs, self.gas, self.nbs = zs, gas, nbs   # raw conv outputs, their gradients, norm vectors (tests, tools)
         b.add("sigmoid_backward", L.mpgan_sigmoid_backward, self.g_prob.data_ptr(), self.prob.data_ptr(), n,
               dlogit.data_ptr(), keep=(dlogit,))
         b.add("linear1_backward", L.mpgan_linear1_backward, zs[-1].data_ptr(), C.byref(pc), n, P_last, c_last,

@@ -24,6 +24,9 @@ CONV_CASES = [
     (2, 64, 128, 3, 1, 0, (20, 18), 2),    # D conv2
     (2, 128, 256, 4, 2, 0, (18, 16), 2),   # D conv3
     (2, 256, 256, 4, 2, 0, (15, 13), 2),   # D conv4 (odd input: uneven phases in dgrad)
+    (2, 64, 128, 3, 1, 0, (126, 126), 1),   # D conv2 at the C1 size
+    (2, 128, 256, 4, 2, 0, (124, 124), 1),  # D conv3 at the C1 size: many m-tiles x 4 phases x 64-wide tiles in dgrad
+    (2, 256, 256, 4, 2, 0, (61, 61), 1),    # D conv4 at the C1 size (weights > 3 MiB: phase-outer block order)
     (3, 1, 16, 3, 2, 1, (8, 10, 12), 2),   # 3-D variants (reference's true shape)
     (3, 16, 32, 3, 2, 1, (8, 10, 12), 1),
     (3, 32, 32, 3, 1, 1, (6, 5, 7), 2),

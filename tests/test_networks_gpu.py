@@ -98,7 +98,12 @@ def test_discriminator_forward_backward_matches_oracle(dims, spatial, n):
     ours.cuda().train()
     gen = torch.Generator().manual_seed(17)
     x = (torch.rand(n, 1, *spatial, generator=gen) * 2 - 1).requires_grad_(True)
+    acts = {}
+    hooks = [ref.model_conv[i].register_forward_hook(lambda m, a, out, i=i: acts.__setitem__(i, out.detach()))
+             for i in (1, 4, 7, 10)]
     p_ref = ref(x)
+    for h in hooks:
+        h.remove()
     loss_ref = R.adversarial_loss(p_ref, torch.full_like(p_ref, 0.9))
     loss_ref.backward()
     xc = x.detach().cuda().requires_grad_(True)
@@ -108,9 +113,30 @@ def test_discriminator_forward_backward_matches_oracle(dims, spatial, n):
     loss = adversarial_loss(p, torch.full_like(p, 0.9))
     assert_close(loss.reshape(1), loss_ref.reshape(1), rtol=1e-5, what="bce")
     loss.backward()
-    # four train-mode BatchNorms over few pixels amplify fp32 rounding: 5e-3 of the gradient's max
-    assert_close(xc.grad, x.grad, rtol=5e-3, atol=5e-3 * x.grad.abs().max().item(), what="dL/dx", outliers=0.005)
-    _check_param_grads(ours, ref, rtol=5e-3)
+    # LeakyReLU kinks: an activation within fp32 rounding of 0 may fall on opposite sides in two correct
+    # implementations; its gradient then differs by the slope ratio over its whole receptive field
+    # (tools/debug_dgrad_noise.py shows the HIP forward agreeing with a float64 graph to
+    # 1e-5 while one flipped element of conv4 moves dL/dx by 8 % on 28 input rows).  Count them.
+    plan = [pl for pool in ours._plans.values() for pl in pool][0]
+    flips = 0
+    for k, i in enumerate((1, 4, 7, 10)):
+        z = plan.zs[k].squeeze(1) if dims == 2 else plan.zs[k]
+        a = (z * plan.nbs[k].scale + plan.nbs[k].shift).cpu()
+        a = a.permute(0, 3, 1, 2) if dims == 2 else a.permute(0, 4, 1, 2, 3)
+        flips += int(((a > 0) != (acts[i] > 0)).sum())
+    assert flips <= 4, flips
+    if flips == 0:
+        # four train-mode BatchNorms over few pixels amplify fp32 rounding: 5e-3 of the gradient's max
+        assert_close(xc.grad, x.grad, rtol=5e-3, atol=5e-3 * x.grad.abs().max().item(), what="dL/dx", outliers=0.005)
+        _check_param_grads(ours, ref, rtol=5e-3)
+    else:
+        l2 = lambda a, b: ((a.cpu() - b).norm() / (b.norm() + 1e-30)).item()
+        # measured with 2 flips at 128x128, bs 1: dL/dx 4e-2, BatchNorm weight gradients (sums that cancel) 7e-2
+        assert l2(xc.grad, x.grad) < 1e-1, (flips, l2(xc.grad, x.grad))
+        rp = dict(ref.named_parameters())
+        for name, p in ours.named_parameters():
+            if not _pre_norm_bias(name, set(rp)):
+                assert l2(p.grad, rp[name].grad) < 1e-1, (name, flips, l2(p.grad, rp[name].grad))
     sd, sr = ours.state_dict(), ref.state_dict()
     for k in sr:
         if "running_" in k:

@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpgan_hip.so")
+LIB_PATH = os.environ.get("MPGAN_LIB_PATH") or os.path.join(_HERE, "libmpgan_hip.so")   # override: kernel experiments
 _lib = None
 
 

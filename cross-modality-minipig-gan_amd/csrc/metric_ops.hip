@@ -1,7 +1,7 @@
 // Evaluation metrics of the reference's offline scripts, on the device:
 //   inferrence.py:188-204  rescale a volume to 0..255 (ScaleIntensityRangePercentiles 0/100 ==
 //                          min/max), round, then MAE against the ground truth;
-//   metrics.py:213-223, psnr_ssim_metric.py:88-106  MSE and PSNR with data_range = 256.
+//   metrics.py:213-223, psnr_ssim_metric.py:88-106  MSE, PSNR and SSIM with data_range = 256.
 // HBM-bound two-stage reductions (fixed order, no atomics).
 #include "mpgan_common.h"
 
@@ -102,9 +102,144 @@ __global__ __launch_bounds__(64) void err_final_kernel(const float* __restrict__
   }
 }
 
+// ---- SSIM (skimage.metrics.structural_similarity as psnr_ssim_metric.py:91-92 calls it) -------
+// 7-wide uniform window (7x7 for a slice, 7x7x7 for a volume), K1 = 0.01, K2 = 0.03, sample
+// covariance (NP/(NP-1)), mean of S over the interior that excludes the 3 border samples per
+// windowed axis.  A block stages the (TZ+WZ-1) x 14 x 38 input region of both images in LDS;
+// a thread owns one (y, x) column of the 8 x 32 tile: it forms the 7x7 plane sums of
+// (a, b, a^2, b^2, ab) for every staged z once (double precision: sums of 343 products of
+// 0..255 values would cost fp32 its variance digits) and slides the z window over them.
+constexpr int SS_W = 7, SS_TY = 8, SS_TX = 32, SS_RY = SS_TY + SS_W - 1, SS_RX = SS_TX + SS_W - 1;
+
+template <int WZ, int TZ>
+__global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           int D, int H, int W, int tiles_x, int tiles_y,
+                                                           double c1, double c2, double* __restrict__ partials) {
+  constexpr int RZ = TZ + WZ - 1;
+  extern __shared__ float sm[];                 // [2][RZ][SS_RY][SS_RX]
+  float* sa = sm;
+  float* sb = sm + RZ * SS_RY * SS_RX;
+  const int tid = threadIdx.x;
+  const int bx = blockIdx.x % tiles_x;
+  const int by = (blockIdx.x / tiles_x) % tiles_y;
+  const int bz = blockIdx.x / (tiles_x * tiles_y);
+  const int z0 = bz * TZ, y0 = by * SS_TY, x0 = bx * SS_TX;   // origin of the tile = first window corner
+  for (int i = tid; i < RZ * SS_RY * SS_RX; i += 256) {
+    const int rx = i % SS_RX, ry = (i / SS_RX) % SS_RY, rz = i / (SS_RX * SS_RY);
+    const int z = z0 + rz, y = y0 + ry, x = x0 + rx;
+    const bool ok = z < D && y < H && x < W;
+    const long off = ((long)z * H + y) * W + x;
+    sa[i] = ok ? a[off] : 0.f;
+    sb[i] = ok ? b[off] : 0.f;
+  }
+  __syncthreads();
+  const int tx = tid % SS_TX, ty = tid / SS_TX;
+  const int OD = D - WZ + 1, OH = H - SS_W + 1, OW = W - SS_W + 1;   // outputs = window corners
+  double pa[RZ], pb[RZ], paa[RZ], pbb[RZ], pab[RZ];
+#pragma unroll
+  for (int rz = 0; rz < RZ; ++rz) {
+    double s_a = 0, s_b = 0, s_aa = 0, s_bb = 0, s_ab = 0;
+    for (int dy = 0; dy < SS_W; ++dy) {
+      const float* ra = sa + (rz * SS_RY + ty + dy) * SS_RX + tx;
+      const float* rb = sb + (rz * SS_RY + ty + dy) * SS_RX + tx;
+#pragma unroll
+      for (int dx = 0; dx < SS_W; ++dx) {
+        const double u = (double)ra[dx], v = (double)rb[dx];
+        s_a += u; s_b += v;
+        s_aa = fma(u, u, s_aa); s_bb = fma(v, v, s_bb); s_ab = fma(u, v, s_ab);
+      }
+    }
+    pa[rz] = s_a; pb[rz] = s_b; paa[rz] = s_aa; pbb[rz] = s_bb; pab[rz] = s_ab;
+  }
+  constexpr double NP = (double)(WZ * SS_W * SS_W);
+  constexpr double cov_norm = NP / (NP - 1.0);
+  double local = 0.0;
+#pragma unroll
+  for (int zo = 0; zo < TZ; ++zo) {
+    if (z0 + zo >= OD || y0 + ty >= OH || x0 + tx >= OW) continue;
+    double s_a = 0, s_b = 0, s_aa = 0, s_bb = 0, s_ab = 0;
+#pragma unroll
+    for (int dz = 0; dz < WZ; ++dz) {
+      s_a += pa[zo + dz]; s_b += pb[zo + dz]; s_aa += paa[zo + dz]; s_bb += pbb[zo + dz]; s_ab += pab[zo + dz];
+    }
+    const double ux = s_a / NP, uy = s_b / NP;
+    const double vx = cov_norm * (s_aa / NP - ux * ux), vy = cov_norm * (s_bb / NP - uy * uy);
+    const double vxy = cov_norm * (s_ab / NP - ux * uy);
+    const double A1 = 2.0 * ux * uy + c1, A2 = 2.0 * vxy + c2;
+    const double B1 = ux * ux + uy * uy + c1, B2 = vx + vy + c2;
+    local += (A1 * A2) / (B1 * B2);
+  }
+  // block sum in a fixed order
+  __shared__ double red[256];
+  red[tid] = local;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (tid < s2) red[tid] += red[tid + s2];
+    __syncthreads();
+  }
+  if (tid == 0) partials[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void ssim_final_kernel(const double* __restrict__ partials, int nb, double inv_count,
+                                                         float* __restrict__ out1) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partials[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out1[0] = (float)(red[0] * inv_count);
+}
+
+constexpr int SS_TZ3 = 4;
+
+static long ssim_blocks(const int32_t* dhw, bool vol) {
+  const int OD = vol ? dhw[0] - SS_W + 1 : dhw[0], OH = dhw[1] - SS_W + 1, OW = dhw[2] - SS_W + 1;
+  const long tz = vol ? (OD + SS_TZ3 - 1) / SS_TZ3 : OD;
+  return tz * ((OH + SS_TY - 1) / SS_TY) * ((OW + SS_TX - 1) / SS_TX);
+}
+
 }  // namespace mpgan
 
 using namespace mpgan;
+
+extern "C" int64_t mpgan_ssim_workspace(const int32_t* dhw) {
+  if (!dhw || dhw[1] < SS_W || dhw[2] < SS_W || dhw[0] < 1) return -1;
+  const bool vol = dhw[0] >= SS_W;
+  return ssim_blocks(dhw, vol) * (int64_t)sizeof(double);
+}
+
+extern "C" int mpgan_ssim(const float* a, const float* b, const int32_t* dhw, float data_range, void* workspace,
+                          int64_t workspace_bytes, float* out1, void* stream) {
+  MPGAN_CHECK_ARG(a && b && dhw && workspace && out1, "ssim: null pointer");
+  MPGAN_CHECK_ARG(dhw[1] >= SS_W && dhw[2] >= SS_W && dhw[0] >= 1, "ssim: extents below the 7-wide window");
+  MPGAN_UNSUPPORTED(dhw[0] > 1 && dhw[0] < SS_W, "ssim: depth %d is neither a slice (1) nor >= 7", dhw[0]);
+  const bool vol = dhw[0] >= SS_W;
+  const long blocks = ssim_blocks(dhw, vol);
+  MPGAN_CHECK_ARG(workspace_bytes >= blocks * (int64_t)sizeof(double), "ssim: workspace too small");
+  MPGAN_CHECK_ARG(blocks < (1L << 31), "ssim: too many tiles");
+  const int OD = vol ? dhw[0] - SS_W + 1 : dhw[0], OH = dhw[1] - SS_W + 1, OW = dhw[2] - SS_W + 1;
+  const int tiles_x = (OW + SS_TX - 1) / SS_TX, tiles_y = (OH + SS_TY - 1) / SS_TY;
+  const double c1 = (0.01 * (double)data_range) * (0.01 * (double)data_range);
+  const double c2 = (0.03 * (double)data_range) * (0.03 * (double)data_range);
+  double* part = static_cast<double*>(workspace);
+  hipStream_t st = (hipStream_t)stream;
+  if (vol) {
+    const size_t smem = 2ul * (SS_TZ3 + SS_W - 1) * SS_RY * SS_RX * sizeof(float);
+    hipLaunchKernelGGL((ssim_partial_kernel<SS_W, SS_TZ3>), dim3((unsigned)blocks), dim3(256), smem, st, a, b, dhw[0],
+                       dhw[1], dhw[2], tiles_x, tiles_y, c1, c2, part);
+  } else {
+    const size_t smem = 2ul * SS_RY * SS_RX * sizeof(float);
+    hipLaunchKernelGGL((ssim_partial_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), smem, st, a, b, dhw[0], dhw[1],
+                       dhw[2], tiles_x, tiles_y, c1, c2, part);
+  }
+  hipLaunchKernelGGL(ssim_final_kernel, dim3(1), dim3(256), 0, st, part, (int)blocks,
+                     1.0 / ((double)OD * OH * OW), out1);
+  return check_launch("ssim");
+}
 
 extern "C" int32_t mpgan_metric_partials(void) { return 2 * MET_BLOCKS; }
 

@@ -1,9 +1,11 @@
 """On-device evaluation metrics of the reference's offline scripts (SURVEY.md section 8(f)
 row N2): 0..255 rescale + round as code/GAN/inferrence.py:188-204 applies it, then MAE / MSE /
-PSNR (data_range 256, code/GAN/psnr_ssim_metric.py:88-106; code/GAN/metrics.py:213-223).
-SSIM (skimage) is not built."""
+PSNR and SSIM (data_range 256, code/GAN/psnr_ssim_metric.py:88-106; code/GAN/metrics.py:213-223).
+SSIM restates skimage.metrics.structural_similarity's published algorithm (skimage itself is not in
+this image: parity is pinned on a scipy.ndimage restatement in oracle/metrics_ref.py only)."""
 from __future__ import annotations
 
+import ctypes as C
 from typing import Dict
 
 import torch
@@ -39,5 +41,28 @@ def image_errors(a: torch.Tensor, b: torch.Tensor, data_range: float = 256.0) ->
 
 
 def score_volume(generated: torch.Tensor, ground_truth: torch.Tensor) -> Dict[str, torch.Tensor]:
-    """The inference script's scoring: both volumes rescaled to 0..255 and rounded, then compared."""
-    return image_errors(rescale_0_255(generated), rescale_0_255(ground_truth), 256.0)
+    """The inference script's scoring: both volumes rescaled to 0..255 and rounded, then compared
+    (MAE / MSE / PSNR; plus SSIM when the tensors are (H, W) or (D, H, W))."""
+    g, t = rescale_0_255(generated), rescale_0_255(ground_truth)
+    out = image_errors(g, t, 256.0)
+    if g.dim() in (2, 3) and min(g.shape[-2:]) >= 7 and (g.dim() == 2 or g.shape[0] >= 7):
+        out["ssim"] = ssim(g, t, 256.0)
+    return out
+
+
+def ssim(a: torch.Tensor, b: torch.Tensor, data_range: float = 256.0) -> torch.Tensor:
+    """structural_similarity(a, b, data_range=256) of two (H, W) slices or (D, H, W) volumes
+    (code/GAN/psnr_ssim_metric.py:91-92): 7-wide uniform window, K1 = 0.01, K2 = 0.03, sample
+    covariance, mean over the interior.  Returns a device scalar."""
+    if a.shape != b.shape or a.dim() not in (2, 3):
+        raise ValueError("ssim: expects two same-shape (H, W) or (D, H, W) tensors")
+    a, b = a.contiguous().float(), b.contiguous().float()
+    dhw = (C.c_int32 * 3)(*((1,) * (3 - a.dim()) + tuple(a.shape)))
+    need = int(lib().mpgan_ssim_workspace(dhw))
+    if need < 0:
+        raise ValueError(f"ssim: extents {tuple(a.shape)} are below the 7-wide window")
+    ws = torch.empty(max(need // 8, 1), dtype=torch.float64, device=a.device)
+    out = torch.empty(1, device=a.device)
+    check(lib().mpgan_ssim(a.data_ptr(), b.data_ptr(), dhw, float(data_range), ws.data_ptr(), ws.numel() * 8,
+                           out.data_ptr(), _stream()), "ssim")
+    return out[0]

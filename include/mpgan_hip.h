@@ -285,6 +285,15 @@ int mpgan_rescale_minmax(const float* x, int64_t numel, float b_min, float b_max
 int mpgan_image_errors(const float* a, const float* b, int64_t numel, float data_range,
                        float* partials, float* out3, void* stream);
 
+/* Mean structural similarity of two slices (dhw[0] == 1: 7x7 window) or volumes (dhw[0] >= 7: 7x7x7),
+ * the algorithm skimage.metrics.structural_similarity runs with the arguments psnr_ssim_metric.py:91-92
+ * passes (data_range only): uniform window, K1 = 0.01, K2 = 0.03, sample covariance, mean over the
+ * interior that drops 3 border samples per windowed axis.  a, b: contiguous (D,H,W) fp32.
+ * workspace >= mpgan_ssim_workspace(dhw) bytes (per-tile partial sums, double). */
+int64_t mpgan_ssim_workspace(const int32_t* dhw);
+int mpgan_ssim(const float* a, const float* b, const int32_t* dhw, float data_range,
+               void* workspace, int64_t workspace_bytes, float* out1, void* stream);
+
 /* ---- optimiser ------------------------------------------------------------ */
 /* torch.optim.Adam.step over one flat buffer (GAN_final.py:306-307):
  * m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t)+eps).

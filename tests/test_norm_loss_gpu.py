@@ -223,3 +223,33 @@ def test_eval_metrics_match_numpy_restatement():
     np.testing.assert_allclose(s["mae"].item(), np.abs(ra - rb).mean(), rtol=1e-3)
     np.testing.assert_allclose(s["mse"].item(), mse, rtol=1e-3)
     np.testing.assert_allclose(s["psnr"].item(), 10 * np.log10(256.0 ** 2 / mse), rtol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(40, 48, 44), (9, 35, 71), (64, 50), (7, 7, 7), (128, 128, 128)])
+def test_ssim_matches_restated_skimage_algorithm(shape):
+    """psnr_ssim_metric.py:91-92: structural_similarity(t2, t2_gen, data_range=256) on 0..255 volumes (and,
+    for the 2-D instantiation, slices).  Oracle: oracle/metrics_ref.py (skimage's algorithm on
+    scipy.ndimage.uniform_filter, float64; skimage itself is absent: parity unpinned against it).
+    Tolerance 1e-6: the kernel accumulates the window sums in double."""
+    from mpgan_amd import metrics
+    from oracle.metrics_ref import structural_similarity
+    gen = torch.Generator().manual_seed(31 + len(shape))
+    a = torch.round(torch.rand(shape, generator=gen) * 255)
+    b = torch.round((a + 25 * torch.randn(shape, generator=gen)).clamp(0, 255))
+    want = structural_similarity(a.numpy(), b.numpy(), data_range=256)
+    got = metrics.ssim(a.cuda(), b.cuda(), 256.0).item()
+    assert abs(got - want) < 1e-6, (got, want)
+    assert abs(metrics.ssim(a.cuda(), a.cuda()).item() - 1.0) < 1e-6          # identical images
+    if len(shape) == 3 and shape[0] >= 7:
+        s = metrics.score_volume(a.cuda(), b.cuda())
+        assert "ssim" in s
+
+
+def test_ssim_rejects_small_or_mismatched_inputs():
+    from mpgan_amd import metrics
+    with pytest.raises(ValueError):
+        metrics.ssim(torch.zeros(5, 5, device="cuda"), torch.zeros(5, 5, device="cuda"))
+    with pytest.raises(ValueError):
+        metrics.ssim(torch.zeros(8, 8, device="cuda"), torch.zeros(8, 9, device="cuda"))
+    with pytest.raises(RuntimeError, match="neither a slice"):
+        metrics.ssim(torch.zeros(3, 8, 8, device="cuda"), torch.zeros(3, 8, 8, device="cuda"))

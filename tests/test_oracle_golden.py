@@ -140,3 +140,21 @@ def test_crop_patches_gather_is_exact():
     b, s = 1, 3
     z, y, x = corners[b, s]
     assert torch.equal(p[b * 5 + s, 0], vols[b, 0, z:z + 4, y:y + 4, x:x + 4])
+
+
+def test_ssim_restatement_properties():
+    """oracle/metrics_ref.py (skimage's SSIM restated on scipy): identical images score 1, the score is
+    symmetric, and a constant offset lowers only the luminance term by the closed form
+    (2 u (u+d) + C1) / (u^2 + (u+d)^2 + C1) on a flat image."""
+    import numpy as np
+    from oracle.metrics_ref import structural_similarity
+    rng = np.random.RandomState(0)
+    a = np.round(rng.rand(12, 14, 16) * 255)
+    b = np.round(np.clip(a + 20 * rng.randn(*a.shape), 0, 255))
+    assert abs(structural_similarity(a, a) - 1.0) < 1e-12
+    assert abs(structural_similarity(a, b) - structural_similarity(b, a)) < 1e-12
+    flat = np.full((9, 9, 9), 100.0)
+    d = 30.0
+    c1, c2 = (0.01 * 256) ** 2, (0.03 * 256) ** 2
+    want = (2 * 100 * 130 + c1) / (100 ** 2 + 130 ** 2 + c1)      # variances are 0: contrast term = C2/C2
+    assert abs(structural_similarity(flat, flat + d) - want) < 1e-12

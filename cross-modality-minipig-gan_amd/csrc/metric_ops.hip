@@ -194,6 +194,115 @@ __global__ __launch_bounds__(256) void ssim_final_kernel(const double* __restric
   if (threadIdx.x == 0) out1[0] = (float)(red[0] * inv_count);
 }
 
+// ---- np.percentile on the device (ScaleIntensityRangePercentilesd, GAN_final.py:386-394) --------
+// Exact order statistics by a 3-pass radix select (11 + 11 + 10 bits) over the monotone uint32
+// image of the floats; integer atomics only, so the result does not depend on execution order.
+constexpr int PCT_MAXT = 4;                     // order statistics per call (2 percentiles x {lo, lo+1})
+constexpr int PCT_BINS = 2048;
+struct PctState {
+  unsigned prefix[PCT_MAXT];                    // key bits fixed so far (left-aligned)
+  unsigned long long k[PCT_MAXT];               // rank still to find inside the prefix class
+};
+
+__device__ __forceinline__ unsigned pct_key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float pct_unkey(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// pass 0: bits 31..21, one histogram shared by all targets; pass 1: bits 20..10 among the keys whose
+// top 11 bits equal the target's prefix; pass 2: bits 9..0 among those whose top 22 bits do.
+template <int PASS>
+__global__ __launch_bounds__(256) void pct_hist_kernel(const float* __restrict__ x, long n, int nt,
+                                                       const PctState* __restrict__ stt, unsigned* __restrict__ hist) {
+  extern __shared__ unsigned lh[];              // [PASS == 0 ? 1 : nt][PCT_BINS]
+  const int nh = PASS == 0 ? 1 : nt;
+  for (int i = threadIdx.x; i < nh * PCT_BINS; i += 256) lh[i] = 0;
+  unsigned pre[PCT_MAXT];
+#pragma unroll
+  for (int t = 0; t < PCT_MAXT; ++t) pre[t] = (PASS > 0 && t < nt) ? stt->prefix[t] : 0u;
+  __syncthreads();
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const unsigned key = pct_key(x[i]);
+    if (PASS == 0) {
+      atomicAdd(&lh[key >> 21], 1u);
+    } else {
+#pragma unroll
+      for (int t = 0; t < PCT_MAXT; ++t) {
+        if (t >= nt) break;
+        if (PASS == 1 && (key >> 21) == (pre[t] >> 21)) atomicAdd(&lh[t * PCT_BINS + ((key >> 10) & 2047u)], 1u);
+        if (PASS == 2 && (key >> 10) == (pre[t] >> 10)) atomicAdd(&lh[t * PCT_BINS + (key & 1023u)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nh * PCT_BINS; i += 256)
+    if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// one thread per target walks its histogram to the bin that holds rank k; clears the histogram
+template <int PASS>
+__global__ __launch_bounds__(64) void pct_scan_kernel(int nt, PctState* __restrict__ stt, unsigned* __restrict__ hist) {
+  const int t = threadIdx.x;
+  if (t < nt) {
+    const unsigned* h = hist + (PASS == 0 ? 0 : t * PCT_BINS);
+    unsigned long long k = stt->k[t], cum = 0;
+    const int bins = PASS == 2 ? 1024 : PCT_BINS;
+    int bsel = bins - 1;
+    for (int b2 = 0; b2 < bins; ++b2) {
+      const unsigned c = h[b2];
+      if (k < cum + c) { bsel = b2; break; }
+      cum += c;
+    }
+    stt->k[t] = k - cum;
+    const int shift = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
+    stt->prefix[t] |= (unsigned)bsel << shift;
+  }
+  __syncthreads();
+  const int nh = PASS == 0 ? 1 : nt;
+  for (int i = threadIdx.x; i < nh * PCT_BINS; i += 64) hist[i] = 0;
+}
+
+__global__ void pct_init_kernel(PctState* stt, unsigned* hist, int nt, unsigned long long k0, unsigned long long k1,
+                                unsigned long long k2, unsigned long long k3) {
+  const unsigned long long ks[4] = {k0, k1, k2, k3};
+  if (threadIdx.x < PCT_MAXT) {
+    stt->prefix[threadIdx.x] = 0;
+    stt->k[threadIdx.x] = threadIdx.x < nt ? ks[threadIdx.x] : 0;
+  }
+  for (int i = threadIdx.x; i < PCT_MAXT * PCT_BINS; i += blockDim.x) hist[i] = 0;
+}
+
+// out[j] = s[lo_j] + frac_j * (s[lo_j + 1] - s[lo_j])   (numpy's linear interpolation, in double)
+__global__ void pct_final_kernel(const PctState* __restrict__ stt, int nq, double f0, double f1,
+                                 float* __restrict__ out) {
+  const double fr[2] = {f0, f1};
+  if ((int)threadIdx.x < nq) {
+    const double a = (double)pct_unkey(stt->prefix[2 * threadIdx.x]);
+    const double b = (double)pct_unkey(stt->prefix[2 * threadIdx.x + 1]);
+    const double t = fr[threadIdx.x];
+    out[threadIdx.x] = (float)(t >= 0.5 ? b - (b - a) * (1.0 - t) : a + (b - a) * t);
+  }
+}
+
+// y = (x - a_min) / (a_max - a_min) * (b_max - b_min) + b_min, optionally clipped (MONAI ScaleIntensityRange)
+__global__ __launch_bounds__(256) void scale_range_kernel(const float* __restrict__ x, long n,
+                                                          const float* __restrict__ a_minmax, float b_min, float b_max,
+                                                          int clip, float* __restrict__ y) {
+  const float lo = a_minmax[0], hi = a_minmax[1];
+  const float span = hi - lo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = x[i] - lo;
+    if (span != 0.f) {                           // MONAI: a_min == a_max -> warn and return x - a_min
+      v = v / span * (b_max - b_min) + b_min;
+      if (clip) v = fminf(fmaxf(v, b_min), b_max);
+    }
+    y[i] = v;
+  }
+}
+
 constexpr int SS_TZ3 = 4;
 
 static long ssim_blocks(const int32_t* dhw, bool vol) {
@@ -266,4 +375,56 @@ extern "C" int mpgan_image_errors(const float* a, const float* b, int64_t numel,
   hipLaunchKernelGGL(err_final_kernel, dim3(1), dim3(64), 0, st, partials, (int)blocks, 1.0 / (double)numel,
                      data_range, out3);
   return check_launch("image_errors");
+}
+
+extern "C" int64_t mpgan_percentile_workspace(void) {
+  return (int64_t)sizeof(PctState) + (int64_t)PCT_MAXT * PCT_BINS * (int64_t)sizeof(unsigned) + 64;
+}
+
+extern "C" int mpgan_percentiles(const float* x, int64_t numel, const double* q_host, int32_t nq, void* workspace,
+                                 int64_t workspace_bytes, float* out, void* stream) {
+  MPGAN_CHECK_ARG(x && q_host && workspace && out && numel > 0, "percentiles: bad argument");
+  MPGAN_UNSUPPORTED(nq < 1 || nq > 2, "percentiles: 1 or 2 percentiles per call (got %d)", nq);
+  MPGAN_CHECK_ARG(workspace_bytes >= mpgan_percentile_workspace(), "percentiles: workspace too small");
+  MPGAN_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "percentiles: workspace must be 8-byte aligned");
+  unsigned long long ks[4] = {0, 0, 0, 0};
+  double fr[2] = {0, 0};
+  for (int j = 0; j < nq; ++j) {
+    MPGAN_CHECK_ARG(q_host[j] >= 0.0 && q_host[j] <= 100.0, "percentiles: q outside [0, 100]");
+    const double r = q_host[j] / 100.0 * (double)(numel - 1);      // numpy: virtual index q * (n - 1)
+    long lo = (long)r;
+    if (lo > numel - 1) lo = numel - 1;
+    const long hi = lo + 1 < numel ? lo + 1 : lo;
+    ks[2 * j] = (unsigned long long)lo;
+    ks[2 * j + 1] = (unsigned long long)hi;
+    fr[j] = r - (double)lo;
+  }
+  PctState* stt = static_cast<PctState*>(workspace);
+  unsigned* hist = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + ((sizeof(PctState) + 63) / 64) * 64);
+  const int nt = 2 * nq;
+  hipStream_t st = (hipStream_t)stream;
+  long blocks = (numel + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pct_init_kernel, dim3(1), dim3(256), 0, st, stt, hist, nt, ks[0], ks[1], ks[2], ks[3]);
+  hipLaunchKernelGGL((pct_hist_kernel<0>), dim3((unsigned)blocks), dim3(256), PCT_BINS * sizeof(unsigned), st, x,
+                     (long)numel, nt, stt, hist);
+  hipLaunchKernelGGL((pct_scan_kernel<0>), dim3(1), dim3(64), 0, st, nt, stt, hist);
+  hipLaunchKernelGGL((pct_hist_kernel<1>), dim3((unsigned)blocks), dim3(256), nt * PCT_BINS * sizeof(unsigned), st, x,
+                     (long)numel, nt, stt, hist);
+  hipLaunchKernelGGL((pct_scan_kernel<1>), dim3(1), dim3(64), 0, st, nt, stt, hist);
+  hipLaunchKernelGGL((pct_hist_kernel<2>), dim3((unsigned)blocks), dim3(256), nt * PCT_BINS * sizeof(unsigned), st, x,
+                     (long)numel, nt, stt, hist);
+  hipLaunchKernelGGL((pct_scan_kernel<2>), dim3(1), dim3(64), 0, st, nt, stt, hist);
+  hipLaunchKernelGGL(pct_final_kernel, dim3(1), dim3(64), 0, st, stt, nq, fr[0], fr[1], out);
+  return check_launch("percentiles");
+}
+
+extern "C" int mpgan_scale_intensity_range(const float* x, int64_t numel, const float* a_minmax, float b_min,
+                                           float b_max, int32_t clip, float* y, void* stream) {
+  MPGAN_CHECK_ARG(x && a_minmax && y && numel > 0, "scale_intensity_range: bad argument");
+  long blocks = (numel + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_range_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)numel,
+                     a_minmax, b_min, b_max, clip, y);
+  return check_launch("scale_intensity_range");
 }

@@ -285,6 +285,19 @@ int mpgan_rescale_minmax(const float* x, int64_t numel, float b_min, float b_max
 int mpgan_image_errors(const float* a, const float* b, int64_t numel, float data_range,
                        float* partials, float* out3, void* stream);
 
+/* ---- pre-processing, array half of next-row N3 (GAN_final.py:386-394:
+ *      ScaleIntensityRangePercentilesd(lower=1, upper=99, b_min=-1, b_max=1, clip=True)) ---------- */
+/* out[j] = np.percentile(x, q[j]) (linear interpolation) for nq in {1, 2} percentiles: exact order
+ * statistics by a 3-pass radix select; q_host is read on the host at call time.
+ * workspace >= mpgan_percentile_workspace() bytes, 8-byte aligned. */
+int64_t mpgan_percentile_workspace(void);
+int mpgan_percentiles(const float* x, int64_t numel, const double* q_host, int32_t nq,
+                      void* workspace, int64_t workspace_bytes, float* out, void* stream);
+/* y = (x - a_min)/(a_max - a_min)*(b_max - b_min) + b_min, clipped to [b_min, b_max] when clip != 0
+ * (MONAI ScaleIntensityRange; a_minmax = device float[2], e.g. the output of mpgan_percentiles). */
+int mpgan_scale_intensity_range(const float* x, int64_t numel, const float* a_minmax, float b_min,
+                                float b_max, int32_t clip, float* y, void* stream);
+
 /* Mean structural similarity of two slices (dhw[0] == 1: 7x7 window) or volumes (dhw[0] >= 7: 7x7x7),
  * the algorithm skimage.metrics.structural_similarity runs with the arguments psnr_ssim_metric.py:91-92
  * passes (data_range only): uniform window, K1 = 0.01, K2 = 0.03, sample covariance, mean over the

@@ -32,3 +32,18 @@ def structural_similarity(im1, im2, data_range=256.0, win_size=7, K1=0.01, K2=0.
     pad = (win_size - 1) // 2
     crop = tuple(slice(pad, s - pad) for s in S.shape)
     return float(S[crop].mean(dtype=np.float64))
+
+
+def scale_intensity_range_percentiles(img, lower=1.0, upper=99.0, b_min=-1.0, b_max=1.0, clip=True):
+    """MONAI 0.4.0 `ScaleIntensityRangePercentiles.__call__` with relative=False followed by
+    `ScaleIntensityRange.__call__` (3rd-party source restated; call site code/GAN/GAN_final.py:386-394)."""
+    img = np.asarray(img)
+    a_min = np.percentile(img, lower)
+    a_max = np.percentile(img, upper)
+    if a_max - a_min == 0.0:
+        return img - a_min
+    out = (img - a_min) / (a_max - a_min)
+    out = out * (b_max - b_min) + b_min
+    if clip:
+        out = np.clip(out, b_min, b_max)
+    return out

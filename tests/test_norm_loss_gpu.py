@@ -253,3 +253,39 @@ def test_ssim_rejects_small_or_mismatched_inputs():
         metrics.ssim(torch.zeros(8, 8, device="cuda"), torch.zeros(8, 9, device="cuda"))
     with pytest.raises(RuntimeError, match="neither a slice"):
         metrics.ssim(torch.zeros(3, 8, 8, device="cuda"), torch.zeros(3, 8, 8, device="cuda"))
+
+
+@pytest.mark.parametrize("n,kind", [(1, "rand"), (2, "rand"), (1000, "rand"), (64 * 64 * 64, "mri"),
+                                    (100003, "dups"), (128 * 128 * 128, "mri")])
+def test_percentiles_are_numpy_percentiles(n, kind):
+    """The radix select returns the exact order statistics: np.percentile (linear interpolation) on the same
+    float32 data, relative 1e-6 (the interpolation itself runs in double on both sides)."""
+    from mpgan_amd import preprocess
+    rng = np.random.RandomState(n % 9973)
+    if kind == "rand":
+        x = (rng.rand(n) * 2000 - 1000).astype(np.float32)
+    elif kind == "dups":
+        x = rng.randint(-5, 6, size=n).astype(np.float32)            # heavy ties, negative values, zeros
+    else:                                                             # 60 % background, skewed foreground
+        x = np.where(rng.rand(n) < 0.6, 0.0, rng.gamma(2.0, 300.0, size=n)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    for q in ((1.0, 99.0), (0.0, 100.0), (50.0,), (12.5, 87.25)):
+        got = preprocess.percentiles(xt, q).cpu().numpy().astype(np.float64)
+        want = np.percentile(x.astype(np.float64), q)
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6 * max(1.0, np.abs(want).max()), err_msg=str(q))
+
+
+def test_scale_intensity_range_percentiles_matches_monai_restatement():
+    """GAN_final.py:386-394: lower=1, upper=99, b_min=-1, b_max=1, clip=True on a 96^3 volume."""
+    from mpgan_amd import preprocess
+    from oracle.metrics_ref import scale_intensity_range_percentiles
+    rng = np.random.RandomState(5)
+    vol = np.where(rng.rand(96, 96, 96) < 0.55, 0.0, rng.gamma(2.0, 250.0, size=(96, 96, 96))).astype(np.float32)
+    want = scale_intensity_range_percentiles(vol.astype(np.float64))
+    got = preprocess.scale_intensity_range_percentiles(torch.from_numpy(vol).cuda()).cpu().numpy()
+    assert got.min() >= -1.0 and got.max() <= 1.0
+    np.testing.assert_allclose(got, want, atol=2e-6)
+    # no clipping, other target range
+    want2 = scale_intensity_range_percentiles(vol.astype(np.float64), 5, 95, 0.0, 255.0, clip=False)
+    got2 = preprocess.scale_intensity_range_percentiles(torch.from_numpy(vol).cuda(), 5, 95, 0.0, 255.0, False)
+    np.testing.assert_allclose(got2.cpu().numpy(), want2, rtol=1e-5, atol=1e-3)

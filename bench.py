@@ -33,7 +33,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
-DOMINANT = "gather_conv_pipe_kernel<128, 2, 2, 2, 1, 3>"   # as rocprofv3 names it (D's dense layers, forward)
+DOMINANT = "gather_conv_pipe_kernel<128, 2, 2, 2, 1, 3, true>"   # as rocprofv3 names it (D's dense layers, forward)
 
 
 def note(msg):

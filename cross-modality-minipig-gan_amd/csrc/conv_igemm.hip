@@ -87,7 +87,7 @@ constexpr int PITCH = BK + 4;
 // optional fused BatchNorm statistics.  Called after the K-loop's final barrier.
 template <int BN, int TM, int TN, int WN>
 __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& ph, f32x16 (&acc)[TM][TN], float* lds,
-                                              long m0, int n0, long Mtot, int stats_row) {
+                                              long m0, int n0, long Mtot, int stats_row, bool zero_rows = false) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -168,6 +168,18 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
     constexpr int WM = 4 / WN;
     float* st = lds + 1024;                 // [WM][2][BN], clear of rowpix
     int* nvp = reinterpret_cast<int*>(lds) + 512;
+    if (zero_rows) {                        // FAST kernels gather clamped (non-zero) rows past the last pixel
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (rowpix[row] < 0) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn][r] = 0.f;
+          }
+        }
+    }
     if (tid < BM) {
       const unsigned long long b = __ballot(rowpix[tid] >= 0);
       if (lane == 0) nvp[wid] = __popcll(b);
@@ -492,7 +504,11 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
 //   PRO   : 0 none, 1 per-channel scale/shift (BatchNorm), 2 per-(n,c) (InstanceNorm),
 //           3 per-channel + LeakyReLU whose slope the host knows to lie in [0, 1]
 // ---------------------------------------------------------------------------
-template <int BN, int TM, int TN, int WN, int WRAPS, int PRO>
+//   FAST  : pad-free forward gather with Cout % BN == 0 (the discriminator's valid convs): every tap of
+//           every pixel is in range, so the per-row range tests and the zero masks of both operands
+//           (84 of the K-step's 146 vector instructions) are dropped; rows past the last pixel gather
+//           the last pixel instead of zeros and are cleared before the fused statistics.
+template <int BN, int TM, int TN, int WN, int WRAPS, int PRO, bool FAST = false>
 __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int STAGE = (BM + BN) * PITCH;
@@ -540,7 +556,8 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
   unsigned rbB[4];                       // byte offset of (row pixel, channel 0)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const unsigned m = (unsigned)m0 + r0 + 32 * i;
+    unsigned m = (unsigned)m0 + r0 + 32 * i;
+    if constexpr (FAST) m = m < (unsigned)Mtot ? m : (unsigned)Mtot - 1u;
     if (m < (unsigned)Mtot) {
       unsigned q, umx, umy, umz;
       fdivmod(m, ph.fMx, q, umx);
@@ -671,12 +688,15 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
     const unsigned cisB = (unsigned)(tci & cmask) * 4u;      // channel 0 past the last tap: reads stay in range
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int iz = rz[i] + dz, iy = ry[i] + dy, ix = rx[i] + dx;
-      const int ok = ((unsigned)iz < (unsigned)Di ? cmask : 0) & ((unsigned)iy < (unsigned)Hi ? -1 : 0) &
-                     ((unsigned)ix < (unsigned)Wi ? -1 : 0);           // 0 / -1
+      int ok = cmask;                                                  // 0 / -1
+      if constexpr (!FAST) {
+        const int iz = rz[i] + dz, iy = ry[i] + dy, ix = rx[i] + dx;
+        ok = ((unsigned)iz < (unsigned)Di ? cmask : 0) & ((unsigned)iy < (unsigned)Hi ? -1 : 0) &
+             ((unsigned)ix < (unsigned)Wi ? -1 : 0);
+      }
       const unsigned boff = (rbB[i] + deltaB + (unsigned)tci * 4u) & (unsigned)ok;
       ra[i] = *reinterpret_cast<const float4*>(ginb + boff);
-      amask |= ((unsigned)ok & 1u) << i;
+      if constexpr (!FAST) amask |= ((unsigned)ok & 1u) << i;
       if constexpr (PRO == 2) {
         const unsigned sb = (unsigned)(rn[i] * nstride) * 4u + cisB;
         rsc[i] = *reinterpret_cast<const float4*>(gscb + sb);
@@ -719,15 +739,19 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
         v.z = act_apply(v.z * sc.z + sh.z, act, slope);
         v.w = act_apply(v.w * sc.w + sh.w, act, slope);
       }
-      const bool ok = (amask >> i) & 1u;
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if constexpr (!FAST) {
+        const bool ok = (amask >> i) & 1u;
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      }
       *reinterpret_cast<float4*>(As + (r0 + 32 * i) * PITCH + cc * 4) = v;
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
       float4 v = rb[i];
-      const bool ok = (kvalid & (int)((bvalid >> i) & 1u)) != 0;   // kvalid is 0 / -1
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if constexpr (!FAST) {      // FAST: every channel row exists and tiles past the last K-step are never read
+        const bool ok = (kvalid & (int)((bvalid >> i) & 1u)) != 0;   // kvalid is 0 / -1
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      }
       *reinterpret_cast<float4*>(Bs + (r0 + 32 * i) * PITCH + cc * 4) = v;
     }
   };
@@ -810,7 +834,7 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
       __syncthreads();
     }
   }
-  conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot, stats_row);
+  conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot, stats_row, FAST && m0 + BM > Mtot);
 }
 
 // ---------------------------------------------------------------------------
@@ -1556,9 +1580,9 @@ static int select_variant(const GatherConv& p, long maxM, bool thin1, bool thin2
   return bn;
 }
 
-template <int BN, int TM, int TN, int WN, int WRAPS, int PRO>
+template <int BN, int TM, int TN, int WN, int WRAPS, int PRO, bool FAST = false>
 static int launch_pipe_variant(const GatherConv& p, long maxM, hipStream_t st) {
-  auto kern = gather_conv_pipe_kernel<BN, TM, TN, WN, WRAPS, PRO>;
+  auto kern = gather_conv_pipe_kernel<BN, TM, TN, WN, WRAPS, PRO, FAST>;
   static const int lds_pad = getenv("MPGAN_DBG_LDS_PAD") ? atoi(getenv("MPGAN_DBG_LDS_PAD")) : 0;
   const int smem = 2 * (BM + BN) * PITCH * (int)sizeof(float) + lds_pad;
   static bool attr_set = false;
@@ -1581,8 +1605,27 @@ static int launch_pipe_variant(const GatherConv& p, long maxM, hipStream_t st) {
   return check_launch("gather_conv_pipe");
 }
 
+// every tap of every pixel in range and no partial channel tile: see FAST on gather_conv_pipe_kernel
+static bool fast_geometry(const GatherConv& p, int bn) {
+  static const bool off = getenv("MPGAN_DBG_NO_FAST") != nullptr;
+  if (off || p.nphase != 1 || p.Cout % bn != 0 || p.Cin % 32 != 0 || p.ksplit > 1) return false;
+  const Phase& ph = p.ph[0];
+  if (ph.nz * ph.ny * ph.nx == 0) return false;
+  const int d0[3] = {ph.dz0, ph.dy0, ph.dx0}, nj[3] = {ph.nz, ph.ny, ph.nx}, M[3] = {ph.Mz, ph.My, ph.Mx};
+  const int G[3] = {p.Di, p.Hi, p.Wi};
+  for (int d = 0; d < 3; ++d) {
+    const int lo = p.dstep[d] > 0 ? d0[d] : d0[d] + p.dstep[d] * (nj[d] - 1);
+    const int hi = p.dstep[d] > 0 ? d0[d] + p.dstep[d] * (nj[d] - 1) : d0[d];
+    if (lo < 0 || (M[d] - 1) * p.istride[d] + hi > G[d] - 1) return false;
+  }
+  return true;
+}
+
 template <int WRAPS, int PRO>
 static int launch_pipe_bn(const GatherConv& p, int variant, long maxM, hipStream_t st) {
+  if constexpr (WRAPS == 1 && PRO == 3) {
+    if (variant == 128 && fast_geometry(p, 128)) return launch_pipe_variant<128, 2, 2, 2, 1, 3, true>(p, maxM, st);
+  }
   if (variant == 128) return launch_pipe_variant<128, 2, 2, 2, WRAPS, PRO>(p, maxM, st);
   if (variant == 64) return launch_pipe_variant<64, 1, 2, 1, WRAPS, PRO>(p, maxM, st);
   return launch_pipe_variant<32, 1, 1, 1, WRAPS, PRO>(p, maxM, st);
@@ -1879,5 +1922,6 @@ extern "C" int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward
                   (lanes & (lanes - 1)) == 0 && (long)T * p.Cin * 4 <= 48 * 1024;
   const int v = select_variant(p, max_phase_pixels(p), t1, t2);
   if (v > 2 && patch_plan(p, nullptr, nullptr)) return 16;
+  if (v == 128 && has_prologue == 3 && fast_geometry(p, 128)) return 1128;
   return v;
 }

@@ -222,7 +222,10 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
     """The kernel symbol (as rocprofv3 prints it, minus `void mpgan::` and the argument list)
     the C dispatcher picks for this conv (mpgan_conv_variant + launch_gather's rules)."""
     gc = g.c()
-    v = int(lib().mpgan_conv_variant(C.byref(gc), int(backward_data), (2 if per_sample_norm else 1) if has_pro else 0))
+    v = int(lib().mpgan_conv_variant(C.byref(gc), int(backward_data),
+                                     (2 if per_sample_norm else (3 if fast_leaky else 1)) if has_pro else 0))
+    fast = v >= 1000                             # mask-free instance of the pipelined kernel
+    v = v - 1000 if fast else v
     if v == 1:
         return "thin_cin1_kernel"
     if v == 2:
@@ -234,7 +237,8 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
     tm, tn, wn = {128: (2, 2, 2), 64: (1, 2, 1), 32: (1, 1, 1)}[v]
     if cin_eff % 32 == 0 or cin_eff == 16:      # software-pipelined main kernel <BN, TM, TN, WN, WRAPS, PRO>
         pro = 0 if not has_pro else (2 if per_sample_norm else (3 if fast_leaky else 1))
-        return f"gather_conv_pipe_kernel<{v}, {tm}, {tn}, {wn}, {1 if cin_eff % 32 == 0 else 2}, {pro}>"
+        return (f"gather_conv_pipe_kernel<{v}, {tm}, {tn}, {wn}, {1 if cin_eff % 32 == 0 else 2}, {pro}, "
+                f"{'true' if fast else 'false'}>")
     return f"gather_conv_kernel<{v}, {tm}, {tn}, {wn}, {'false' if cin_eff % 4 == 0 else 'true'}>"
 
 

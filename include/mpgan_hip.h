@@ -113,7 +113,9 @@ int mpgan_conv_backward_data(const mpgan_conv_geom* g, const float* dy, int32_t 
  * stencil, 2 = thin Cout==1 VALU stencil, 16 = fp32-MFMA patch kernel (2-D, <= 32
  * output channels, input patch + weights staged once in LDS), 32/64/128 = fp32-MFMA
  * K-stepped implicit GEMM with that output-channel tile.
- * has_prologue: 0 none, 1 per-channel scale/shift, 2 per-(sample, channel). */
+ * 1128 = the 128 tile's mask-free instance (pad-free forward conv, Cout % 128 == 0, has_prologue 3).
+ * has_prologue: 0 none, 1 per-channel scale/shift, 2 per-(sample, channel), 3 per-channel +
+ * LeakyReLU with a host-known slope in [0, 1]. */
 int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward_data, int32_t has_prologue);
 
 /* Weight gradient: dW (torch layout, (Cout,Cin,k..) or (Cin,Cout,k..) for a

@@ -221,6 +221,60 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restr
   }
 }
 
+// BatchNorm with >= 256 partial rows: ONE BLOCK per channel (lanes stride over the rows, fixed
+// assignment; fixed-order tree in LDS) -- 8 dependent loads per lane for 2048 rows instead of 32.
+__global__ __launch_bounds__(256) void norm_finalize_wide_kernel(const float* __restrict__ partials, int rows, int C,
+                                                                 double cnt, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps,
+                                                                 float momentum, float* running_mean,
+                                                                 float* running_var, int64_t* nbt,
+                                                                 float* __restrict__ scale, float* __restrict__ shift,
+                                                                 float* __restrict__ mean, float* __restrict__ invstd) {
+  __shared__ double rs[256], rq[256];
+  const int c = blockIdx.x, t = threadIdx.x;
+  if (c == 0 && t == 0 && nbt) *nbt += 1;
+  double s = 0.0, ss = 0.0;
+  for (int r = t; r < rows; r += 1024) {          // four rows per trip: eight independent loads in flight
+    float v[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r + u * 256;
+      const float* row = partials + (long)(rr < rows ? rr : r) * 2 * C;
+      const float m = rr < rows ? 1.f : 0.f;
+      v[u][0] = row[c] * m;
+      v[u][1] = row[C + c] * m;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s += (double)v[u][0];
+      ss += (double)v[u][1];
+    }
+  }
+  rs[t] = s;
+  rq[t] = ss;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (t < h) { rs[t] += rs[t + h]; rq[t] += rq[t + h]; }
+    __syncthreads();
+  }
+  if (t != 0) return;
+  const double m = rs[0] / cnt;
+  double var = rq[0] / cnt - m * m;
+  if (var < 0.0) var = 0.0;
+  const float istd = (float)(1.0 / sqrt(var + (double)eps));
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const float sc = ga * istd;
+  scale[c] = sc;
+  shift[c] = be - (float)m * sc;
+  mean[c] = (float)m;
+  invstd[c] = istd;
+  if (running_mean) {
+    const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
 // Thousands of partial rows (a conv's fused statistics leave one per pixel tile) are first
 // folded to NQ_COMPACT rows with coalesced reads: lane = channel, waves stride over rows.
 constexpr int COMPACT_ROWS = 32;
@@ -249,11 +303,23 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __r
   if (!instance) {
     double s1 = 0.0, s2 = 0.0;
     const int rows = N * chunks;
-    for (int r = lane; r < rows; r += 64) {
-      const float* row = partials + (long)r * 3 * C;
-      s1 += (double)row[c];
-      s2 += (double)row[C + c];
-      s3 += (double)row[2 * C + c];
+    for (int r = lane; r < rows; r += 256) {
+      float v[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + u * 64;
+        const float* row = partials + (long)(rr < rows ? rr : r) * 3 * C;
+        const float m = rr < rows ? 1.f : 0.f;
+        v[u][0] = row[c] * m;
+        v[u][1] = row[C + c] * m;
+        v[u][2] = row[2 * C + c] * m;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s1 += (double)v[u][0];
+        s2 += (double)v[u][1];
+        s3 += (double)v[u][2];
+      }
     }
     t1 = wave_sum_d(s1);
     t2 = wave_sum_d(s2);
@@ -518,6 +584,12 @@ extern "C" int mpgan_norm_finalize(const float* partials, int32_t n, int32_t chu
     n = 1;
     chunks = COMPACT_ROWS;
   }
+  if (!instance && (long)n * chunks >= 256) {
+    hipLaunchKernelGGL(norm_finalize_wide_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, partials, n * chunks, c,
+                       (double)P * n, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift, mean,
+                       invstd);
+    return check_launch("norm_finalize");
+  }
   const int total = instance ? n * c : c;
   hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, n,
                      chunks, c, (long)P, instance, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale,
@@ -580,6 +652,9 @@ extern "C" int mpgan_norm_bwd_finalize(const float* partials, int32_t n, int32_t
                                        float* c2, void* stream) {
   MPGAN_CHECK_ARG(partials && c1 && c2 && n > 0 && c > 0 && chunks > 0, "norm_bwd_finalize: bad argument");
   // per-channel slope terms go to the tail of the partials buffer (>= c floats past the partial rows)
+  // (Measured and dropped: one 1024-thread block finalizing every channel plus the slope sum, to save
+  //  the second launch -- 23-31 us against 10 + 5: one CU's address unit serialises its 16 waves'
+  //  one-line-per-lane row reads.)
   float* slope_tmp = dslope ? const_cast<float*>(partials) + (long)n * chunks * 3 * c : nullptr;
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, n,
                      chunks, c, (long)P, instance, dgamma, dbeta, slope_tmp, c1, c2);

@@ -19,6 +19,7 @@
 // half-waves take different K quads so a quad feeds four MFMAs.
 #include "mpgan_common.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 
 namespace mpgan {
@@ -1176,9 +1177,17 @@ struct PatchLaunch {
   int patch_floats;      // LDS floats reserved for the input patch (max over phases)
   FastDiv fCout;         // the staging loops are VALU-bound: no software divides in them
   FastDiv fPW[8], fNx[8];
+  // merged form (one block per tile, all phases): union of the phases' tap offsets, LDS offset of
+  // the statistics scratch (the patch stays live across phases)
+  int merged, ylo, yhi, xlo, xhi, stats_off;
+  FastDiv fPWm, fKx;
 };
 
-template <int CIN, int PRO, bool NARROW>
+//   MERGE : one block walks ALL phases of its tile (strided backward-data / transposed convs): the
+//           phases read the same input pixels, so the patch (union of their tap offsets) and the
+//           whole kernel's weights are staged once instead of once per phase -- a quarter of the
+//           blocks, loads and round trips of the phase-per-block form.
+template <int CIN, int PRO, bool NARROW, bool MERGE>
 __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, const PatchLaunch pl) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1189,32 +1198,43 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const unsigned wblk = xcd_remap(blockIdx.x, gridDim.x);
-  // phase fastest: the phases of one tile read the same input patch and run back to back on one XCD
-  const int phase = (int)(wblk % (unsigned)p.nphase);
-  unsigned q = wblk / (unsigned)p.nphase;
+  // !MERGE: phase fastest -- the phases of one tile read the same input patch and run back to back on one XCD
+  const int phase0 = MERGE ? 0 : (int)(wblk % (unsigned)p.nphase);
+  const int nph = MERGE ? p.nphase : 1;
+  unsigned q = MERGE ? wblk : wblk / (unsigned)p.nphase;
   const int tx = (int)(q % (unsigned)pl.tiles_x);
   q /= (unsigned)pl.tiles_x;
   const int ty = (int)(q % (unsigned)pl.tiles_y);
   const int n = (int)(q / (unsigned)pl.tiles_y);
-  const Phase& ph = p.ph[phase];
   const int Cout = p.Cout;
   const int my0 = ty * PT_H, mx0 = tx * PT_W;
-  const int My = ph.Mz > 0 ? ph.My : 0, Mx = ph.Mx;
-  if (my0 >= My || mx0 >= Mx) {
-    if (p.stats && tid < Cout) {
-      float* row = p.stats + (long)wblk * 2 * Cout;
-      row[tid] = 0.f;
-      row[Cout + tid] = 0.f;
+  if constexpr (!MERGE) {
+    const Phase& ph = p.ph[phase0];
+    const int My = ph.Mz > 0 ? ph.My : 0, Mx = ph.Mx;
+    if (my0 >= My || mx0 >= Mx) {
+      if (p.stats && tid < Cout) {
+        float* row = p.stats + (long)wblk * 2 * Cout;
+        row[tid] = 0.f;
+        row[Cout + tid] = 0.f;
+      }
+      return;
     }
-    return;
   }
   const int Hi = p.Hi, Wi = p.Wi, ldi = p.ldi;
   const int isy = p.istride[1], isx = p.istride[2];
   const int dsy = p.dstep[1], dsx = p.dstep[2];
-  const int ny = ph.nz > 0 ? ph.ny : 0, nx = ph.nx;
-  const int ye = ph.dy0 + dsy * (ny > 0 ? ny - 1 : 0), xe = ph.dx0 + dsx * (nx > 0 ? nx - 1 : 0);
-  const int ylo = ph.dy0 < ye ? ph.dy0 : ye, yhi = ph.dy0 < ye ? ye : ph.dy0;
-  const int xlo = ph.dx0 < xe ? ph.dx0 : xe, xhi = ph.dx0 < xe ? xe : ph.dx0;
+  int ylo, yhi, xlo, xhi, sntaps;             // staged patch: tap-offset range; staged weights: tap count
+  if constexpr (MERGE) {
+    ylo = pl.ylo; yhi = pl.yhi; xlo = pl.xlo; xhi = pl.xhi;
+    sntaps = p.Ky * p.Kx;                     // every tap of the kernel, indexed by its flat position
+  } else {
+    const Phase& ph = p.ph[phase0];
+    const int ny = ph.nz > 0 ? ph.ny : 0, nx = ph.nx;
+    const int ye = ph.dy0 + dsy * (ny > 0 ? ny - 1 : 0), xe = ph.dx0 + dsx * (nx > 0 ? nx - 1 : 0);
+    ylo = ph.dy0 < ye ? ph.dy0 : ye; yhi = ph.dy0 < ye ? ye : ph.dy0;
+    xlo = ph.dx0 < xe ? ph.dx0 : xe; xhi = ph.dx0 < xe ? xe : ph.dx0;
+    sntaps = ny * nx;
+  }
   const int PH = (PT_H - 1) * isy + (yhi - ylo) + 1, PW = (PT_W - 1) * isx + (xhi - xlo) + 1;
   const int y0 = my0 * isy + ylo, x0 = mx0 * isx + xlo;
   float* patch = lds;
@@ -1236,9 +1256,9 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
       act = p.pro.act;
     }
     const int total = PH * PW * CQ;
-    const FastDiv fPW = pl.fPW[phase], fNx = pl.fNx[phase], fCout = pl.fCout;
-    const int ntaps = ny * nx;
-    const int wtotal = ntaps * Cout * CQ;
+    const FastDiv fPW = MERGE ? pl.fPWm : pl.fPW[phase0], fNx = MERGE ? pl.fKx : pl.fNx[phase0], fCout = pl.fCout;
+    const Phase& ph0 = p.ph[phase0];
+    const int wtotal = sntaps * Cout * CQ;
     const int Ktot = p.Kz * p.Ky * p.Kx * CIN;
     float4 pv[LU], wv[WU];
     unsigned pok;
@@ -1284,8 +1304,9 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
         unsigned t, co, jy, jx;
         fdivmod(row, fCout, t, co);
         fdivmod(t, fNx, jy, jx);
-        const int ky = ph.ky0 + p.kstep[1] * (int)jy, kx = ph.kx0 + p.kstep[2] * (int)jx;
-        const int tapflat = (ph.kz0 * p.Ky + ky) * p.Kx + kx;
+        const int ky = MERGE ? (int)jy : ph0.ky0 + p.kstep[1] * (int)jy;
+        const int kx = MERGE ? (int)jx : ph0.kx0 + p.kstep[2] * (int)jx;
+        const int tapflat = (ph0.kz0 * p.Ky + ky) * p.Kx + kx;
         wv[u] = *reinterpret_cast<const float4*>(gw + ((int)co * Ktot + tapflat * CIN + 4 * cq));
       }
     };
@@ -1315,6 +1336,19 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
   float* gout = p.out;
   const int ldo = p.ldo, ldr = p.ldr, tanh_out = p.tanh_out;
   const int osy = p.ostride[1], osx = p.ostride[2];
+  for (int phase = phase0; phase < phase0 + nph; ++phase) {
+  const Phase& ph = p.ph[phase];
+  const int My = ph.Mz > 0 ? ph.My : 0, Mx = ph.Mx;
+  const int ny = ph.nz > 0 ? ph.ny : 0, nx = ph.nx;
+  const long srow = MERGE ? (long)wblk * p.nphase + phase : (long)wblk;
+  if (MERGE && (my0 >= My || mx0 >= Mx)) {      // this phase has no pixel in the tile (block-uniform)
+    if (p.stats && tid < Cout) {
+      float* row = p.stats + srow * 2 * Cout;
+      row[tid] = 0.f;
+      row[Cout + tid] = 0.f;
+    }
+    continue;
+  }
   float sm = 0.f, sq = 0.f;
   int scol;          // statistics column of this lane
   bool swrite;       // lane that publishes the wave's column sums
@@ -1334,7 +1368,7 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
         for (int jx = 0; jx < nx; ++jx) {
           const int dx = ph.dx0 + dsx * jx;
           const float* A = Arow + (dy * PW + dx) * PC;
-          const float* B = Brow + (jy * nx + jx) * Cout * PC;
+          const float* B = Brow + (MERGE ? (ph.ky0 + p.kstep[1] * jy) * p.Kx + ph.kx0 + p.kstep[2] * jx : jy * nx + jx) * Cout * PC;
 #pragma unroll
           for (int g = 0; g < CIN / 8; ++g) {
             const float4 a = *reinterpret_cast<const float4*>(A + 8 * g);
@@ -1384,7 +1418,7 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
         for (int jx = 0; jx < nx; ++jx) {
           const int dx = ph.dx0 + dsx * jx;
           const int aoff = (dy * PW + dx) * PC;
-          const float* B = Brow + (jy * nx + jx) * Cout * PC;
+          const float* B = Brow + (MERGE ? (ph.ky0 + p.kstep[1] * jy) * p.Kx + ph.kx0 + p.kstep[2] * jx : jy * nx + jx) * Cout * PC;
 #pragma unroll
           for (int g = 0; g < CIN / 16; ++g) {
             const float4 a0 = *reinterpret_cast<const float4*>(A0row + aoff + 16 * g);
@@ -1430,8 +1464,8 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
   }
 
   if (p.stats) {
-    __syncthreads();                         // the patch is dead: reuse its head for the wave partials
-    float* st = lds;                         // [4 waves][2][32]
+    __syncthreads();                         // !MERGE: the patch is dead, reuse its head for the wave partials
+    float* st = MERGE ? lds + pl.stats_off : lds;   // [4 waves][2][32]
     if (swrite) {
       st[(wid * 2 + 0) * 32 + scol] = sm;
       st[(wid * 2 + 1) * 32 + scol] = sq;
@@ -1444,11 +1478,12 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
         a += st[(w * 2 + 0) * 32 + tid];
         b += st[(w * 2 + 1) * 32 + tid];
       }
-      float* row = p.stats + (long)wblk * 2 * Cout;
+      float* row = p.stats + srow * 2 * Cout;
       row[tid] = a;
       row[Cout + tid] = b;
     }
   }
+  }   // phases
 }
 
 // Geometry test for the patch kernel (pointer alignment is checked at launch).
@@ -1483,19 +1518,48 @@ static bool patch_plan(const GatherConv& p, PatchLaunch* out, int* smem_bytes) {
   if (patch_floats < 256) patch_floats = 256;              // the statistics partials reuse the head
   const long bytes = ((long)patch_floats + (long)maxtaps * p.Cout * PC) * 4;
   if (bytes > 96 * 1024) return false;
+  // merged form: one block per tile walks every phase (see MERGE on the kernel)
+  static const bool no_merge = getenv("MPGAN_DBG_NO_MERGE") != nullptr;
+  bool merged = p.nphase > 1 && !p.pro.scale && !no_merge;
+  int ylo = 1 << 20, yhi = -(1 << 20), xlo = 1 << 20, xhi = -(1 << 20);
+  long mbytes = 0;
+  int mpatch = 0;
+  if (merged) {
+    for (int i = 0; i < p.nphase; ++i) {
+      const Phase& ph = p.ph[i];
+      if (ph.nz == 0) continue;
+      const int ye = ph.dy0 + p.dstep[1] * (ph.ny - 1), xe = ph.dx0 + p.dstep[2] * (ph.nx - 1);
+      ylo = std::min(ylo, std::min(ph.dy0, ye)); yhi = std::max(yhi, std::max(ph.dy0, ye));
+      xlo = std::min(xlo, std::min(ph.dx0, xe)); xhi = std::max(xhi, std::max(ph.dx0, xe));
+    }
+    if (ylo > yhi) merged = false;
+  }
+  if (merged) {
+    const int PHu = (PT_H - 1) * p.istride[1] + (yhi - ylo) + 1, PWu = (PT_W - 1) * p.istride[2] + (xhi - xlo) + 1;
+    mpatch = PHu * PWu * PC;
+    mbytes = ((long)mpatch + (long)p.Ky * p.Kx * p.Cout * PC + 256) * 4;
+    if (mbytes > 96 * 1024) merged = false;
+    else if (out) {
+      out->fPWm = make_fastdiv((unsigned)PWu);
+      out->fKx = make_fastdiv((unsigned)p.Kx);
+    }
+  }
   if (out) {
     out->tiles_x = (maxMx + PT_W - 1) / PT_W;
     out->tiles_y = (maxMy + PT_H - 1) / PT_H;
-    out->patch_floats = patch_floats;
+    out->patch_floats = merged ? mpatch : patch_floats;
     out->fCout = make_fastdiv((unsigned)p.Cout);
+    out->merged = merged ? 1 : 0;
+    out->ylo = ylo; out->yhi = yhi; out->xlo = xlo; out->xhi = xhi;
+    out->stats_off = mpatch + p.Ky * p.Kx * p.Cout * PC;
   }
-  if (smem_bytes) *smem_bytes = (int)bytes;
+  if (smem_bytes) *smem_bytes = (int)(merged ? mbytes : bytes);
   return true;
 }
 
-template <int CIN, int PRO, bool NARROW>
+template <int CIN, int PRO, bool NARROW, bool MERGE>
 static int launch_patch_variant(const GatherConv& p, const PatchLaunch& pl, int smem, hipStream_t st) {
-  auto kern = gather_patch_kernel<CIN, PRO, NARROW>;
+  auto kern = gather_patch_kernel<CIN, PRO, NARROW, MERGE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1506,7 +1570,7 @@ static int launch_patch_variant(const GatherConv& p, const PatchLaunch& pl, int 
     }
     attr_set = true;
   }
-  dim3 grid((unsigned)(pl.tiles_x * pl.tiles_y * p.N * p.nphase));
+  dim3 grid((unsigned)(pl.tiles_x * pl.tiles_y * p.N * (MERGE ? 1 : p.nphase)));
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p, pl);
   return check_launch("gather_patch");
 }
@@ -1514,9 +1578,15 @@ static int launch_patch_variant(const GatherConv& p, const PatchLaunch& pl, int 
 template <int CIN>
 static int launch_patch_cin(const GatherConv& p, const PatchLaunch& pl, int smem, hipStream_t st) {
   const bool pro = p.pro.scale != nullptr;
+  if (pl.merged) {       // never with a prologue (patch_plan)
+    if (p.Cout <= 16) return launch_patch_variant<CIN, 0, true, true>(p, pl, smem, st);
+    return launch_patch_variant<CIN, 0, false, true>(p, pl, smem, st);
+  }
   if (p.Cout <= 16)
-    return pro ? launch_patch_variant<CIN, 1, true>(p, pl, smem, st) : launch_patch_variant<CIN, 0, true>(p, pl, smem, st);
-  return pro ? launch_patch_variant<CIN, 1, false>(p, pl, smem, st) : launch_patch_variant<CIN, 0, false>(p, pl, smem, st);
+    return pro ? launch_patch_variant<CIN, 1, true, false>(p, pl, smem, st)
+               : launch_patch_variant<CIN, 0, true, false>(p, pl, smem, st);
+  return pro ? launch_patch_variant<CIN, 1, false, false>(p, pl, smem, st)
+             : launch_patch_variant<CIN, 0, false, false>(p, pl, smem, st);
 }
 
 static int launch_patch(const GatherConv& p, const PatchLaunch& pl, int smem, hipStream_t st) {
@@ -1815,7 +1885,7 @@ extern "C" int32_t mpgan_conv_stats_rows(const mpgan_conv_geom* g, int32_t has_p
   if (v < 16) return 0;   // thin VALU kernels (or invalid geometry): no fused statistics
   GatherConv p{};
   build_for_forward(p, g);
-  if (v == 16) {          // patch kernel: one partial row per block
+  if (v == 16 || v == 17) {   // patch kernel: one partial row per (tile, phase)
     PatchLaunch pl;
     patch_plan(p, &pl, nullptr);
     return (int32_t)(pl.tiles_x * pl.tiles_y * p.N * p.nphase);
@@ -1921,7 +1991,10 @@ extern "C" int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward
   const bool t2 = p.Cout == 1 && !p.pro.scale && p.Cin % 4 == 0 && lanes >= 1 && lanes <= 64 &&
                   (lanes & (lanes - 1)) == 0 && (long)T * p.Cin * 4 <= 48 * 1024;
   const int v = select_variant(p, max_phase_pixels(p), t1, t2);
-  if (v > 2 && patch_plan(p, nullptr, nullptr)) return 16;
+  if (v > 2) {
+    PatchLaunch pl;
+    if (patch_plan(p, &pl, nullptr)) return pl.merged ? 17 : 16;
+  }
   if (v == 128 && has_prologue == 3 && fast_geometry(p, 128)) return 1128;
   return v;
 }

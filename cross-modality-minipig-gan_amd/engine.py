@@ -231,9 +231,10 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
     if v == 2:
         return "thin_cout1_kernel"
     cin_eff = g.cout if backward_data else g.cin
-    if v == 16:
+    if v in (16, 17):
         cout_eff = g.cin if backward_data else g.cout
-        return f"gather_patch_kernel<{cin_eff}, {1 if has_pro else 0}, {'true' if cout_eff <= 16 else 'false'}>"
+        return (f"gather_patch_kernel<{cin_eff}, {1 if has_pro else 0}, {'true' if cout_eff <= 16 else 'false'}, "
+                f"{'true' if v == 17 else 'false'}>")
     tm, tn, wn = {128: (2, 2, 2), 64: (1, 2, 1), 32: (1, 1, 1)}[v]
     if cin_eff % 32 == 0 or cin_eff == 16:      # software-pipelined main kernel <BN, TM, TN, WN, WRAPS, PRO>
         pro = 0 if not has_pro else (2 if per_sample_norm else (3 if fast_leaky else 1))

@@ -111,7 +111,8 @@ int mpgan_conv_backward_data(const mpgan_conv_geom* g, const float* dy, int32_t 
 
 /* Which kernel serves this geometry (for profiling labels): 1 = thin Cin==1 VALU
  * stencil, 2 = thin Cout==1 VALU stencil, 16 = fp32-MFMA patch kernel (2-D, <= 32
- * output channels, input patch + weights staged once in LDS), 32/64/128 = fp32-MFMA
+ * output channels, input patch + weights staged once in LDS; 17 = its merged form, one block per
+ * tile walking every phase of a strided backward-data / transposed conv), 32/64/128 = fp32-MFMA
  * K-stepped implicit GEMM with that output-channel tile.
  * 1128 = the 128 tile's mask-free instance (pad-free forward conv, Cout % 128 == 0, has_prologue 3).
  * has_prologue: 0 none, 1 per-channel scale/shift, 2 per-(sample, channel), 3 per-channel +

@@ -285,6 +285,7 @@ def test_patch_kernel_forward_stats_prologue_and_dgrad(case):
     g = _geom(2, n, cin, cout, k, s, p, spatial, transposed=tr)
     gc = g.c()
     assert lib().mpgan_conv_variant(ctypes.byref(gc), 0, 1) == 16, "expected the patch kernel for this geometry"
+    assert lib().mpgan_conv_variant(ctypes.byref(gc), 0, 0) == (17 if tr else 16)     # merged phases without a prologue
     wp = ops.pack_weight(w.cuda(), transposed=tr)
 
     # (1) prologue + fused statistics
@@ -320,7 +321,7 @@ def test_patch_kernel_forward_stats_prologue_and_dgrad(case):
         gy = torch.rand(n, cin, *spatial, generator=gen) * 2 - 1
         F.conv2d(xf, wf, None, stride=s, padding=p).backward(gy)
         gfc = gf.c()
-        assert lib().mpgan_conv_variant(ctypes.byref(gfc), 1, 0) == 16
+        assert lib().mpgan_conv_variant(ctypes.byref(gfc), 1, 0) == 17      # all phases in one block
         dx = torch.full((n, *gf.in_dhw, cout), float("nan"), device="cuda")
         ops.conv_backward_data(gf, to_cl(gy), ops.pack_weight(wf.cuda(), for_dgrad=True), dx)
         assert_close(from_cl(dx, 2), xf.grad, what="patch dgrad (strided conv)")

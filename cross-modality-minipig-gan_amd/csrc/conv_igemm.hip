@@ -1643,6 +1643,8 @@ static int select_variant(const GatherConv& p, long maxM, bool thin1, bool thin2
   // matrix pipe ~85 % fed from ONE resident block, while narrow tiles (16 MFMAs per K-step
   // and wave) cannot cover their own load/store/barrier overhead.
   const long mtiles = (maxM + BM - 1) / BM * p.nphase;
+  static const int force_bn = getenv("MPGAN_DBG_BN") ? atoi(getenv("MPGAN_DBG_BN")) : 0;   // experiments
+  if (force_bn == 32 || force_bn == 64 || force_bn == 128) return force_bn;
   int bn = 32;
   if (p.Cout > 64 && mtiles * ((p.Cout + 127) / 128) >= 256) bn = 128;
   else if (p.Cout > 32 && mtiles * ((p.Cout + 63) / 64) >= 256) bn = 64;

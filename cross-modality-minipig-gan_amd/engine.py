@@ -155,7 +155,7 @@ class Program:
         probe = _PROBE
         lanes = self.lanes
         multi = (stream is None and not _SINGLE_STREAM and not (probe is not None and probe.detail)
-                 and any(lanes))
+                 and 1 in lanes)
         side = side_stream(main.device) if multi else None
         s1 = side.cuda_stream if multi else s
         side_busy = False

@@ -243,3 +243,37 @@ def test_generator_eval_mode_uses_running_statistics():
     assert (y.cpu() - y_ref).abs().mean().item() < 1e-4
     after = ours.state_dict()
     assert all(torch.equal(before[k], after[k]) for k in before), "eval forward must not touch parameters or buffers"
+
+
+def test_stream_overlap_is_bitwise_identical_to_single_stream():
+    """The second/third HIP streams (weight gradients beside the backward-data chain, the D step's
+    generator forward beside D(real)) only re-order independent work: every kernel is deterministic,
+    so two G+D steps must leave bit-identical parameters and losses with and without the overlap.
+    A missing event/join shows up here as a difference (or as NaNs)."""
+    from mpgan_amd import engine
+    from mpgan_amd.gan import GAN
+    gen = torch.Generator().manual_seed(99)
+    batch = {"t1w": (torch.rand(4, 1, 64, 64, generator=gen) * 2 - 1).cuda(),
+             "t2w": (torch.rand(4, 1, 64, 64, generator=gen) * 2 - 1).cuda()}
+    results = []
+    for single in (True, False):
+        torch.manual_seed(7)
+        gan = GAN(1, 64, 64, dimensions=2, n_unet_blocks=3, g_lr=1e-3, d_lr=1e-3)
+        gan.train()
+        gan.overlap_streams = not single
+        saved = engine._SINGLE_STREAM
+        engine._SINGLE_STREAM = single
+        try:
+            opts, _ = gan.configure_optimizers()
+            logs = [gan.fit_batch(batch, i, opts) for i in range(2)]
+            torch.cuda.synchronize()
+        finally:
+            engine._SINGLE_STREAM = saved
+        results.append((gan.generator.store.flat.clone(), gan.discriminator.store.flat.clone(),
+                        {k: v.clone() for k, v in logs[-1].items()}))
+    (g1, d1, l1), (g2, d2, l2) = results
+    assert torch.isfinite(g2).all() and torch.isfinite(d2).all()
+    assert torch.equal(g1, g2), (g1 - g2).abs().max().item()
+    assert torch.equal(d1, d2), (d1 - d2).abs().max().item()
+    for k in l1:
+        assert torch.equal(l1[k], l2[k]), k

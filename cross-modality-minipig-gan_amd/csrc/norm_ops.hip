@@ -291,20 +291,47 @@ __global__ __launch_bounds__(256) void partials_compact_kernel(const float* __re
   if (w == 0 && c < W) compact[(long)g * W + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
-// One wave per channel.  slope_tmp[c] receives the channel's PReLU-slope term.
+// One wave per channel (dgamma, dbeta, c1, c2).
+// The grid's LAST block (when dslope != null) adds the PReLU-slope gradient instead: the sum of the
+// third partial over every row and channel, formed directly from the rows (a few thousand values for
+// the U-Net's layers) -- no per-channel hand-off, hence no second launch.
 __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __restrict__ partials, int N, int chunks,
                                                                 int C, long P, int instance, float* dgamma,
-                                                                float* dbeta, float* __restrict__ slope_tmp,
+                                                                float* dbeta, float* dslope,
                                                                 float* __restrict__ c1, float* __restrict__ c2) {
+  if (dslope && blockIdx.x == gridDim.x - 1) {
+    __shared__ double red[256];
+    const long total = (long)N * chunks * C;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < total; i += 1024) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long j = i + u * 256;
+        const long jj = j < total ? j : i;
+        const long r = jj / C;
+        v[u] = j < total ? partials[r * 3 * C + 2 * C + (jj - r * C)] : 0.f;
+      }
+      s += (double)v[0] + (double)v[1] + (double)v[2] + (double)v[3];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+      if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *dslope += (float)red[0];
+    return;
+  }
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int c = gt >> 6, lane = threadIdx.x & 63;
   if (c >= C) return;
-  double t1 = 0.0, t2 = 0.0, s3 = 0.0;
+  double t1 = 0.0, t2 = 0.0;
   if (!instance) {
     double s1 = 0.0, s2 = 0.0;
     const int rows = N * chunks;
     for (int r = lane; r < rows; r += 256) {
-      float v[4][3];
+      float v[4][2];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int rr = r + u * 64;
@@ -312,13 +339,11 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __r
         const float m = rr < rows ? 1.f : 0.f;
         v[u][0] = row[c] * m;
         v[u][1] = row[C + c] * m;
-        v[u][2] = row[2 * C + c] * m;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         s1 += (double)v[u][0];
         s2 += (double)v[u][1];
-        s3 += (double)v[u][2];
       }
     }
     t1 = wave_sum_d(s1);
@@ -335,7 +360,6 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __r
         const float* row = partials + ((long)n * chunks + k) * 3 * C;
         s1 += (double)row[c];
         s2 += (double)row[C + c];
-        s3 += (double)row[2 * C + c];
       }
       s1 = wave_sum_d(s1);
       s2 = wave_sum_d(s2);
@@ -347,20 +371,10 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __r
       }
     }
   }
-  s3 = wave_sum_d(s3);
   if (lane == 0) {
     if (dgamma) dgamma[c] += (float)t2;
     if (dbeta) dbeta[c] += (float)t1;
-    if (slope_tmp) slope_tmp[c] = (float)s3;
   }
-}
-
-// *out += sum(v[0..n)) : one wave, fixed order
-__global__ __launch_bounds__(64) void accum_sum_kernel(const float* __restrict__ v, int n, float* out) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 64) s += (double)v[i];
-  s = wave_sum_d(s);
-  if (threadIdx.x == 0) *out += (float)s;
 }
 
 // ---------------------------------------------------------------------------
@@ -652,13 +666,13 @@ extern "C" int mpgan_norm_bwd_finalize(const float* partials, int32_t n, int32_t
                                        float* c2, void* stream) {
   MPGAN_CHECK_ARG(partials && c1 && c2 && n > 0 && c > 0 && chunks > 0, "norm_bwd_finalize: bad argument");
   // per-channel slope terms go to the tail of the partials buffer (>= c floats past the partial rows)
-  // (Measured and dropped: one 1024-thread block finalizing every channel plus the slope sum, to save
-  //  the second launch -- 23-31 us against 10 + 5: one CU's address unit serialises its 16 waves'
-  //  one-line-per-lane row reads.)
-  float* slope_tmp = dslope ? const_cast<float*>(partials) + (long)n * chunks * 3 * c : nullptr;
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, n,
-                     chunks, c, (long)P, instance, dgamma, dbeta, slope_tmp, c1, c2);
-  if (dslope) hipLaunchKernelGGL(accum_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slope_tmp, c, dslope);
+  // (Measured and dropped: one 1024-thread block finalizing every channel plus the slope sum: 23-31 us
+  //  against 10 -- one CU's address unit serialises its 16 waves' one-line-per-lane row reads.)
+  MPGAN_UNSUPPORTED(dslope && (long)n * chunks * c > (1L << 18),
+                    "norm_bwd_finalize: slope gradient over %ld partials (sized for the generator's layers)",
+                    (long)n * chunks * c);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((c + 3) / 4 + (dslope ? 1 : 0)), dim3(256), 0, (hipStream_t)stream,
+                     partials, n, chunks, c, (long)P, instance, dgamma, dbeta, dslope, c1, c2);
   return check_launch("norm_bwd_finalize");
 }
 

@@ -277,3 +277,27 @@ def test_stream_overlap_is_bitwise_identical_to_single_stream():
     assert torch.equal(d1, d2), (d1 - d2).abs().max().item()
     for k in l1:
         assert torch.equal(l1[k], l2[k]), k
+
+
+def test_generator_output_l1_target_at_c2_shape():
+    """north_star: "G-output L1 vs CPU reference < 1e-4" on 256x256 slices through the full 6-U-Net cascade
+    (config C2's shape at batch 4 so that the CPU oracle finishes in seconds), train-mode BatchNorm."""
+    R = _oracle()
+    from mpgan_amd.networks import CasNetGenerator
+    torch.manual_seed(3)
+    ref = R.CasNetGenerator((1, 256, 256), 6, dimensions=2)
+    ref.train()
+    ours = CasNetGenerator((1, 256, 256), 6, dimensions=2)
+    ours.load_state_dict(ref.state_dict())
+    ours.cuda().train()
+    gen = torch.Generator().manual_seed(1234)
+    x = torch.rand(4, 1, 256, 256, generator=gen) * 2 - 1
+    with torch.no_grad():
+        y_ref = ref(x)
+        y = ours(x.cuda()).cpu()
+    l1 = (y - y_ref).abs().mean().item()
+    mse = ((y - y_ref) ** 2).mean().item()
+    psnr = 10 * torch.log10(torch.tensor(4.0 / max(mse, 1e-30))).item()      # data range 2 ([-1, 1])
+    assert l1 < 1e-4, l1
+    assert (y - y_ref).abs().max().item() < 2e-3
+    assert psnr > 80.0, psnr

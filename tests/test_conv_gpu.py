@@ -310,6 +310,18 @@ def test_patch_kernel_forward_stats_prologue_and_dgrad(case):
     assert_close(from_cl(ybuf[..., 4:4 + cout], 2), torch.tanh(y0 + r), what="patch forward (resid+tanh)")
     assert torch.isnan(ybuf[..., :4]).all() and torch.isnan(ybuf[..., 4 + cout:]).all()
 
+    # (2b) no prologue + fused statistics (for transposed layers: the merged-phase form, one partial row per
+    #      (tile, phase))
+    rows0 = ops.conv_stats_rows(g, False)
+    part0 = torch.full(((rows0 + 32) * 2 * cout,), float("nan"), device="cuda")
+    y2 = torch.full((n, *g.out_dhw, cout), float("nan"), device="cuda")
+    ops.conv_forward(g, to_cl(z), wp, b.cuda(), y2, stats_partials=part0)
+    assert_close(from_cl(y2, 2), y0, what="patch forward (stats, no prologue)")
+    sums0 = part0[:rows0 * 2 * cout].reshape(rows0, 2, cout).double().sum(0).cpu()
+    assert_close(sums0[0].float(), y0.double().sum((0, 2, 3)).float(), rtol=1e-4, what="fused sum (no prologue)")
+    assert_close(sums0[1].float(), (y0.double() ** 2).sum((0, 2, 3)).float(), rtol=1e-4,
+                 what="fused sum of squares (no prologue)")
+
     # (3) backward-data of the mirrored layer (gathers `cin` channels of dy, lands on `cout`)
     if tr:
         # dgrad of a ConvNd(cout -> cin, stride s) is this transposed gather

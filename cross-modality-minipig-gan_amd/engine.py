@@ -156,6 +156,13 @@ class Program:
         lanes = self.lanes
         multi = (stream is None and not _SINGLE_STREAM and not (probe is not None and probe.detail)
                  and 1 in lanes)
+        if probe is None and not multi:            # plain program on one stream: the tight loop
+            for i, (fn, args) in enumerate(self.calls):
+                if fn is not None:
+                    rc = fn(*args, s)
+                    if rc:
+                        raise RuntimeError(f"{self.names[i]} failed (status {rc}): {lib().mpgan_last_error().decode()}")
+            return
         side = side_stream(main.device) if multi else None
         s1 = side.cuda_stream if multi else s
         side_busy = False

@@ -746,7 +746,10 @@ static WgradPlan plan_wgrad(int Cd, int NC, long M) {
   pl.tiles_c = (NC + pl.BG - 1) / pl.BG;
   pl.tiles_d = (Cd + pl.BD - 1) / pl.BD;
   long tiles = (long)pl.tiles_c * pl.tiles_d;
-  long want = (1024 + tiles - 1) / tiles;          // ~4 blocks per CU in total
+  // at most 1024 blocks = two full rounds of the 512 resident ones (2 per CU): rounding UP here left
+  // D.conv2 (5 column tiles x 205 splits = 1025 blocks) with one straggler block after the second round
+  long want = 1024 / tiles;
+  if (want < 1) want = 1;
   long maxsplit = M / 256;                         // at least 8 K-steps per split (small maps need the blocks)
   if (maxsplit < 1) maxsplit = 1;
   long ns = want < maxsplit ? want : maxsplit;

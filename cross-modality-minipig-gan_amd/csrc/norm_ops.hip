@@ -301,18 +301,26 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __r
                                                                 float* __restrict__ c1, float* __restrict__ c2) {
   if (dslope && blockIdx.x == gridDim.x - 1) {
     __shared__ double red[256];
-    const long total = (long)N * chunks * C;
+    const int rows = N * chunks;
     double s = 0.0;
-    for (long i = threadIdx.x; i < total; i += 1024) {
-      float v[4];
+    // thread = (row group, channel): no division in the loop; 8 loads in flight per lane so that this
+    // block does not outlast the per-channel waves beside it
+    const int cw = C <= 256 ? C : 256;                     // channels covered per pass
+    const int c0 = (int)threadIdx.x % cw, rg = (int)threadIdx.x / cw, nrg = 256 / cw;
+    for (int cb = 0; cb < C; cb += cw) {
+      const int c = cb + c0;
+      if (c >= C || rg >= nrg) continue;
+      const float* col = partials + 2 * C + c;
+      for (int r = rg; r < rows; r += 8 * nrg) {
+        float v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const long j = i + u * 256;
-        const long jj = j < total ? j : i;
-        const long r = jj / C;
-        v[u] = j < total ? partials[r * 3 * C + 2 * C + (jj - r * C)] : 0.f;
+        for (int u = 0; u < 8; ++u) {
+          const int rr = r + u * nrg;
+          v[u] = rr < rows ? col[(long)rr * 3 * C] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
       }
-      s += (double)v[0] + (double)v[1] + (double)v[2] + (double)v[3];
     }
     red[threadIdx.x] = s;
     __syncthreads();

@@ -932,16 +932,16 @@ __global__ __launch_bounds__(256) void thin_cin1_full_kernel(const GatherConv p)
   __syncthreads();
   const unsigned Mtot = (unsigned)p.N * ph.Mz * ph.My * ph.Mx;
   const unsigned m = blockIdx.x * 256u + threadIdx.x;
-  if (m >= Mtot) return;
-  const PixDecode d = decode_pixel(p, ph, m);
-  if (d.opix < 0) return;
+  const PixDecode d = decode_pixel(p, ph, m < Mtot ? m : 0u);
+  const bool valid = m < Mtot && d.opix >= 0;
+  if (!valid && !p.stats) return;            // with fused statistics every thread reaches the block reduction
   float4 acc[CQ];
 #pragma unroll
   for (int q = 0; q < CQ; ++q)
     acc[q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float* __restrict__ gin = p.in;
   const int ldi = p.ldi;
-  for (int jz = 0; jz < ph.nz; ++jz) {
+  for (int jz = 0; jz < (valid ? ph.nz : 0); ++jz) {
     const int iz = d.bz + ph.dz0 + p.dstep[0] * jz, kz = ph.kz0 + p.kstep[0] * jz;
     if ((unsigned)iz >= (unsigned)p.Di) continue;
     for (int jy = 0; jy < ph.ny; ++jy) {
@@ -964,17 +964,50 @@ __global__ __launch_bounds__(256) void thin_cin1_full_kernel(const GatherConv p)
       }
     }
   }
-  float* o = p.out + (long)d.opix * p.ldo;
-  const float* r = p.resid ? p.resid + (long)d.opix * p.ldr : nullptr;
+  if (valid) {
+    float* o = p.out + (long)d.opix * p.ldo;
+    const float* r = p.resid ? p.resid + (long)d.opix * p.ldr : nullptr;
 #pragma unroll
-  for (int q = 0; q < CQ; ++q) {
-    float4 v = acc[q];
-    if (r) {
-      const float4 rv = *reinterpret_cast<const float4*>(r + 4 * q);
-      v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+    for (int q = 0; q < CQ; ++q) {
+      float4 v = acc[q];
+      if (r) {
+        const float4 rv = *reinterpret_cast<const float4*>(r + 4 * q);
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      }
+      if (p.tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+      *reinterpret_cast<float4*>(o + 4 * q) = v;
     }
-    if (p.tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
-    *reinterpret_cast<float4*>(o + 4 * q) = v;
+  }
+  if (p.stats) {
+    // Fused BatchNorm statistics (raw output incl. bias; the host forbids resid/tanh with them): the block's
+    // 256 pixel rows go through LDS [256][CO+1], then 2*CO threads sum one column each in row order.
+    float* sred = wl + ((T * CO + 3) & ~3);
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+      float* dst = sred + threadIdx.x * (CO + 1) + 4 * q;
+      dst[0] = valid ? acc[q].x : 0.f; dst[1] = valid ? acc[q].y : 0.f;
+      dst[2] = valid ? acc[q].z : 0.f; dst[3] = valid ? acc[q].w : 0.f;
+    }
+    __syncthreads();
+    // 2*CO (column, moment) pairs x RG row groups: each thread folds 256/RG rows, then the first 2*CO
+    // threads fold the RG partials -- fixed order, 256/RG + RG serial steps instead of 256
+    constexpr int RG = 256 / (2 * CO);
+    const int pair = threadIdx.x % (2 * CO), g = threadIdx.x / (2 * CO);
+    const int c = pair % CO, sq = pair / CO;
+    float t = 0.f;
+    for (int r2 = g; r2 < 256; r2 += RG) {
+      const float v = sred[r2 * (CO + 1) + c];
+      t += sq ? v * v : v;
+    }
+    __syncthreads();
+    sred[g * (2 * CO) + pair] = t;
+    __syncthreads();
+    if (threadIdx.x < 2 * CO) {
+      float tt = 0.f;
+#pragma unroll
+      for (int k = 0; k < RG; ++k) tt += sred[k * (2 * CO) + threadIdx.x];
+      p.stats[((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * CO + sq * CO + c] = tt;
+    }
   }
 }
 
@@ -1116,9 +1149,11 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
     const bool full = v4 && (p.Cout == 16 || p.Cout == 32 || p.Cout == 64) &&
                       (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) &&
                       (!p.resid || ((p.ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0));
+    MPGAN_UNSUPPORTED(p.stats && !(full && p.Cout <= 32),
+                      "thin conv: fused statistics need the all-channel kernel (Cout 16 or 32, 16-byte aligned output/bias)");
     if (full) {
       dim3 grid((unsigned)((maxM + 255) / 256), 1, (unsigned)p.nphase);
-      const size_t smem = (size_t)T * p.Cout * sizeof(float);
+      const size_t smem = ((size_t)((T * p.Cout + 3) & ~3) + (p.stats ? 256 * (size_t)(p.Cout + 1) : 0)) * sizeof(float);
       if (p.Cout == 16) hipLaunchKernelGGL(thin_cin1_full_kernel<4>, grid, dim3(256), smem, st, p);
       else if (p.Cout == 32) hipLaunchKernelGGL(thin_cin1_full_kernel<8>, grid, dim3(256), smem, st, p);
       else hipLaunchKernelGGL(thin_cin1_full_kernel<16>, grid, dim3(256), smem, st, p);
@@ -1884,7 +1919,12 @@ extern "C" int64_t mpgan_conv_splitk_workspace(const mpgan_conv_geom* g) {
 
 extern "C" int32_t mpgan_conv_stats_rows(const mpgan_conv_geom* g, int32_t has_prologue) {
   const int v = mpgan_conv_variant(g, 0, has_prologue);
-  if (v < 16) return 0;   // thin VALU kernels (or invalid geometry): no fused statistics
+  if (v == 1 && (g->cout == 16 || g->cout == 32)) {   // all-channel 1 -> C stencil: one partial row per 256-pixel block
+    GatherConv p1{};
+    build_for_forward(p1, g);
+    return (int32_t)((max_phase_pixels(p1) + 255) / 256) * p1.nphase;
+  }
+  if (v < 16) return 0;   // other thin VALU kernels (or invalid geometry): no fused statistics
   GatherConv p{};
   build_for_forward(p, g);
   if (v == 16 || v == 17) {   // patch kernel: one partial row per (tile, phase)

@@ -1101,14 +1101,26 @@ __global__ __launch_bounds__(256) void convt_quad_cout1_kernel(const GatherConv 
   float t = (b1 ? r1 : r0) + __shfl_xor(b1 ? r0 : r1, 2, 64);
 #pragma unroll
   for (int off = 4; off < LANES; off <<= 1) t += __shfl_xor(t, off, 64);
+  float sv = 0.f;                               // raw output (with bias) of this lane, 0 if it owns none
   if (live && l < 4) {
     const int oy = 2 * y + (l & 1), ox = 2 * x + (l >> 1);
     if (oy < p.Ho && ox < p.Wo) {
       const long pix = ((long)n * p.Ho + oy) * p.Wo + ox;
       float v = t + (p.bias ? p.bias[0] : 0.f);
+      sv = v;
       if (p.resid) v += p.resid[pix * p.ldr];
       if (p.tanh_out) v = tanhf(v);
       p.out[pix * p.ldo] = v;
+    }
+  }
+  if (p.stats) {                                // fused BatchNorm statistics of the single output channel
+    __shared__ float ws1[4], ws2[4];
+    const float s1 = wave_sum(sv), s2 = wave_sum(sv * sv);
+    if ((threadIdx.x & 63) == 0) { ws1[threadIdx.x >> 6] = s1; ws2[threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      p.stats[2 * (long)blockIdx.x] = ws1[0] + ws1[1] + ws1[2] + ws1[3];
+      p.stats[2 * (long)blockIdx.x + 1] = ws2[0] + ws2[1] + ws2[2] + ws2[3];
     }
   }
 }
@@ -1169,6 +1181,8 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
     return check_launch("thin_cin1");
   }
   const int lanes = p.Cin / 4;
+  MPGAN_UNSUPPORTED(p.stats && !convt_quad_ok(p),
+                    "thin conv: fused statistics of a 1-channel output exist for ConvTranspose2d(C -> 1, k3 s2) only");
   if (convt_quad_ok(p)) {
     const long qthreads = (long)p.N * p.Hi * p.Wi * lanes;
     dim3 qgrid((unsigned)((qthreads + 255) / 256));
@@ -1923,6 +1937,16 @@ extern "C" int32_t mpgan_conv_stats_rows(const mpgan_conv_geom* g, int32_t has_p
     GatherConv p1{};
     build_for_forward(p1, g);
     return (int32_t)((max_phase_pixels(p1) + 255) / 256) * p1.nphase;
+  }
+  if (v == 2) {           // quad kernel of ConvTranspose2d(C -> 1, k3 s2): one partial row per block
+    static const float dummy16[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
+    GatherConv p2{};
+    build_for_forward(p2, g);
+    p2.in = dummy16;
+    p2.ldi = g->cin;
+    p2.pro = make_pro(nullptr);
+    if (!convt_quad_ok(p2)) return 0;
+    return (int32_t)(((long)p2.N * p2.Hi * p2.Wi * (p2.Cin / 4) + 255) / 256);
   }
   if (v < 16) return 0;   // other thin VALU kernels (or invalid geometry): no fused statistics
   GatherConv p{};

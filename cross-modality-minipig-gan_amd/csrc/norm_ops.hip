@@ -595,7 +595,7 @@ extern "C" int mpgan_norm_finalize(const float* partials, int32_t n, int32_t chu
                                    float* scale, float* shift, float* mean, float* invstd, void* stream) {
   MPGAN_CHECK_ARG(partials && scale && shift && mean && invstd && n > 0 && c > 0 && chunks > 0,
                   "norm_finalize: bad argument");
-  if (!instance && (long)n * chunks > 4096) {
+  if (!instance && (long)n * chunks > 16384) {   // (the block-per-channel finalize below takes 16K rows in 16 trips)
     // fold the rows first; the compact rows live in the caller's buffer right after the input rows
     const int rows = n * chunks, W = 2 * c;
     float* compact = const_cast<float*>(partials) + (long)rows * W;

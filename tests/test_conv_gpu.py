@@ -207,7 +207,8 @@ def test_unsupported_and_invalid_arguments_raise():
 @pytest.mark.parametrize("cin,cout,k,s,p,spatial,transposed", [
     (16, 32, 3, 2, 1, (20, 24), False), (64, 128, 3, 1, 0, (20, 18), False), (256, 256, 4, 2, 0, (15, 13), False),
     (192, 32, 3, 2, 1, (7, 5), True),
-    (1, 16, 3, 2, 1, (38, 26), False), (1, 32, 3, 1, 1, (17, 23), False)])    # all-channel 1 -> C stencil
+    (1, 16, 3, 2, 1, (38, 26), False), (1, 32, 3, 1, 1, (17, 23), False),     # all-channel 1 -> C stencil
+    (32, 1, 3, 2, 1, (19, 14), True)])                                         # quad kernel of ConvTranspose2d(C -> 1)
 def test_fused_batchnorm_statistics_from_conv_epilogue(cin, cout, k, s, p, spatial, transposed):
     """The conv's own epilogue leaves per-tile (sum, sum^2) rows; finalize turns them
     into the same scale/shift/running stats as F.batch_norm on the conv output."""

@@ -1298,9 +1298,9 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     float slope = 1.f;
     int act = 0;
-    if constexpr (PRO != 0) {
-      sc = *reinterpret_cast<const float4*>(p.pro.scale + 4 * cq);
-      sh = *reinterpret_cast<const float4*>(p.pro.shift + 4 * cq);
+    if constexpr (PRO != 0) {             // per channel, or per (sample, channel): a block serves one sample
+      sc = *reinterpret_cast<const float4*>(p.pro.scale + (long)n * p.pro.n_stride + 4 * cq);
+      sh = *reinterpret_cast<const float4*>(p.pro.shift + (long)n * p.pro.n_stride + 4 * cq);
       slope = pro_slope(p.pro);
       act = p.pro.act;
     }
@@ -1542,7 +1542,7 @@ static bool patch_plan(const GatherConv& p, PatchLaunch* out, int* smem_bytes) {
   if (p.Di != 1 || p.Do != 1 || p.Kz != 1) return false;
   if (!(p.Cin == 16 || p.Cin == 32 || p.Cin == 64)) return false;
   if (p.Cout < 2 || p.Cout > 32) return false;
-  if (p.pro.scale && p.pro.n_stride != 0) return false;
+  if (p.pro.scale && p.pro.n_stride % 4 != 0) return false;
   if (p.ksplit > 1) return false;
   int maxMy = 0, maxMx = 0, maxpix = 0, maxtaps = 0;
   for (int i = 0; i < p.nphase; ++i) {
@@ -1973,7 +1973,7 @@ extern "C" int mpgan_conv_forward(const mpgan_conv_geom* g, const float* x, int3
   build_for_forward(p, g);
   if (stats_partials) {
     MPGAN_CHECK_ARG(!resid && !tanh_out, "conv_forward: fused statistics describe the raw conv output (no resid/tanh)");
-    MPGAN_UNSUPPORTED(mpgan_conv_stats_rows(g, pro && pro->scale) == 0,
+    MPGAN_UNSUPPORTED(mpgan_conv_stats_rows(g, pro && pro->scale ? (pro->n_stride ? 2 : 1) : 0) == 0,
                       "conv_forward: this geometry runs on a thin kernel without fused statistics "
                       "(mpgan_conv_stats_rows() == 0): use mpgan_channel_stats");
     p.stats = stats_partials;

@@ -483,8 +483,8 @@ def emit_norm_stats(prog, z, nb: NormBuf, norm_mod, partials, eps=1e-5, momentum
 
 def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod, partials, pro=None, training=True):
     """Conv whose raw output feeds a norm layer: BatchNorm statistics come out of the
-    conv's own epilogue when the MFMA kernel serves it (one finalize launch follows);
-    InstanceNorm and the thin VALU kernels take the separate statistics pass.  In eval
+    conv's own epilogue (one finalize launch follows); so do InstanceNorm's when the partial rows
+    fall into per-sample groups; otherwise a separate statistics pass runs.  In eval
     mode BatchNorm's scale/shift come from the running statistics instead."""
     if not training and not nb.instance:
         emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro)
@@ -493,7 +493,18 @@ def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod,
                  nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
                  keep=(norm_mod.weight, norm_mod.bias, norm_mod.running_mean, norm_mod.running_var, nb))
         return
-    rows = 0 if nb.instance else ops.conv_stats_rows(g, pro is not None)
+    code = 0 if pro is None else (2 if pro.n_stride else 1)
+    rows = ops.conv_stats_rows(g, code)
+    n, P, _ = ops._cl(y, "conv+norm")
+    if nb.instance and rows:
+        # InstanceNorm needs the partial rows grouped by sample: true for the patch kernel (sample is the
+        # slowest block index), for 128-pixel tiles of a non-transposed conv when 128 | P, and for the
+        # thin kernel's 256-pixel blocks when 256 | P
+        v = ops.conv_variant(g, False, code)
+        grouped = (v in (16, 17) or (v == 1 and P % 256 == 0)
+                   or (v in (32, 64, 128) and not g.transposed and P % 128 == 0))
+        if not grouped or rows % n:
+            rows = 0
     if rows == 0:
         emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro)
         emit_norm_stats(prog, y, nb, norm_mod, partials)
@@ -501,7 +512,12 @@ def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod,
     c = g.cout
     assert partials.numel() >= (rows + 32) * 2 * c
     emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro, stats=partials)
-    n, P, _ = ops._cl(y, "conv+norm")
+    if nb.instance:
+        prog.add("norm_finalize", lib().mpgan_norm_finalize, partials.data_ptr(), n, rows // n, c, P, 1,
+                 _p(norm_mod.weight), _p(norm_mod.bias), float(norm_mod.eps), 0.0, None, None, None,
+                 nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
+                 keep=(norm_mod.weight, norm_mod.bias, nb, partials))
+        return
     rm = getattr(norm_mod, "running_mean", None)
     rv = getattr(norm_mod, "running_var", None)
     nbt = getattr(norm_mod, "num_batches_tracked", None)
@@ -572,7 +588,7 @@ class Scratch:
     def want_ws(self, g: ConvGeom):
         self.ws_need = max(self.ws_need, ops.conv_wgrad_workspace(g) // 4)
         # fused-statistics partial rows of the forward conv (with or without prologue: same count)
-        rows = max(ops.conv_stats_rows(g, True), ops.conv_stats_rows(g, False))
+        rows = max(ops.conv_stats_rows(g, code) for code in (0, 1, 2))
         self.partials_need = max(self.partials_need, (rows + 32) * 2 * g.cout)   # + finalize's fold scratch
 
     def alloc(self):

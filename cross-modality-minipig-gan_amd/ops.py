@@ -146,9 +146,16 @@ def _check_in_out(g: ConvGeom, x: torch.Tensor, y: torch.Tensor, what: str):
         raise ValueError(f"{what}: output shape {tuple(y.shape)} != {(g.n, *g.out_dhw, g.cout)}")
 
 
-def conv_stats_rows(g: ConvGeom, has_prologue: bool) -> int:
+def conv_stats_rows(g: ConvGeom, has_prologue) -> int:
+    """Partial rows the conv's fused statistics leave (0: none).  has_prologue: False/True, or the C
+    code 0 none / 1 per-channel / 2 per-(sample, channel) / 3 per-channel fast LeakyReLU."""
     gc = g.c()
     return int(lib().mpgan_conv_stats_rows(C.byref(gc), int(has_prologue)))
+
+
+def conv_variant(g: ConvGeom, backward_data: bool, has_prologue) -> int:
+    gc = g.c()
+    return int(lib().mpgan_conv_variant(C.byref(gc), int(backward_data), int(has_prologue)))
 
 
 def conv_forward(g: ConvGeom, x, w_packed, bias, y, *, pro: Optional[Prologue] = None, resid=None,
@@ -164,7 +171,8 @@ def conv_forward(g: ConvGeom, x, w_packed, bias, y, *, pro: Optional[Prologue] =
     if w_packed.numel() < g.cout * g.cin * g.taps:
         raise ValueError("conv_forward: packed weight too small")
     gc = g.c()
-    if stats_partials is not None and stats_partials.numel() < conv_stats_rows(g, pro is not None) * 2 * g.cout:
+    if stats_partials is not None and stats_partials.numel() < conv_stats_rows(
+            g, 0 if pro is None else (2 if pro.n_stride else 1)) * 2 * g.cout:
         raise ValueError("conv_forward: stats_partials too small")
     check(lib().mpgan_conv_forward(C.byref(gc), x.data_ptr(), ldx, w_packed.data_ptr(), _ptr(bias), _pro(pro),
                                    _ptr(resid), ldr, int(tanh_out), _ptr(stats_partials), y.data_ptr(), ldy,

@@ -57,7 +57,7 @@ def cpu_baseline_leg(gan, spatial, sample_bs=4, timed_steps=6):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))                # the GPU box's CPU share for one GPU
     torch.set_num_threads(cores)
-    ref = R.GAN((1, *spatial), dimensions=2)
+    ref = R.GAN((1, *spatial), dimensions=2, norm=gan.generator.norm)
     ref.generator.load_state_dict({k: v.cpu() for k, v in gan.generator.state_dict().items()})
     ref.discriminator.load_state_dict({k: v.cpu() for k, v in gan.discriminator.state_dict().items()})
     ref.train()
@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the N>1 code path where ranks must share one GPU)")
     ap.add_argument("--no-gfwd", action="store_true", help="skip the side measurement of the G forward (clean profiles)")
+    ap.add_argument("--norm", default="batch", choices=("batch", "instance"),
+                    help="generator norm layers: the reference's BatchNorm (default, the headline) or north_star's InstanceNorm")
     ap.add_argument("--lr", type=float, default=1e-6,
                     help="Adam lr for both nets.  The reference's 5e-4 drives the 952,576-input Linear head into "
                          "sigmoid saturation within ONE step (its own checkpoints show g_loss=100.03, d_loss=45.00), "
@@ -125,7 +127,7 @@ def main():
 
     spatial = (args.size,) * args.dims
     torch.manual_seed(0)                           # torch default init, identical on every rank
-    gan = GAN(1, *spatial, dimensions=args.dims, device=dev, g_lr=args.lr, d_lr=args.lr)
+    gan = GAN(1, *spatial, dimensions=args.dims, device=dev, g_lr=args.lr, d_lr=args.lr, norm=args.norm)
     # With torch-default init the 952,576-input Linear saturates the sigmoid (BCE sits on its
     # -100 clamp, as in the reference's own checkpoints: g_loss=100.03, d_loss=45.00), which
     # makes every discriminator gradient exactly zero.  All-zero MFMA operands let the chip
@@ -205,7 +207,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"C3: {args.size}x{args.size} bs{args.batch}/GPU" if args.dims == 2 else
                                     f"C5 shape (fp32): {args.size}^3 bs{args.batch}/GPU") +
-                                   " full G+D adversarial step (6-UNet CasNet G + conv D, BatchNorm, Adam x2)",
+                                   " full G+D adversarial step (6-UNet CasNet G + conv D, " +
+                                   ("BatchNorm" if args.norm == "batch" else "InstanceNorm in G") + ", Adam x2)",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "adam_lr": args.lr},
             "roofline": roofline,
             "step_mfma_frac": (step_flops_sample * args.batch) / (dt / args.steps) / 1e12 / PEAK_FP32_TFLOPS,

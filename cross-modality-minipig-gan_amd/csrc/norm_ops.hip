@@ -759,6 +759,37 @@ extern "C" int mpgan_norm_from_running(const float* gamma, const float* beta, co
   return check_launch("norm_from_running");
 }
 
+// All eval-mode norm layers of a network in ONE launch: block b serves table row b =
+// {gamma, beta, running_mean, running_var, scale, shift, mean, invstd (device addresses), C, eps bits}.
+__global__ __launch_bounds__(256) void norm_from_running_multi_kernel(const long long* __restrict__ table) {
+  const long long* e = table + 10 * (long)blockIdx.x;
+  const float* gamma = reinterpret_cast<const float*>(e[0]);
+  const float* beta = reinterpret_cast<const float*>(e[1]);
+  const float* rm = reinterpret_cast<const float*>(e[2]);
+  const float* rv = reinterpret_cast<const float*>(e[3]);
+  float* scale = reinterpret_cast<float*>(e[4]);
+  float* shift = reinterpret_cast<float*>(e[5]);
+  float* mean = reinterpret_cast<float*>(e[6]);
+  float* invstd = reinterpret_cast<float*>(e[7]);
+  const int c = (int)e[8];
+  const float eps = __uint_as_float((unsigned)e[9]);
+  for (int i = threadIdx.x; i < c; i += 256) {
+    const float istd = 1.f / sqrtf(rv[i] + eps);
+    const float sc = (gamma ? gamma[i] : 1.f) * istd;
+    scale[i] = sc;
+    shift[i] = (beta ? beta[i] : 0.f) - rm[i] * sc;
+    mean[i] = rm[i];
+    invstd[i] = istd;
+  }
+}
+
+extern "C" int mpgan_norm_from_running_multi(const int64_t* table, int32_t n_layers, void* stream) {
+  MPGAN_CHECK_ARG(table && n_layers > 0, "norm_from_running_multi: bad argument");
+  hipLaunchKernelGGL(norm_from_running_multi_kernel, dim3((unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(table));
+  return check_launch("norm_from_running_multi");
+}
+
 extern "C" int32_t mpgan_tap_l1_partials(void) { return 3 * 1024; }
 
 extern "C" int mpgan_tap_l1(const float* za, int32_t lda, const mpgan_prologue* pa, const float* zb, int32_t ldb,

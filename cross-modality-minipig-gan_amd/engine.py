@@ -481,13 +481,17 @@ def emit_norm_stats(prog, z, nb: NormBuf, norm_mod, partials, eps=1e-5, momentum
              keep=(norm_mod.weight, norm_mod.bias, rm, rv, nbt, nb))
 
 
-def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod, partials, pro=None, training=True):
+def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod, partials, pro=None, training=True,
+                       eval_norms=None):
     """Conv whose raw output feeds a norm layer: BatchNorm statistics come out of the
     conv's own epilogue (one finalize launch follows); so do InstanceNorm's when the partial rows
     fall into per-sample groups; otherwise a separate statistics pass runs.  In eval
     mode BatchNorm's scale/shift come from the running statistics instead."""
     if not training and not nb.instance:
         emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro)
+        if eval_norms is not None:       # input-independent: the plan folds all of them into one launch up front
+            eval_norms.append((norm_mod, nb, g.cout))
+            return
         prog.add("norm_from_running", lib().mpgan_norm_from_running, _p(norm_mod.weight), _p(norm_mod.bias),
                  norm_mod.running_mean.data_ptr(), norm_mod.running_var.data_ptr(), float(norm_mod.eps), g.cout,
                  nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
@@ -525,6 +529,23 @@ def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod,
              _p(norm_mod.weight), _p(norm_mod.bias), float(norm_mod.eps), float(norm_mod.momentum), _p(rm), _p(rv),
              _p(nbt), nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
              keep=(norm_mod.weight, norm_mod.bias, rm, rv, nbt, nb, partials))
+
+
+def emit_eval_norms(prog, eval_norms, dev):
+    """One launch computing scale/shift of every eval-mode BatchNorm layer of a plan (they depend on
+    parameters and running statistics only, not on the input)."""
+    if not eval_norms:
+        return
+    import struct
+    rows = []
+    for norm_mod, nb, c in eval_norms:
+        eps_bits = struct.unpack("<I", struct.pack("<f", float(norm_mod.eps)))[0]
+        rows.append([_p(norm_mod.weight) or 0, _p(norm_mod.bias) or 0, norm_mod.running_mean.data_ptr(),
+                     norm_mod.running_var.data_ptr(), nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(),
+                     nb.invstd.data_ptr(), c, eps_bits])
+    table = torch.tensor(rows, dtype=torch.int64, device=dev)
+    prog.add("norm_from_running_multi", lib().mpgan_norm_from_running_multi, table.data_ptr(), len(rows),
+             keep=(table, eval_norms))
 
 
 def emit_norm_act_add(prog, z, pz, r, pr, out, tanh=False):
@@ -730,6 +751,7 @@ class UNetPlan:
         self._late = (down_state, up_state)
         self.scratch = scratch
         self._marks = (own_mark, wait_mark)
+        self.eval_norms = [] if not training else None   # eval mode: (norm module, NormBuf, C) of every layer
         self._build_args = dict(x_in=x_in, y_out=y_out, tanh_out=tanh_out, want_backward=want_backward, gbufs=gbufs,
                                 chans=chans, L=L, sizes=sizes, in_ch=in_ch, sub_out=sub_out, cats=cats, R=R,
                                 bottom=dict(bc0=bc0, BN0=BN0, BA0=BA0, bc1=bc1, BN1=BN1, BA1=BA1, res=bottom.res,
@@ -755,29 +777,29 @@ class UNetPlan:
         for l in range(L - 1):
             s = down_state[l]
             (cv0, N0, A0), (cv1, N1, A1) = s["ru"].units
-            emit_conv_fwd_norm(f, s["g0"], s["xin"], wp(R(cv0)), cv0.bias, s["z0"], s["nb0"], N0, part, training=tr)
+            emit_conv_fwd_norm(f, s["g0"], s["xin"], wp(R(cv0)), cv0.bias, s["z0"], s["nb0"], N0, part, training=tr, eval_norms=self.eval_norms)
             # (the residual conv could run on the side stream; measured: the event hand-offs cost more
             #  than the ~20 us kernels they would overlap -- G forward 4.42 -> 4.56 ms)
             emit_conv_fwd(f, s["gr"], s["xin"], wp(R(s["ru"].res)), s["ru"].res.bias, s["r"])
             emit_conv_fwd_norm(f, s["g1"], s["z0"], wp(R(cv1)), cv1.bias, s["z1"], s["nb1"], N1, part,
-                               pro=prelu_pro(s["nb0"], A0), training=tr)
+                               pro=prelu_pro(s["nb0"], A0), training=tr, eval_norms=self.eval_norms)
             emit_norm_act_add(f, s["z1"], prelu_pro(s["nb1"], A1), s["r"], None, cats[l][..., :s["c"]])
         d_last = cats[L - 2][..., :bt["cb_in"]]
         emit_conv_fwd_norm(f, bt["gb0"], d_last, wp(R(bt["bc0"])), bt["bc0"].bias, bt["zb0"], bt["nbb0"], bt["BN0"],
-                           part, training=tr)
+                           part, training=tr, eval_norms=self.eval_norms)
         emit_conv_fwd(f, bt["gbr"], d_last, wp(R(bt["res"])), bt["res"].bias, bt["rb"])
         emit_conv_fwd_norm(f, bt["gb1"], bt["zb0"], wp(R(bt["bc1"])), bt["bc1"].bias, bt["zb1"], bt["nbb1"],
-                           bt["BN1"], part, pro=prelu_pro(bt["nbb0"], bt["BA0"]), training=tr)
+                           bt["BN1"], part, pro=prelu_pro(bt["nbb0"], bt["BA0"]), training=tr, eval_norms=self.eval_norms)
         emit_norm_act_add(f, bt["zb1"], prelu_pro(bt["nbb1"], bt["BA1"]), bt["rb"], None,
                           cats[L - 2][..., bt["cb_in"]:])
         for l in range(L - 2, -1, -1):
             u = up_state[l]
             emit_conv_fwd_norm(f, u["gt"], cats[l], wp(R(u["ct"])), u["ct"].bias, u["zt"], u["nbt"], u["NT"], part,
-                               training=tr)
+                               training=tr, eval_norms=self.eval_norms)
             pt = prelu_pro(u["nbt"], u["AT"])
             if "zu" in u:
                 emit_conv_fwd_norm(f, u["gu"], u["zt"], wp(R(u["cu"])), u["cu"].bias, u["zu"], u["nbu"], u["NU"], part,
-                                   pro=pt, training=tr)
+                                   pro=pt, training=tr, eval_norms=self.eval_norms)
                 dst = cats[l - 1][..., chans[l - 1]:] if l > 0 else y_out
                 emit_norm_act_add(f, u["zu"], prelu_pro(u["nbu"], u["AU"]), u["zt"], pt, dst,
                                   tanh=(a["tanh_out"] and l == 0))
@@ -927,6 +949,8 @@ class GeneratorPlan:
             p.emit()
         self.fwd = Program()
         store.emit_pack(self.fwd)
+        if not training:
+            emit_eval_norms(self.fwd, [e for p in self.unet_plans for e in p.eval_norms], dev)
         for p in self.unet_plans:
             self.fwd.extend(p.fwd)
         self.bwd = Program()

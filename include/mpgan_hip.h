@@ -187,6 +187,11 @@ int mpgan_norm_from_running(const float* gamma, const float* beta, const float* 
                             const float* running_var, float eps, int32_t c,
                             float* scale, float* shift, float* mean, float* invstd, void* stream);
 
+/* The same for every norm layer of a network in one launch.  table: device int64[n_layers][10] =
+ * {gamma, beta, running_mean, running_var, scale, shift, mean, invstd (device addresses; gamma/beta
+ * may be 0), C, eps (the float's bit pattern in the low 32 bits)}. */
+int mpgan_norm_from_running_multi(const int64_t* table, int32_t n_layers, void* stream);
+
 /* out = act(z*scale+shift) [+ r]   where r is either a plain tensor or itself
  * act(zr*scale_r+shift_r); optional tanh on the sum.  (ResidualUnit.forward's
  * "cx + res" and the generator's final Tanh, GAN_final.py:117.) */

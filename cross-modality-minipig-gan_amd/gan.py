@@ -211,3 +211,22 @@ class GAN(nn.Module):
             for p in other.parameters():
                 p.requires_grad_(True)
         return dict(self.logged)
+
+
+def load_reference_checkpoint(model: nn.Module, path: str, strict: bool = False):
+    """Load a Lightning checkpoint written by the reference's trainer (code/GAN/inferrence.py:97-106:
+    `torch.load(ckpt)['state_dict']`, `load_state_dict(..., strict=False)`) into `model` (a GAN, or a
+    bare generator / discriminator: then the `generator.` / `discriminator.` prefix is stripped).
+    The file is read with `weights_only=True`: nothing in it is executed; a checkpoint whose pickle
+    needs arbitrary classes is refused by torch with its own error."""
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    sd = blob["state_dict"] if isinstance(blob, dict) and "state_dict" in blob else blob
+    if not isinstance(model, GAN):
+        want = set(model.state_dict().keys())
+        for prefix in ("generator.", "discriminator."):
+            sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+            if sub and set(sub) & want:
+                sd = sub
+                break
+    return model.load_state_dict(sd, strict=strict)
+

@@ -86,3 +86,25 @@ def test_shard_batch_partitions_without_overlap():
     assert [p["t1w"].shape[0] for p in parts] == [3, 3, 2, 2]
     assert torch.equal(torch.cat([p["t1w"] for p in parts]), b["t1w"])
     assert torch.equal(torch.cat([p["t2w"] for p in parts]), b["t2w"])
+
+
+def test_reference_checkpoint_loads_into_modules(tmp_path):
+    """inferrence.py:97-106: a Lightning checkpoint's `state_dict` (keys `generator.*`, `discriminator.*`)
+    loads into the whole GAN and, prefix stripped, into a bare generator; extra entries are ignored
+    (strict=False, as the reference does).  The file is a synthetic one in the reference's format."""
+    from mpgan_amd.gan import load_reference_checkpoint
+    from mpgan_amd.networks import CasNetGenerator
+    from oracle import refmodel as R
+    ref = R.GAN((1, 32, 32), dimensions=2, n_unet_blocks=2)
+    R.closed_form_fill_(ref.generator)
+    sd = {"generator." + k: v for k, v in ref.generator.state_dict().items()}
+    sd.update({"discriminator." + k: v for k, v in ref.discriminator.state_dict().items()})
+    sd["some_metric.total"] = torch.zeros(1)
+    path = tmp_path / "epoch=3.ckpt"
+    torch.save({"epoch": 3, "global_step": 120, "state_dict": sd, "hparams_name": "kwargs"}, path)
+    g = CasNetGenerator((1, 32, 32), 2, dimensions=2, device="cpu")
+    res = load_reference_checkpoint(g, str(path))
+    assert not res.missing_keys
+    for k, v in ref.generator.state_dict().items():
+        assert torch.equal(g.state_dict()[k], v), k
+

@@ -4,7 +4,13 @@ training step (BASELINE.json config C3: bs 16 per GPU, fp32), weak-scaled over
 N GPUs with one RCCL all-reduce per optimiser.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 from a bare shell (no WORLD_SIZE in the environment): this process starts N fresh
+rank processes itself -- before it has made any GPU call -- waits for them and exits with
+their status; rank 0 prints the JSON line.  Under `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N ...` the ranks already exist and each process is one.
+A world size that does not match --gpus, or fewer devices than ranks with the nccl (= RCCL)
+backend, is refused with a non-zero exit code: never a silent 1-rank run.
 
 A "step" = Lightning's per-batch loop of the reference (G step then D step:
 G fwd x2, G bwd, D fwd x3, D bwd x3, two fused Adam steps) on one synthetic
@@ -13,49 +19,137 @@ batch already resident in HBM.  Rank 0 prints ONE JSON line.
   roofline     : the dominant kernel (the BN=128 fp32-MFMA implicit-GEMM conv with the
                  BatchNorm+LeakyReLU load prologue: D's three dense layers, 9 forward
                  launches per step) timed live with HIP events on the launch stream
-                 during the timed steps;
-                 achieved = algorithmic FLOPs of those launches / their time,
-                 against the 157.3 TFLOP/s fp32 matrix peak.
-  cpu_baseline : the CPU oracle (plain torch restatement, oracle/) timed on this
-                 host on a bounded sample (4 slices per step, 6 steps), plus the
-                 G-output L1 between the HIP path and that oracle.
+                 during the timed steps; achieved = algorithmic FLOPs of those launches /
+                 their time, against the 157.3 TFLOP/s fp32 matrix peak.  `dense_families`
+                 gives the same figure for each family of D's dense kernels (forward,
+                 backward-data, weight gradient) and their time-weighted mean.
+  cpu_baseline : the CPU oracle (plain torch restatement, oracle/) timed on this host on
+                 the SAME configuration (C3: 256x256, bs 16; 1 warm-up + 3 steps, all cores
+                 of the affinity mask), plus the G-output L1 between the HIP path and it.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
+PEAK_BF16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak
 DOMINANT = "gather_conv_pipe_kernel<128, 2, 2, 2, 1, 3, true>"   # as rocprofv3 names it (D's dense layers, forward)
+DENSE_MIN_GFLOP = 20.0            # per launch: D's conv2/3/4 in all three directions, nothing of G
+HEAD_WEIGHT_SCALE = 0.02          # see main(): keeps the 952,576-input head out of sigmoid saturation
 
 
 def note(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def kernel_source_hash():
+    """sha256 over the HIP sources: profiles/traffic.json is only quoted when it was measured on these."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "cross-modality-minipig-gan_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="slices per GPU (C3/C4: 16)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dims", type=int, default=2, choices=(2, 3),
+                    help="2: BASELINE configs C3/C4 (256x256 slices); 3: config C5's shape (the reference's own "
+                         "3-D graph: --dims 3 --size 128 --batch 4 [--dtype bf16])")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
+                    help="storage type of the discriminator's activations / packed weights (accumulation, statistics, "
+                         "master weights and Adam stay fp32); bf16 is config C5")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                                                      "the N>1 code path where ranks must share one GPU)")
+    ap.add_argument("--no-gfwd", action="store_true", help="skip the side measurement of the G forward (clean profiles)")
+    ap.add_argument("--norm", default="batch", choices=("batch", "instance"),
+                    help="generator norm layers: the reference's BatchNorm (default, the headline) or north_star's InstanceNorm")
+    ap.add_argument("--lr", type=float, default=1e-6,
+                    help="Adam lr for both nets.  The reference's 5e-4 drives the 952,576-input Linear head into "
+                         "sigmoid saturation within ONE step (its own checkpoints show g_loss=100.03, d_loss=45.00), "
+                         "after which every D gradient is exactly zero; all-zero MFMA operands let the chip clock up, "
+                         "so the default keeps the same work on non-degenerate data.")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, form the process group, all-reduce one number and print the JSON stub: "
+                         "the launcher's own test (no GPU work)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args) -> int:
+    """Parent of an N-rank run: no GPU call has been made in this process (counting devices does not
+    initialise the runtime).  Starts N fresh interpreters of this file, one rank each, and returns
+    the first non-zero exit status (0 when every rank succeeded)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and not args.rendezvous_only and ndev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} with the nccl (RCCL) backend needs {args.gpus} devices, this node shows "
+              f"{ndev}; refusing to run fewer ranks (use --backend gloo only to rehearse ranks sharing a GPU)",
+              file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:                                   # a failed rank must not leave the others waiting in a collective
+        for p in list(live):
+            st = p.poll()
+            if st is None:
+                continue
+            live.remove(p)
+            if st != 0 and rc == 0:
+                rc = st if st > 0 else 1
+                for q in live:
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def synthetic_batch(bs, spatial, rank, device):
+    import torch
     g = torch.Generator().manual_seed(1234 + rank)
     t1 = torch.rand(bs, 1, *spatial, generator=g) * 2 - 1
     t2 = torch.rand(bs, 1, *spatial, generator=g) * 2 - 1
     return {"t1w": t1.to(device), "t2w": t2.to(device)}
 
 
-def cpu_baseline_leg(gan, spatial, sample_bs=4, timed_steps=6):
-    """Oracle on the host cores: bounded sample of the same workload + the
+def cpu_baseline_leg(gan, spatial, sample_bs=16, timed_steps=3):
+    """Oracle on the host cores, the plan of BASELINE.md section 3: the bench's own configuration
+    (bs 16 at 256x256), every core of the affinity mask, 1 warm-up + 3 timed G+D steps; plus the
     G-output L1 of the HIP path against it (same weights, same input)."""
+    import torch
     from oracle import refmodel as R
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))                # the GPU box's CPU share for one GPU
     torch.set_num_threads(cores)
     ref = R.GAN((1, *spatial), dimensions=2, norm=gan.generator.norm)
     ref.generator.load_state_dict({k: v.cpu() for k, v in gan.generator.state_dict().items()})
@@ -70,56 +164,74 @@ def cpu_baseline_leg(gan, spatial, sample_bs=4, timed_steps=6):
     l1 = (y - y_ref).abs().mean().item()
     mse = ((y - y_ref) ** 2).mean().item()
     psnr = float("inf") if mse == 0 else 10.0 * torch.log10(torch.tensor(4.0 / mse)).item()  # data range 2
-    note(f"cpu baseline: oracle G forward done (L1 vs HIP {l1:.2e}); timing {timed_steps} oracle steps on {cores} threads")
+    note(f"cpu baseline: oracle G forward done (L1 vs HIP {l1:.2e}); timing {timed_steps} oracle steps at bs {sample_bs} "
+         f"on {cores} threads")
     opts, _ = ref.configure_optimizers()
     ref.step(batch, 0, opts)                      # warm-up
     note("cpu baseline: warm-up step done")
     t0 = time.perf_counter()
     for i in range(timed_steps):
         ref.step(batch, i + 1, opts)
+        note(f"cpu baseline: step {i} done")
     dt = time.perf_counter() - t0
     return {"value": sample_bs * timed_steps / dt, "unit": "slices/s", "cores": cores, "kind": "port",
-            "sample": f"{timed_steps} G+D steps of the torch-CPU oracle at 256x256, bs {sample_bs} (1 warm-up)",
+            "sample": f"{timed_steps} G+D steps of the torch-CPU oracle at 256x256, bs {sample_bs} (1 warm-up), "
+                      f"{cores} threads = every core of the affinity mask",
             "g_output_l1_vs_cpu": l1, "g_output_psnr_vs_cpu_db": psnr}
 
 
+def family_of(name: str) -> str:
+    if name.startswith("wgrad"):
+        return "wgrad"
+    return "dgrad" if name.startswith("dgrad:") else "fwd"
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="slices per GPU (C3/C4: 16)")
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dims", type=int, default=2, choices=(2, 3),
-                    help="2: BASELINE configs C3/C4 (256x256 slices); 3: config C5's shape (the reference's own "
-                         "3-D graph, e.g. --dims 3 --size 128 --batch 4; fp32 -- bf16 storage is not built)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
-                                                      "the N>1 code path where ranks must share one GPU)")
-    ap.add_argument("--no-gfwd", action="store_true", help="skip the side measurement of the G forward (clean profiles)")
-    ap.add_argument("--norm", default="batch", choices=("batch", "instance"),
-                    help="generator norm layers: the reference's BatchNorm (default, the headline) or north_star's InstanceNorm")
-    ap.add_argument("--lr", type=float, default=1e-6,
-                    help="Adam lr for both nets.  The reference's 5e-4 drives the 952,576-input Linear head into "
-                         "sigmoid saturation within ONE step (its own checkpoints show g_loss=100.03, d_loss=45.00), "
-                         "after which every D gradient is exactly zero; all-zero MFMA operands let the chip clock up, "
-                         "so the default keeps the same work on non-degenerate data.")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))              # parent: spawns the ranks, makes no GPU call itself
+
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run a different rank count")
+
+    if args.rendezvous_only:                       # launcher self-test: CPU only
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
+                                                         "backend": "gloo" if world > 1 else None},
+                              "rank_sum": t.item()}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     ndev = torch.cuda.device_count()
-    torch.cuda.set_device(local_rank % max(ndev, 1))
-    dev = torch.device("cuda", local_rank % max(ndev, 1))
+    if ndev < 1:
+        raise SystemExit("bench.py: no GPU visible (there is no CPU path)")
+    if world > 1 and args.backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} nccl ranks need {world} devices, {ndev} visible")
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
 
     from mpgan_amd import engine
     from mpgan_amd.gan import GAN
@@ -127,20 +239,19 @@ def main():
 
     spatial = (args.size,) * args.dims
     torch.manual_seed(0)                           # torch default init, identical on every rank
-    gan = GAN(1, *spatial, dimensions=args.dims, device=dev, g_lr=args.lr, d_lr=args.lr, norm=args.norm)
+    gan = GAN(1, *spatial, dimensions=args.dims, device=dev, g_lr=args.lr, d_lr=args.lr, norm=args.norm,
+              storage_dtype=args.dtype)
     # With torch-default init the 952,576-input Linear saturates the sigmoid (BCE sits on its
     # -100 clamp, as in the reference's own checkpoints: g_loss=100.03, d_loss=45.00), which
     # makes every discriminator gradient exactly zero.  All-zero MFMA operands let the chip
     # clock up and would flatter the timing, so the head's weight is scaled to keep logits O(1).
+    head_scale = HEAD_WEIGHT_SCALE * (0.4 if args.dims == 3 else 1.0)   # 3-D head: 6,243,584 inputs at 128^3
     with torch.no_grad():
-        gan.discriminator.model_linear[1].weight.mul_(0.02)
+        gan.discriminator.model_linear[1].weight.mul_(head_scale)
     gan.train()
     ddp = DataParallelGAN(gan)
     opts, _ = gan.configure_optimizers()
     batch = synthetic_batch(args.batch, spatial, rank, dev)
-    if args.dims == 3:      # keep the 3-D head (6,243,584 inputs at 128^3) out of saturation as well
-        with torch.no_grad():
-            gan.discriminator.model_linear[1].weight.mul_(0.4)
 
     def barrier():
         if world > 1:
@@ -152,7 +263,7 @@ def main():
         gan.fit_batch(batch, i, opts)
         torch.cuda.synchronize()
         note(f"warm-up step {i} done")
-    probe = engine.KernelProbe(want={DOMINANT})
+    probe = engine.KernelProbe(min_flops=DENSE_MIN_GFLOP * 1e9)
     engine.set_probe(probe)
     barrier()
     t0 = time.perf_counter()
@@ -166,28 +277,53 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    ddp.sync_logged()                              # mean over ranks of the four logged scalars
     losses = {k: float(v) for k, v in gan.logged.items()}
 
     if rank == 0:
-        summ = probe.summary().get(DOMINANT, dict(calls=0, ms=0.0, flops=0.0))
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_FP32_TFLOPS
+        summ_all = probe.summary()
+        # dominant kernel = the one with the most time among the dense launches (named, so rocprof can be matched)
+        dominant = max(summ_all, key=lambda k: summ_all[k]["ms"]) if summ_all else DOMINANT
+        if args.dims == 2 and args.dtype == "f32" and DOMINANT in summ_all:
+            dominant = DOMINANT
+        summ = summ_all.get(dominant, dict(calls=0, ms=0.0, flops=0.0))
         achieved = summ["flops"] / (summ["ms"] * 1e-3) / 1e12 if summ["ms"] > 0 else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
+        src_hash = kernel_source_hash()
         tp = os.path.join(ROOT, "profiles", "traffic.json")       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(tp) and args.dims == 2 and args.size == 256 and args.batch == 16:
-            traffic = json.load(open(tp)).get(DOMINANT, {}).get("hbm_bytes_per_launch")
-        roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "kernel": DOMINANT,
+        if os.path.exists(tp) and args.dims == 2 and args.size == 256 and args.batch == 16 and args.dtype == "f32":
+            tj = json.load(open(tp))
+            traffic_src = tj.get("_source_sha256_16")
+            if traffic_src == src_hash:            # only quoted when measured on exactly these kernel sources
+                traffic = tj.get(dominant, {}).get("hbm_bytes_per_launch")
+        fam = {}
+        for k, d in summ_all.items():
+            f = fam.setdefault(family_of(k), dict(calls=0, ms=0.0, flops=0.0))
+            for key in ("calls", "ms", "flops"):
+                f[key] += d[key]
+        fam_out = {k: {"launches_per_step": d["calls"] / max(args.steps, 1), "ms_per_step": d["ms"] / max(args.steps, 1),
+                       "tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] else 0.0,
+                       "frac": d["flops"] / (d["ms"] * 1e-3) / 1e12 / peak if d["ms"] else 0.0}
+                   for k, d in sorted(fam.items())}
+        tot_ms = sum(d["ms"] for d in fam.values())
+        tot_fl = sum(d["flops"] for d in fam.values())
+        fam_out["time_weighted_frac"] = tot_fl / (tot_ms * 1e-3) / 1e12 / peak if tot_ms else 0.0
+        roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                    "frac": achieved / peak, "traffic": traffic, "traffic_kernel_sources": traffic_src,
+                    "kernel_sources": src_hash, "kernel": dominant.replace("dgrad:", ""),
                     "launches_per_step": summ["calls"] / max(args.steps, 1),
                     "avg_launch_ms": summ["ms"] / max(summ["calls"], 1),
-                    "avg_launch_gflop": summ["flops"] / max(summ["calls"], 1) / 1e9}
+                    "avg_launch_gflop": summ["flops"] / max(summ["calls"], 1) / 1e9,
+                    "dense_families": fam_out}
         # G-forward-only (config C2) on the side: not part of `value`
         g_fwd_ms = None
         with torch.no_grad():
-            for _ in range(0 if args.no_gfwd else 2):
+            for _ in range(0 if args.no_gfwd else 3):
                 gan.generator(batch["t1w"])
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            reps = 0 if args.no_gfwd else 10
+            reps = 0 if args.no_gfwd else 20
             for _ in range(reps):
                 gan.generator(batch["t1w"])
             torch.cuda.synchronize()
@@ -199,17 +335,25 @@ def main():
         else:
             g_flops_sample, step_flops_sample = 145.131e9 * (args.size / 128.0) ** 3, 16.64e12 * (args.size / 128.0) ** 3
         g_fwd_flops = g_flops_sample * args.batch
+        if args.dims == 2:
+            workload = f"C3: {args.size}x{args.size} bs{args.batch}/GPU"
+        elif args.dtype == "bf16":
+            workload = f"C5: {args.size}^3 bs{args.batch}/GPU, bf16 storage in D (fp32 accumulate/statistics/Adam; G fp32)"
+        else:
+            workload = f"C5 shape (fp32): {args.size}^3 bs{args.batch}/GPU"
         out = {
             "metric": ("T1->T2 256x256 slices/sec (G+D step)" if args.dims == 2 else
                        f"T1->T2 {args.size}^3 volumes/sec (G+D step)"),
-            "value": world * args.batch * args.steps / dt, "unit": "slices/s" if args.dims == 2 else "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": world * args.batch * args.steps / dt, "unit": "slices/s" if args.dims == 2 else "volumes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"C3: {args.size}x{args.size} bs{args.batch}/GPU" if args.dims == 2 else
-                                    f"C5 shape (fp32): {args.size}^3 bs{args.batch}/GPU") +
-                                   " full G+D adversarial step (6-UNet CasNet G + conv D, " +
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": workload + " full G+D adversarial step (6-UNet CasNet G + conv D, " +
                                    ("BatchNorm" if args.norm == "batch" else "InstanceNorm in G") + ", Adam x2)",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "adam_lr": args.lr},
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "adam_lr": args.lr,
+                       "d_head_weight_scale": head_scale},
+            "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
+                     "backend": dist.get_backend() if world > 1 else None},
             "roofline": roofline,
             "step_mfma_frac": (step_flops_sample * args.batch) / (dt / args.steps) / 1e12 / PEAK_FP32_TFLOPS,
             "g_forward": None if g_fwd_ms is None else {

@@ -35,9 +35,10 @@ class KernelProbe:
     """HIP-event timing of tagged launches (bench.py's live roofline figure):
     events are recorded on the stream the kernels are launched on."""
 
-    def __init__(self, want=None, detail=False):
+    def __init__(self, want=None, detail=False, min_flops=0.0):
         self.want = want            # None = every tagged call, else a set of kernel names
         self.detail = detail        # True: time EVERY call, keyed "<c entry point> <geometry>" (tools/profile_step.py)
+        self.min_flops = min_flops  # only launches with at least this much algorithmic work (the dense families)
         self.samples = []           # (kernel, flops, ev0, ev1)
 
     def summary(self):
@@ -199,15 +200,16 @@ class Program:
             if probe is not None:
                 if probe.detail:
                     tag = (f"{self.names[i]} {self.descs[i]}".strip(), tag[1] if tag else 0.0)
-                timed = tag is not None and (probe.want is None or tag[0] in probe.want) and not on_side
-            if timed:
+                timed = (tag is not None and (probe.want is None or tag[0] in probe.want)
+                         and tag[1] >= probe.min_flops)
+            if timed:                              # events go on the stream the kernel is launched on
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+                e0.record(side if on_side else main)
             rc = fn(*args, s1 if on_side else s)
             if rc:
                 raise RuntimeError(f"{self.names[i]} failed (status {rc}): {lib().mpgan_last_error().decode()}")
             if timed:
-                e1.record()
+                e1.record(side if on_side else main)
                 probe.samples.append((tag[0], tag[1], e0, e1))
         if side_busy:                              # never leave work un-joined behind a program
             ev = self._event(-1)
@@ -429,7 +431,7 @@ def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):
     gc = g.c()
     prog.add("conv_backward_data", lib().mpgan_conv_backward_data, C.byref(gc), dy.data_ptr(), _ld(dy),
              wp_bwd.data_ptr(), _p(resid), _ld(resid), dx.data_ptr(), _ld(dx), keep=(gc, dy, wp_bwd, dx, resid),
-             desc=_gdesc(g), tag=(gather_kernel_name(g, True, False), 2.0 * conv_macs(g)))
+             desc=_gdesc(g), tag=("dgrad:" + gather_kernel_name(g, True, False), 2.0 * conv_macs(g)))
 
 
 def emit_conv_wgrad(prog, g: ConvGeom, x, dy, dw, ws, pro=None, dbias=None, lane=0):

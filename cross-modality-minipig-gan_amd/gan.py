@@ -5,6 +5,7 @@ in SURVEY.md Appendix B), every FLOP in HIP kernels.
 from __future__ import annotations
 
 import os
+import re
 import types
 from typing import Dict, List, Optional
 
@@ -53,9 +54,32 @@ class _L1Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        g = ctx.grad
-        ops.scale_by_device_scalar(g, gout.contiguous(), g)
+        g = torch.empty_like(ctx.grad)          # a fresh tensor: a second backward (retain_graph) sees the unscaled sign
+        ops.scale_by_device_scalar(ctx.grad, gout.contiguous(), g)
         return g, None
+
+
+class _AxpbyFn(torch.autograd.Function):
+    """alpha*a + beta*b on device scalars (the loss sums of training_step) through the library's own
+    pointwise kernel, so that no torch elementwise kernel sits on the step path."""
+
+    @staticmethod
+    def forward(ctx, a, alpha, b, beta):
+        ctx.alpha, ctx.beta = alpha, beta
+        out = torch.empty_like(a)
+        ops.axpby(a.contiguous(), alpha, b.contiguous(), beta, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        gout = gout.contiguous()
+        ga = ops.axpby(gout, ctx.alpha, None, 0.0, torch.empty_like(gout)) if ctx.needs_input_grad[0] else None
+        gb = ops.axpby(gout, ctx.beta, None, 0.0, torch.empty_like(gout)) if ctx.needs_input_grad[2] else None
+        return ga, None, gb, None
+
+
+def scalar_axpby(a, alpha, b, beta):
+    return _AxpbyFn.apply(a, float(alpha), b, float(beta))
 
 
 def adversarial_loss(y_hat, y):
@@ -86,10 +110,52 @@ class FusedAdam(torch.optim.Optimizer):
     def _state(self):
         store = self.net.store
         if self._version != store.version:
+            # the flat layout is a function of the module tree only: a re-created store (.to()/.cuda()/.float()
+            # after the first step) keeps the moments; a different layout restarts Adam as a whole
+            old_m, old_v = getattr(self, "exp_avg", None), getattr(self, "exp_avg_sq", None)
             self.exp_avg = torch.zeros_like(store.flat)
             self.exp_avg_sq = torch.zeros_like(store.flat)
+            if old_m is not None and old_m.numel() == store.flat.numel():
+                self.exp_avg.copy_(old_m)
+                self.exp_avg_sq.copy_(old_v)
+            elif old_m is not None:
+                import warnings
+                warnings.warn("FusedAdam: parameter layout changed; moments and step count reset")
+                self.step_count = 0
             self._version = store.version
         return store
+
+    # torch.optim.Adam's state_dict format (per-parameter step / exp_avg / exp_avg_sq), so that a
+    # Lightning-style 'optimizer_states' entry round-trips and a torch Adam state loads here
+    def state_dict(self):
+        store = self._state()
+        params = list(self.net.parameters())
+        state = {}
+        if self.step_count > 0:
+            for i, p in enumerate(params):
+                o = store.offset(p)
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[o:o + p.numel()].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view(p.shape).clone()}
+        g = self.param_groups[0]
+        return {"state": state,
+                "param_groups": [{"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0,
+                                  "amsgrad": False, "params": list(range(len(params)))}]}
+
+    def load_state_dict(self, sd):
+        store = self._state()
+        params = list(self.net.parameters())
+        g = sd["param_groups"][0]
+        self.param_groups[0].update(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"])
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step_count = 0
+        for i, st in sd["state"].items():
+            p = params[int(i)]
+            o = store.offset(p)
+            self.exp_avg[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            self.step_count = max(self.step_count, int(float(st["step"])))
 
     def zero_grad(self, set_to_none: bool = False):
         store = self._state()
@@ -123,7 +189,7 @@ class GAN(nn.Module):
                  g_lr: float = 0.0005, b1: float = 0.5, b2: float = 0.999, batch_size: int = 64, example_data=None,
                  one_sided_label_value=0.9, *, dimensions: Optional[int] = None, norm: str = "batch",
                  n_unet_blocks: int = 6, unet_channels=(16, 32, 64, 128), unet_strides=(2, 2, 2), device="cuda",
-                 **kwargs):
+                 storage_dtype: str = "f32", **kwargs):
         super().__init__()
         if dimensions is None:
             dimensions = 3 if depth is not None else 2
@@ -132,7 +198,8 @@ class GAN(nn.Module):
         data_shape = (channels, width, height) + ((depth,) if dimensions == 3 else ())
         self.generator = CasNetGenerator(data_shape, n_unet_blocks, dimensions=dimensions, norm=norm,
                                          channels=unet_channels, strides=unet_strides, device=device)
-        self.discriminator = Discriminator(data_shape, dimensions=dimensions, device=device)
+        self.discriminator = Discriminator(data_shape, dimensions=dimensions, device=device,
+                                           storage_dtype=storage_dtype)
         self.logged: Dict[str, torch.Tensor] = {}
         self.ddp = None  # set by parallel.DataParallelGAN
         self.overlap_streams = not os.environ.get("MPGAN_SINGLE_STREAM")
@@ -160,7 +227,7 @@ class GAN(nn.Module):
             self.log("g_adv_loss", g_adv_loss)
             g_recon_loss = self.reconstruction_loss(generated_imgs, t2w_images)
             self.log("g_recon_loss", g_recon_loss)
-            g_loss = g_adv_loss + g_recon_loss
+            g_loss = scalar_axpby(g_adv_loss, 1.0, g_recon_loss, 1.0)
             self.log("g_loss", g_loss)
             return g_loss
         if optimizer_idx == 1:                      # GAN_final.py:276-296
@@ -183,7 +250,7 @@ class GAN(nn.Module):
                 generated = self(t1w_images).detach()
             fake = torch.zeros(t1w_images.shape[0], 1, device=t1w_images.device, dtype=t1w_images.dtype)
             fake_loss = self.adversarial_loss(self.discriminator(generated), fake)
-            d_loss = (real_loss + fake_loss) / 2
+            d_loss = scalar_axpby(real_loss, 0.5, fake_loss, 0.5)
             self.log("d_loss", d_loss)
             return d_loss
 
@@ -213,13 +280,49 @@ class GAN(nn.Module):
         return dict(self.logged)
 
 
-def load_reference_checkpoint(model: nn.Module, path: str, strict: bool = False):
+_UNSUPPORTED_GLOBAL = re.compile(r"GLOBAL ([\w\.]+) was not an allowed global")
+
+
+def _inert_stub(full_path: str):
+    """A placeholder class carrying the module / name of a global the checkpoint's pickle refers to
+    (e.g. `pytorch_lightning.callbacks.model_checkpoint.ModelCheckpoint`, which Lightning 1.2.1 uses as
+    a KEY of checkpoint['callbacks']).  Nothing is imported and nothing from the file runs: the
+    weights-only unpickler resolves the name to this class, whose construction ignores its arguments.
+    Dict-like names come back as plain dicts so that their items can still be read."""
+    module, _, name = full_path.rpartition(".")
+    ns = {"__module__": module, "__init__": lambda self, *a, **k: None, "__setstate__": lambda self, state: None}
+    if name.endswith("Dict") or name.endswith("dict"):
+        ns["__new__"] = staticmethod(lambda cls, *a, **k: {})
+    return type(name, (object,), ns)
+
+
+def load_checkpoint_blob(path: str):
+    """`torch.load(path, weights_only=True)` that also accepts the reference's real checkpoint format:
+    Lightning writes class objects and small helper types into the pickle next to the tensors, which the
+    weights-only unpickler refuses by name.  Each refused name is mapped to an inert stub (above) through
+    `torch.serialization.safe_globals` and the load is retried; the stubs never leave this function's scope."""
+    stubs = []
+    for _ in range(64):
+        try:
+            with torch.serialization.safe_globals(stubs):
+                return torch.load(path, map_location="cpu", weights_only=True)
+        except Exception as e:          # pickle.UnpicklingError from the weights-only unpickler
+            m = _UNSUPPORTED_GLOBAL.search(str(e))
+            if m is None or any(f"{c.__module__}.{c.__name__}" == m.group(1) for c in stubs):
+                raise
+            stubs.append(_inert_stub(m.group(1)))
+    raise RuntimeError(f"{path}: more than 64 distinct non-tensor globals in the pickle")
+
+
+def load_reference_checkpoint(model: nn.Module, path: str, strict: bool = False, optimizers=None):
     """Load a Lightning checkpoint written by the reference's trainer (code/GAN/inferrence.py:97-106:
     `torch.load(ckpt)['state_dict']`, `load_state_dict(..., strict=False)`) into `model` (a GAN, or a
     bare generator / discriminator: then the `generator.` / `discriminator.` prefix is stripped).
-    The file is read with `weights_only=True`: nothing in it is executed; a checkpoint whose pickle
-    needs arbitrary classes is refused by torch with its own error."""
-    blob = torch.load(path, map_location="cpu", weights_only=True)
+    The file is read with `weights_only=True`: nothing in it is executed (see load_checkpoint_blob for
+    how the trainer's non-tensor entries -- `callbacks` keyed by the ModelCheckpoint class,
+    `hyper_parameters`, `optimizer_states` -- are tolerated).  `optimizers` (the list
+    `configure_optimizers` returned) additionally restores Adam's moments from `optimizer_states`."""
+    blob = load_checkpoint_blob(path)
     sd = blob["state_dict"] if isinstance(blob, dict) and "state_dict" in blob else blob
     if not isinstance(model, GAN):
         want = set(model.state_dict().keys())
@@ -228,5 +331,8 @@ def load_reference_checkpoint(model: nn.Module, path: str, strict: bool = False)
             if sub and set(sub) & want:
                 sd = sub
                 break
-    return model.load_state_dict(sd, strict=strict)
-
+    res = model.load_state_dict(sd, strict=strict)
+    if optimizers is not None and isinstance(blob, dict) and blob.get("optimizer_states"):
+        for opt, st in zip(optimizers, blob["optimizer_states"]):
+            opt.load_state_dict(st)
+    return res

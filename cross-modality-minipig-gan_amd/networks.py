@@ -294,11 +294,14 @@ class Discriminator(_EngineModule):
     Linear(256*29*29*29, 1) for its 128^3 input (:201); in_features here is
     computed from img_shape (the same number for 128^3)."""
 
-    def __init__(self, img_shape, use_perceptual=True, *, dimensions=3, device=None):
+    def __init__(self, img_shape, use_perceptual=True, *, dimensions=3, device=None, storage_dtype="f32"):
         super().__init__()
+        if storage_dtype not in ("f32", "bf16"):
+            raise ValueError(f"storage_dtype must be 'f32' or 'bf16', got {storage_dtype!r}")
         self.use_perceptual = use_perceptual
         self.img_shape = img_shape
         self.dimensions = dimensions
+        self.storage_dtype = storage_dtype      # activations / packed weights in HBM; parameters, statistics, Adam: fp32
         Cv, Bn = _CONV[dimensions], _BN[dimensions]
         self.model_conv = nn.Sequential(
             Cv(1, 64, 3, 1), Bn(64), nn.LeakyReLU(0.2, inplace=True),

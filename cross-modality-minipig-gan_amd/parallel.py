@@ -37,6 +37,18 @@ class DataParallelGAN:
             dist.all_reduce(net.store.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
         opt.grad_scale = 1.0 / self.world
 
+    def sync_logged(self):
+        """Mean over ranks of the logged scalars (`self.log(..., sync_dist=True)` of the reference,
+        code/GAN/GAN_final.py:266): ONE all-reduce of the four values, on request -- not per step."""
+        names = sorted(self.gan.logged)
+        if self.world > 1 and names:
+            t = torch.stack([self.gan.logged[k].reshape(()).float() for k in names])
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+            t /= self.world
+            for i, k in enumerate(names):
+                self.gan.logged[k] = t[i]
+        return dict(self.gan.logged)
+
 
 def reduce_flat_gradient(flat_grad: torch.Tensor, world: int, group=None) -> float:
     """The collective on its own (testable with gloo on CPU): sum all-reduce in

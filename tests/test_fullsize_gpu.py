@@ -103,3 +103,126 @@ def test_batchnorm_statistics_at_full_size_are_normalised():
     y = z.view(-1, cout).double() * scale.double() + shift.double()
     assert y.mean(0).abs().max().item() < 1e-4
     assert (y.var(0, unbiased=False) - 1).abs().max().item() < 1e-3
+
+
+class _GradTap:
+    """Stands where DataParallelGAN would (gan.ddp): copies each network's raw flat gradient
+    after its backward, before Adam turns it into +-lr steps."""
+
+    def __init__(self):
+        self.grads = {}
+
+    def reduce_gradients(self, net, opt):
+        self.grads[id(net)] = {n: p.grad.detach().clone().cpu() for n, p in net.named_parameters()}
+
+
+def _rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-300)).item()
+
+
+def test_full_gd_step_at_c3_matches_oracle():
+    """BASELINE config C3 itself: ONE full G+D step at 256x256, bs 16, closed-form weights, against the
+    CPU oracle's step (about 10-20 s of host time).  What is pinned, in the order the step produces it:
+      * g_adv / g_recon / g_loss (computed before any update) to 2e-3 relative;
+      * the generator's raw flat gradient, per parameter, by relative L2 (pre-norm conv biases, whose true
+        gradient is zero, only by magnitude);
+      * d_loss to 2e-3 -- the oracle's generator is OVERWRITTEN with our updated parameters after the G
+        update, so the D step of both sides starts from identical weights (Adam turns rounding noise in
+        tiny gradients into +-lr steps; without the overwrite only 5 % could be asked);
+      * the discriminator's raw gradients: the 952,576-input head's weight, the first layer's weight,
+        and every other parameter by relative L2;
+      * BatchNorm running statistics and batch counters of both networks (G: 2 forwards, D: 3);
+      * the same step with the stream overlap switched off is bit-identical (side-stream G forward in
+        the D step, weight gradients beside the backward-data chain)."""
+    from mpgan_amd import engine
+    from mpgan_amd.gan import GAN
+    from oracle import refmodel as R
+    ref = R.GAN((1, 256, 256), dimensions=2)
+    R.closed_form_fill_(ref.generator)
+    R.closed_form_fill_(ref.discriminator)
+    ref.train()
+    gen = torch.Generator().manual_seed(1234)
+    t1 = torch.rand(16, 1, 256, 256, generator=gen) * 2 - 1
+    t2 = torch.rand(16, 1, 256, 256, generator=gen) * 2 - 1
+    batch = {"t1w": t1.cuda(), "t2w": t2.cuda()}
+
+    def run_ours(single_stream):
+        ours = GAN(1, 256, 256, dimensions=2)
+        ours.generator.load_state_dict(ref_sd_g)
+        ours.discriminator.load_state_dict(ref_sd_d)
+        ours.train()
+        ours.overlap_streams = not single_stream
+        tap = _GradTap()
+        ours.ddp = tap
+        saved = engine._SINGLE_STREAM
+        engine._SINGLE_STREAM = single_stream
+        try:
+            opts, _ = ours.configure_optimizers()
+            log = {k: float(v) for k, v in ours.fit_batch(batch, 0, opts).items()}
+            torch.cuda.synchronize()
+        finally:
+            engine._SINGLE_STREAM = saved
+        return ours, tap, log
+
+    ref_sd_g = {k: v.clone() for k, v in ref.generator.state_dict().items()}
+    ref_sd_d = {k: v.clone() for k, v in ref.discriminator.state_dict().items()}
+    ours, tap, log = run_ours(False)
+    ours1, tap1, log1 = run_ours(True)
+    assert log == log1, (log, log1)
+    assert torch.equal(ours.generator.store.flat, ours1.generator.store.flat)
+    assert torch.equal(ours.discriminator.store.flat, ours1.discriminator.store.flat)
+    del ours1, tap1
+
+    # ---- oracle, G step (Lightning loop restated in oracle.refmodel.GAN.step, split at the optimizer) ----
+    opts_ref, _ = ref.configure_optimizers()
+    for p in ref.discriminator.parameters():
+        p.requires_grad_(False)
+    opts_ref[0].zero_grad()
+    ref.training_step({"t1w": t1, "t2w": t2}, 0, 0).backward()
+    for k in ("g_adv_loss", "g_recon_loss", "g_loss"):
+        got, want = log[k], float(ref.logged[k])
+        assert abs(got - want) <= 2e-3 * abs(want) + 1e-6, (k, got, want)
+    gg = tap.grads[id(ours.generator)]
+    keys = set(dict(ref.generator.named_parameters()).keys())
+    gmax = max(p.grad.abs().max().item() for p in ref.generator.parameters())
+    worst = 0.0
+    for name, p in ref.generator.named_parameters():
+        if name.endswith("conv.bias") and (name[:-len("conv.bias")] + "adn.N.weight") in keys:
+            assert gg[name].abs().max().item() <= 1e-4 * gmax + 1e-6, name          # true gradient: zero
+            continue
+        worst = max(worst, _rel_l2(gg[name], p.grad))
+        assert _rel_l2(gg[name], p.grad) <= 2e-2, (name, _rel_l2(gg[name], p.grad))
+    flat_ours = torch.cat([gg[n].reshape(-1) for n, _ in ref.generator.named_parameters()])
+    flat_ref = torch.cat([p.grad.reshape(-1) for _, p in ref.generator.named_parameters()])
+    assert _rel_l2(flat_ours, flat_ref) <= 5e-3, _rel_l2(flat_ours, flat_ref)
+    for p in ref.discriminator.parameters():
+        p.requires_grad_(True)
+    # ---- level the field: our updated generator into the oracle (buffers stay the oracle's own) ----
+    with torch.no_grad():
+        for name, p in ref.generator.named_parameters():
+            p.copy_(dict(ours.generator.named_parameters())[name].detach().cpu())
+    # ---- oracle, D step ----
+    for p in ref.generator.parameters():
+        p.requires_grad_(False)
+    opts_ref[1].zero_grad()
+    ref.training_step({"t1w": t1, "t2w": t2}, 0, 1).backward()
+    got, want = log["d_loss"], float(ref.logged["d_loss"])
+    assert abs(got - want) <= 2e-3 * abs(want) + 1e-6, ("d_loss", got, want)
+    gd = tap.grads[id(ours.discriminator)]
+    rd = dict(ref.discriminator.named_parameters())
+    gmax_d = max(p.grad.abs().max().item() for p in rd.values())
+    for name, p in rd.items():
+        if name in ("model_conv.0.bias", "model_conv.3.bias", "model_conv.6.bias", "model_conv.9.bias"):
+            assert gd[name].abs().max().item() <= 1e-4 * gmax_d + 1e-6, name
+            continue
+        tol = 5e-3 if name in ("model_linear.1.weight", "model_conv.0.weight", "model_linear.1.bias") else 2e-2
+        assert _rel_l2(gd[name], p.grad) <= tol, (name, _rel_l2(gd[name], p.grad))
+    # ---- BatchNorm bookkeeping of both networks ----
+    for net, rnet, fwd in ((ours.generator, ref.generator, 2), (ours.discriminator, ref.discriminator, 3)):
+        sd = net.state_dict()
+        for k, v in rnet.state_dict().items():
+            if k.endswith("num_batches_tracked"):
+                assert int(sd[k]) == fwd == int(v), (k, int(sd[k]), int(v))
+            elif k.endswith("running_mean") or k.endswith("running_var"):
+                err = (sd[k].cpu() - v).abs().max().item()
+                assert err <= 1e-4 * v.abs().max().item() + 1e-6, (k, err)

@@ -108,3 +108,76 @@ def test_reference_checkpoint_loads_into_modules(tmp_path):
     for k, v in ref.generator.state_dict().items():
         assert torch.equal(g.state_dict()[k], v), k
 
+
+
+def test_reference_checkpoint_with_lightning_pickle_globals(tmp_path):
+    """A checkpoint in the REAL format of the reference's trainer (Lightning 1.2.1, three ModelCheckpoint
+    callbacks, GAN_final.py:448-484): `callbacks` is keyed by the callback CLASS, so the pickle holds a
+    GLOBAL of a module that is not importable here; `optimizer_states` / `hyper_parameters` ride along.
+    The weights-only loader must read it without importing or executing anything from the file."""
+    import sys
+    import types
+    from mpgan_amd.gan import load_checkpoint_blob, load_reference_checkpoint
+    from mpgan_amd.networks import CasNetGenerator
+    from oracle import refmodel as R
+    # stand-ins for the trainer's classes, present only while the file is WRITTEN
+    names = ["pytorch_lightning", "pytorch_lightning.callbacks", "pytorch_lightning.callbacks.model_checkpoint",
+             "pytorch_lightning.utilities", "pytorch_lightning.utilities.parsing"]
+    mods = {n: types.ModuleType(n) for n in names}
+    ModelCheckpoint = type("ModelCheckpoint", (), {"__module__": names[2]})
+    AttributeDict = type("AttributeDict", (dict,), {"__module__": names[4]})
+    mods[names[2]].ModelCheckpoint = ModelCheckpoint
+    mods[names[4]].AttributeDict = AttributeDict
+    ref = R.GAN((1, 32, 32), dimensions=2, n_unet_blocks=2)
+    R.closed_form_fill_(ref.generator)
+    sd = {"generator." + k: v for k, v in ref.generator.state_dict().items()}
+    sd.update({"discriminator." + k: v for k, v in ref.discriminator.state_dict().items()})
+    opt = torch.optim.Adam(ref.generator.parameters(), lr=5e-4, betas=(0.5, 0.999))
+    for p in ref.generator.parameters():
+        p.grad = torch.full_like(p, 0.25)
+    opt.step()
+    hp = AttributeDict(channels=1, width=32, height=32, g_lr=5e-4)
+    blob = {"epoch": 30, "global_step": 14000, "pytorch-lightning_version": "1.2.1",
+            "callbacks": {ModelCheckpoint: {"monitor": "g_loss_step", "best_model_score": torch.tensor(100.03),
+                                            "best_model_path": "epoch=30-g_loss_step=100.03.ckpt"}},
+            "optimizer_states": [opt.state_dict()], "lr_schedulers": [], "state_dict": sd,
+            "hparams_name": "kwargs", "hyper_parameters": hp}
+    path = tmp_path / "epoch=30-g_loss_step=100.03-g_recon_loss_step=0.03-d_loss_step=45.00.ckpt"
+    sys.modules.update(mods)
+    try:
+        torch.save(blob, path)
+    finally:
+        for n in names:
+            sys.modules.pop(n, None)
+    with pytest.raises(Exception):                      # plain weights_only load refuses the class-keyed entry
+        torch.load(path, map_location="cpu", weights_only=True)
+    got = load_checkpoint_blob(str(path))
+    assert got["epoch"] == 30 and got["hyper_parameters"]["width"] == 32
+    assert not any(n in sys.modules for n in names)     # nothing was imported on the way
+    (cb_key, cb_val), = got["callbacks"].items()
+    assert cb_key.__name__ == "ModelCheckpoint" and cb_val["monitor"] == "g_loss_step"
+    g = CasNetGenerator((1, 32, 32), 2, dimensions=2, device="cpu")
+    res = load_reference_checkpoint(g, str(path))
+    assert not res.missing_keys
+    for k, v in ref.generator.state_dict().items():
+        assert torch.equal(g.state_dict()[k], v), k
+    assert len(got["optimizer_states"][0]["state"]) == len(list(ref.generator.parameters()))
+
+
+def test_bench_launcher_starts_n_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must itself start 2 ranks (the
+    driver's command form) and report n_gpus 2; a mismatching WORLD_SIZE is refused with rc != 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["dist"]["world_size"] == 2 and line["rank_sum"] == 3.0
+    env_bad = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       env=env_bad, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)

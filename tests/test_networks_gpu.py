@@ -301,3 +301,37 @@ def test_generator_output_l1_target_at_c2_shape():
     assert l1 < 1e-4, l1
     assert (y - y_ref).abs().max().item() < 2e-3
     assert psnr > 80.0, psnr
+
+
+def test_fused_adam_state_round_trips_in_torch_adam_format():
+    """FusedAdam.state_dict() has torch.optim.Adam's layout (what a Lightning checkpoint's
+    `optimizer_states` holds): saving after two steps and loading into a fresh optimizer resumes with
+    the same moments and step count, and moving the module (.float(): new flat store) keeps them."""
+    from mpgan_amd.gan import FusedAdam
+    from mpgan_amd.networks import Discriminator
+    torch.manual_seed(0)
+    d = Discriminator((1, 32, 32), dimensions=2, device="cuda")
+    d2 = Discriminator((1, 32, 32), dimensions=2, device="cuda")
+    d2.load_state_dict(d.state_dict())
+    x = torch.rand(2, 1, 32, 32, device="cuda")
+    opt = FusedAdam(d, lr=1e-3, betas=(0.5, 0.999))
+    for _ in range(2):
+        opt.zero_grad()
+        d(x).sum().backward()
+        opt.step()
+    sd = opt.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 2.0
+    ref_opt = torch.optim.Adam(d2.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    ref_opt.load_state_dict(sd)                                    # torch accepts it as its own format
+    d2.load_state_dict(d.state_dict())
+    opt2 = FusedAdam(d2, lr=1e-3, betas=(0.5, 0.999))
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 2
+    d.float()                                                      # re-creates parameter storage: store.version changes
+    for o, net in ((opt, d), (opt2, d2)):
+        o.zero_grad()
+        net(x).sum().backward()
+        o.step()
+    assert opt.step_count == 3
+    assert torch.equal(d.store.flat, d2.store.flat), (d.store.flat - d2.store.flat).abs().max().item()
+    assert torch.equal(opt.exp_avg, opt2.exp_avg) and torch.equal(opt.exp_avg_sq, opt2.exp_avg_sq)

@@ -1,0 +1,143 @@
+// Geometry of the gather-type convolutions shared by the fp32 (conv_igemm.hip) and bf16 (conv_bf16.hip)
+// implicit-GEMM kernels: phases of a (transposed) gather, block-id decoding, host-side builders.
+#pragma once
+#include "mpgan_common.h"
+
+namespace mpgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Phase {
+  FastDiv fMx, fMy, fMz;
+  int Mz, My, Mx;     // extents of the m-grid of this phase
+  int oz, oy, ox;     // output coordinate = m*ostride + o?
+  int nz, ny, nx;     // taps per dimension
+  int kz0, ky0, kx0;  // kernel index of tap j: k0 + kstep*j
+  int dz0, dy0, dx0;  // input offset of tap j:  d0 + dstep*j
+};
+
+struct GatherConv {
+  const float* in;
+  const float* wp;
+  float* out;
+  const float* bias;
+  const float* resid;
+  float* stats;   // optional [nphase*gridDim.x][2][Cout] partial sums of the output (fused BatchNorm statistics)
+  Pro pro;
+  int N, Di, Hi, Wi, Cin, ldi;
+  int Do, Ho, Wo, Cout, ldo, ldr;
+  int Kz, Ky, Kx;
+  int ostride[3], istride[3], kstep[3], dstep[3];
+  int nphase, tanh_out;
+  int mtiles, ntiles;   // 1-D launch of ksplit*nphase*mtiles*ntiles blocks, XCD-remapped, n-tile fastest
+  int phase_outer;      // block order: 1 = phase slowest, 0 = phases of an m-tile adjacent (see conv_block_id)
+  int ksplit;           // > 1: each block covers a K slice and leaves raw partial sums in kpartial
+  float* kpartial;      // [ksplit][N*Do*Ho*Wo][Cout]
+  Phase ph[8];
+};
+
+struct BlockId { int mt, nt, phase, split; };
+__device__ __forceinline__ BlockId conv_block_id(const GatherConv& p) {
+  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
+  BlockId b;
+  // n-tile fastest, then phase, then m-tile: the phases of a strided backward-data gather read the
+  // SAME dy pixels (different taps), so they sit next to each other in the work order -- same XCD,
+  // same time, one fetch into its L2 instead of one per phase.
+  // When the whole weight tensor would crowd a 4 MiB L2 (each phase only touches its own taps'
+  // share of it) the phases run one after another instead (phase_outer).
+  b.nt = (int)(w % (unsigned)p.ntiles);
+  unsigned q = w / (unsigned)p.ntiles;
+  if (p.phase_outer) {
+    b.mt = (int)(q % (unsigned)p.mtiles);
+    q /= (unsigned)p.mtiles;
+    b.phase = (int)(q % (unsigned)p.nphase);
+    b.split = (int)(q / (unsigned)p.nphase);
+  } else {
+    b.phase = (int)(q % (unsigned)p.nphase);
+    q /= (unsigned)p.nphase;
+    b.mt = (int)(q % (unsigned)p.mtiles);
+    b.split = (int)(q / (unsigned)p.mtiles);
+  }
+  return b;
+}
+
+inline long max_phase_pixels(const GatherConv& p) {
+  long maxM = 0;
+  for (int i = 0; i < p.nphase; ++i) {
+    long m = (long)p.N * p.ph[i].Mz * p.ph[i].My * p.ph[i].Mx;
+    if (m > maxM) maxM = m;
+  }
+  return maxM;
+}
+
+// ---- host-side geometry builders -------------------------------------------
+inline int check_geom(const mpgan_conv_geom* g) {
+  MPGAN_CHECK_ARG(g != nullptr, "conv: null geometry");
+  MPGAN_CHECK_ARG(g->n > 0 && g->cin > 0 && g->cout > 0, "conv: bad n/cin/cout");
+  for (int d = 0; d < 3; ++d) {
+    MPGAN_CHECK_ARG(g->in_dhw[d] > 0 && g->out_dhw[d] > 0 && g->k[d] > 0 && g->stride[d] > 0 && g->pad[d] >= 0,
+                    "conv: bad spatial geometry in dim %d", d);
+    MPGAN_UNSUPPORTED(g->stride[d] > 2, "conv: stride > 2 unsupported");
+    if (!g->transposed) {
+      int o = (g->in_dhw[d] + 2 * g->pad[d] - g->k[d]) / g->stride[d] + 1;
+      MPGAN_CHECK_ARG(o == g->out_dhw[d], "conv: out_dhw[%d]=%d does not match geometry (%d)", d, g->out_dhw[d], o);
+    } else {
+      int lo = (g->in_dhw[d] - 1) * g->stride[d] - 2 * g->pad[d] + g->k[d];
+      MPGAN_CHECK_ARG(g->out_dhw[d] >= lo && g->out_dhw[d] < lo + g->stride[d],
+                      "convT: out_dhw[%d]=%d outside [%d,%d)", d, g->out_dhw[d], lo, lo + g->stride[d]);
+    }
+  }
+  return MPGAN_OK;
+}
+
+// forward-type gather: produced[o] = sum_k gathered[o*s - p + k] * W[k]
+inline void build_forward(GatherConv& p, int n, const int32_t* gath_dhw, int cg, const int32_t* prod_dhw, int cp,
+                          const int32_t* k, const int32_t* s, const int32_t* pad) {
+  p.N = n; p.Di = gath_dhw[0]; p.Hi = gath_dhw[1]; p.Wi = gath_dhw[2]; p.Cin = cg;
+  p.Do = prod_dhw[0]; p.Ho = prod_dhw[1]; p.Wo = prod_dhw[2]; p.Cout = cp;
+  p.Kz = k[0]; p.Ky = k[1]; p.Kx = k[2];
+  for (int d = 0; d < 3; ++d) { p.ostride[d] = 1; p.istride[d] = s[d]; p.kstep[d] = 1; p.dstep[d] = 1; }
+  p.nphase = 1;
+  Phase& ph = p.ph[0];
+  ph.Mz = prod_dhw[0]; ph.My = prod_dhw[1]; ph.Mx = prod_dhw[2];
+  ph.fMx = make_fastdiv(ph.Mx); ph.fMy = make_fastdiv(ph.My); ph.fMz = make_fastdiv(ph.Mz);
+  ph.oz = ph.oy = ph.ox = 0;
+  ph.nz = k[0]; ph.ny = k[1]; ph.nx = k[2];
+  ph.kz0 = ph.ky0 = ph.kx0 = 0;
+  ph.dz0 = -pad[0]; ph.dy0 = -pad[1]; ph.dx0 = -pad[2];
+}
+
+// transposed-type gather: produced[o] = sum_k gathered[(o + p - k)/s] * W[k]
+inline void build_transposed(GatherConv& p, int n, const int32_t* gath_dhw, int cg, const int32_t* prod_dhw, int cp,
+                             const int32_t* k, const int32_t* s, const int32_t* pad) {
+  p.N = n; p.Di = gath_dhw[0]; p.Hi = gath_dhw[1]; p.Wi = gath_dhw[2]; p.Cin = cg;
+  p.Do = prod_dhw[0]; p.Ho = prod_dhw[1]; p.Wo = prod_dhw[2]; p.Cout = cp;
+  p.Kz = k[0]; p.Ky = k[1]; p.Kx = k[2];
+  for (int d = 0; d < 3; ++d) { p.ostride[d] = s[d]; p.istride[d] = 1; p.kstep[d] = s[d]; p.dstep[d] = -1; }
+  int np = 0;
+  for (int pz = 0; pz < s[0]; ++pz)
+    for (int py = 0; py < s[1]; ++py)
+      for (int px = 0; px < s[2]; ++px) {
+        Phase& ph = p.ph[np++];
+        const int phs[3] = {pz, py, px};
+        int M[3], nj[3], k0[3], d0[3];
+        for (int d = 0; d < 3; ++d) {
+          int r = (phs[d] + pad[d]) % s[d];
+          nj[d] = r < k[d] ? (k[d] - r + s[d] - 1) / s[d] : 0;
+          k0[d] = r;
+          d0[d] = (phs[d] + pad[d] - r) / s[d];
+          M[d] = prod_dhw[d] > phs[d] ? (prod_dhw[d] - phs[d] + s[d] - 1) / s[d] : 0;
+        }
+        ph.Mz = M[0]; ph.My = M[1]; ph.Mx = M[2];
+        ph.fMx = make_fastdiv(M[2] > 0 ? M[2] : 1); ph.fMy = make_fastdiv(M[1] > 0 ? M[1] : 1);
+        ph.fMz = make_fastdiv(M[0] > 0 ? M[0] : 1);
+        ph.oz = pz; ph.oy = py; ph.ox = px;
+        ph.nz = nj[0]; ph.ny = nj[1]; ph.nx = nj[2];
+        ph.kz0 = k0[0]; ph.ky0 = k0[1]; ph.kx0 = k0[2];
+        ph.dz0 = d0[0]; ph.dy0 = d0[1]; ph.dx0 = d0[2];
+        if (nj[0] == 0 || nj[1] == 0 || nj[2] == 0) { ph.nz = 0; ph.ny = 1; ph.nx = 1; }  // no taps: bias only
+      }
+  p.nphase = np;
+}
+
+}  // namespace mpgan

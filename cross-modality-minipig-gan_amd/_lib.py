@@ -84,6 +84,21 @@ SIGNATURES = {
     "mpgan_adam_step": (_I, [_P, _P, _P, _P, _L, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, _P]),
     "mpgan_patch_gather": (_I, [_P, _I, _I3, _P, _I, _I3, _P, _P]),
     "mpgan_patch_scatter_add": (_I, [_P, _I, _I3, _P, _I, _I3, _P, _P]),
+    # bf16 storage path (config C5)
+    "mpgan_conv_stats_rows_bf16": (_I, [_G]),
+    "mpgan_conv_forward_bf16": (_I, [_G, _P, _I, _P, _P, _P, _P, _I, _P]),
+    "mpgan_conv_backward_data_bf16": (_I, [_G, _P, _I, _P, _P, _I, _P]),
+    "mpgan_conv_wgrad_workspace_bf16": (_L, [_G]),
+    "mpgan_conv_backward_weight_bf16": (_I, [_G, _P, _I, _P, _I, _P, _F, _P, _L, _P]),
+    "mpgan_conv_forward_f32_to_bf16": (_I, [_G, _P, _I, _P, _P, _P, _P, _I, _P]),
+    "mpgan_conv_backward_data_bf16_to_f32": (_I, [_G, _P, _I, _P, _P, _I, _P]),
+    "mpgan_conv_wgrad_workspace_bf16dy": (_L, [_G]),
+    "mpgan_conv_backward_weight_bf16dy": (_I, [_G, _P, _I, _P, _I, _P, _P, _F, _P, _L, _P]),
+    "mpgan_pack_weights_bf16": (_I, [_P, _P, _P, _I, _L, _P]),
+    "mpgan_norm_act_bf16": (_I, [_P, _I, _P, _P, _F, _L, _I, _P, _I, _I, _P]),
+    "mpgan_norm_bwd_rows_bf16": (_I, [_L, _I]),
+    "mpgan_norm_bwd_reduce_bf16": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _F, _L, _I, _P, _P]),
+    "mpgan_norm_bwd_apply_bf16": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _F, _L, _I, _P, _I, _P, _P]),
 }
 
 

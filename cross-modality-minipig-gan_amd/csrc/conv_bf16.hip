@@ -1,0 +1,960 @@
+// bf16-storage implicit-GEMM convolution for gfx950 (config C5: the reference's 3-D graph, GAN_final.py:167-189).
+//
+// Activations and packed weights live in HBM as bf16; products accumulate in fp32 on
+// v_mfma_f32_32x32x16_bf16; BatchNorm statistics are taken from the fp32 accumulators; master weights,
+// gradients of weights and Adam stay fp32 (the fp32 kernels' buffers).
+//
+// At 16x the fp32 matrix rate a K-step has no room for a normalise-on-load prologue (32 elements per
+// thread and K-step = ~150 vector instructions against 512 matrix cycles), so in bf16 mode the producer's
+// BatchNorm + LeakyReLU is materialised once per layer by an HBM-bound pass (norm_act_bf16_kernel: 0.65 ms
+// for D.conv2's 2 GB output against ~20 ms of matrix work that consumes it) and BOTH operands of the
+// contraction go global -> LDS by LDS-DMA (global_load_lds_dwordx4), never through registers:
+//   * LDS image: rows of 64 K-elements (128 B), lane-linear per wave instruction, swizzled on the SOURCE
+//     address (chunk ^ ((row>>1)&7)) so that the fragments' ds_read_b128 are conflict-free;
+//   * out-of-range taps of a backward-data / padded gather read a 256-byte zero page instead of being masked;
+//   * three LDS stages, counted vmcnt, one raw s_barrier per K-step: a tile's loads have two K-steps to land.
+// Tile: 256 pixels x BN channels x 64 K, 256 threads = 4 waves, one block per CU (144 KiB of LDS).
+#include "mpgan_common.h"
+#include "conv_geom.h"
+#include <stdlib.h>
+
+namespace mpgan {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ uint4 g_zero_page[16];   // 256 B of zeros: what a masked LDS-DMA gather reads
+
+#define GLDS16(gptr, lptr)                                                                            \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),             \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+// Fragment reads as inline asm: hipcc's waitcnt pass drains every LDS-DMA in flight (vmcnt(0)) in front of an LDS
+// read it cannot tell apart from the DMA's destination, which would undo the counted-vmcnt pipeline; an asm
+// statement is invisible to that pass.  Its result register is NOT protected either: each set of reads is
+// followed, before its first use, by lds_wait(...) -- `s_waitcnt lgkmcnt(0)` tied to the registers it covers.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ i32x4 lds_read_b128(unsigned addr) {
+  i32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ i32x2 lds_read_tr16_b64(unsigned addr) {
+  i32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+template <int NA, int NB, typename V>
+__device__ __forceinline__ void lds_wait(V (&a)[NA], V (&b)[NB]) {
+  if constexpr (NA == 4 && NB == 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
+  else if constexpr (NA == 2 && NB == 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+  else if constexpr (NA == 4 && NB == 8)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                   "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+  else
+    static_assert(NA == 0, "lds_wait: unsupported fragment set");
+}
+
+constexpr int HB_BM = 256;          // pixels per tile
+constexpr int HB_BK = 64;           // K elements per step (one 128-byte LDS row)
+constexpr int HB_ROWB = 128;
+
+template <int BN>
+struct HbTile {
+  static constexpr int WM = BN == 128 ? 2 : 4, WN = BN == 128 ? 2 : 1;
+  static constexpr int TM = HB_BM / WM / 32, TN = BN / WN / 32;
+  static constexpr int APIECES = HB_BM * 8 / 256, BPIECES = BN * 8 / 256;
+  static constexpr int STAGE = (HB_BM + BN) * HB_ROWB;
+  static constexpr int NSTAGE = 3;
+  static constexpr int IMG_PITCH = BN + 4;                            // floats
+  static constexpr int ROWPIX = HB_BM * IMG_PITCH * 4;                // int[256] behind the fp32 epilogue image
+  static constexpr int SMEM_LOOP = NSTAGE * STAGE;
+  static constexpr int SMEM_EPI = ROWPIX + HB_BM * 4 + 2048;                  // + the column-sum partials
+  static constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
+};
+
+//   MASK : taps can fall outside the gathered tensor (backward-data gathers, padded convs): per-row tap bitmasks,
+//          invalid pieces read the zero page.  !MASK: every tap of every pixel is in range (valid convs).
+template <int BN, bool MASK>
+__global__ __launch_bounds__(256, 1) void gather_conv_bf16_kernel(const GatherConv p) {
+  using T = HbTile<BN>;
+  constexpr int TM = T::TM, TN = T::TN, WN = T::WN;
+  constexpr int NLOADS = T::APIECES + T::BPIECES;     // LDS-DMA instructions per thread and K-step
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const BlockId bid = conv_block_id(p);
+  const Phase& ph = p.ph[bid.phase];
+  const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
+  const long m0 = (long)bid.mt * HB_BM;
+  const int n0 = bid.nt * BN;
+  const int stats_row = bid.phase * p.mtiles + bid.mt;
+  const int Cout = p.Cout;
+  if (m0 >= Mtot) {                                   // empty tile of a short phase (block-uniform)
+    if (p.stats && tid < BN && n0 + tid < Cout) {
+      float* row = p.stats + (long)stats_row * 2 * Cout;
+      row[n0 + tid] = 0.f;
+      row[Cout + n0 + tid] = 0.f;
+    }
+    return;
+  }
+  const int Cin = p.Cin, Di = p.Di, Hi = p.Hi, Wi = p.Wi, ldi = p.ldi;
+  const int ntaps = ph.nz * ph.ny * ph.nx;
+  const int nchunk = Cin / HB_BK;
+  const int nk = ntaps * nchunk;
+  const char* __restrict__ ginb = reinterpret_cast<const char*>(p.in);
+  const char* __restrict__ gwb = reinterpret_cast<const char*>(p.wp);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  // ---- this thread's pieces: rows r0 + 32*i, 16-byte chunk `ck` of the K-step (source-side swizzle) ----
+  const int r0 = tid >> 3, cc = tid & 7;
+  const int ck = cc ^ ((r0 >> 1) & 7);
+  unsigned rbB[T::APIECES];            // byte offset of (row pixel, channel 0)
+  unsigned tmask[MASK ? T::APIECES : 1];
+#pragma unroll
+  for (int i = 0; i < T::APIECES; ++i) {
+    unsigned m = (unsigned)m0 + r0 + 32 * i;
+    const bool live = m < (unsigned)Mtot;
+    m = live ? m : (unsigned)Mtot - 1u;               // clamped rows gather a real pixel; never stored
+    unsigned q, umx, umy, umz;
+    fdivmod(m, ph.fMx, q, umx);
+    fdivmod(q, ph.fMy, q, umy);
+    fdivmod(q, ph.fMz, q, umz);
+    const int bz = (int)umz * p.istride[0], by = (int)umy * p.istride[1], bx = (int)umx * p.istride[2];
+    rbB[i] = (unsigned)((((int)q * Di + bz) * Hi + by) * Wi + bx) * (unsigned)ldi * 2u;
+    if constexpr (MASK) {
+      unsigned mk = 0;
+      int j = 0;
+      for (int jz = 0; jz < ph.nz; ++jz) {
+        const bool okz = (unsigned)(bz + ph.dz0 + p.dstep[0] * jz) < (unsigned)Di;
+        for (int jy = 0; jy < ph.ny; ++jy) {
+          const bool oky = okz && (unsigned)(by + ph.dy0 + p.dstep[1] * jy) < (unsigned)Hi;
+          for (int jx = 0; jx < ph.nx; ++jx, ++j) {
+            const bool ok = oky && (unsigned)(bx + ph.dx0 + p.dstep[2] * jx) < (unsigned)Wi;
+            mk |= (ok ? 1u : 0u) << j;
+          }
+        }
+      }
+      tmask[i] = live ? mk : 0u;
+    }
+  }
+  const unsigned Ktot2 = (unsigned)(p.Kz * p.Ky * p.Kx * Cin) * 2u;
+  unsigned wrowB[T::BPIECES];
+#pragma unroll
+  for (int i = 0; i < T::BPIECES; ++i) {
+    int co = n0 + r0 + 32 * i;
+    co = co < Cout ? co : Cout - 1;                   // clamped columns are computed and dropped
+    wrowB[i] = (unsigned)co * Ktot2;
+  }
+
+  // K order: channel-chunk major, taps inner (the taps that re-read an input element are then adjacent K-steps).
+  // The tap walk is wave-uniform and lives in scalar registers: the K loop makes NO LDS access besides the
+  // fragment reads (hipcc drains every LDS-DMA in flight, vmcnt(0), in front of an LDS read it cannot tell
+  // apart from the staging area -- a table in LDS would serialise the pipeline).
+  int itap = 0, ichunk = 0, istage = 0;               // cursor of the NEXT tile to issue
+  int jx = 0, jy = 0, jz = 0;
+  const int dsz = p.dstep[0], dsy = p.dstep[1], dsx = p.dstep[2], ksz = p.kstep[0], ksy = p.kstep[1], ksx = p.kstep[2];
+  auto issue = [&]() {
+    const int dz = ph.dz0 + dsz * jz, dy = ph.dy0 + dsy * jy, dx = ph.dx0 + dsx * jx;
+    const int kz = ph.kz0 + ksz * jz, ky = ph.ky0 + ksy * jy, kx = ph.kx0 + ksx * jx;
+    const unsigned deltaB = (unsigned)(((dz * Hi + dy) * Wi + dx) * ldi * 2);
+    const unsigned woffB = (unsigned)(((kz * p.Ky + ky) * p.Kx + kx) * Cin * 2);
+    const unsigned ciB = (unsigned)(ichunk * HB_BK + ck * 8) * 2u;
+    char* As = lds + istage * T::STAGE + (8 * wid) * HB_ROWB;
+    char* Bs = As + HB_BM * HB_ROWB;
+#pragma unroll
+    for (int i = 0; i < T::APIECES; ++i) {
+      const char* src = ginb + (rbB[i] + deltaB + ciB);
+      if constexpr (MASK) src = ((tmask[i] >> itap) & 1u) ? src : zero;
+      GLDS16(src, As + 32 * i * HB_ROWB);
+    }
+#pragma unroll
+    for (int i = 0; i < T::BPIECES; ++i) GLDS16(gwb + (wrowB[i] + woffB + ciB), Bs + 32 * i * HB_ROWB);
+    itap += 1;
+    jx += 1;
+    if (jx == ph.nx) { jx = 0; jy += 1; }
+    if (jy == ph.ny) { jy = 0; jz += 1; }
+    if (itap == ntaps) { itap = 0; jz = 0; ichunk += 1; }
+    istage = istage == T::NSTAGE - 1 ? 0 : istage + 1;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment addresses: lane (li, lh) of k-sub s takes chunk 2s+lh of its row, stored at chunk ^ ((row>>1)&7)
+  const int sw = (li >> 1) & 7;
+  int foff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) foff[s] = ((2 * s + lh) ^ sw) * 16;
+  const int arow = (wm * (HB_BM / T::WM) + li) * HB_ROWB;
+  const int brow = HB_BM * HB_ROWB + (wn * (BN / WN) + li) * HB_ROWB;
+
+  const unsigned lds_base = lds_addr(lds);
+  if (nk > 0) issue();
+  if (nk > 1) issue();
+  int cstage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once all but the newest NLOADS DMAs of this wave are done (tile kt+1's)
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");           // every wave's part of tile kt landed; stage of tile kt-1 is free
+    if (kt + 2 < nk) issue();
+    const unsigned As = lds_base + cstage * T::STAGE + arow;
+    const unsigned Bs = lds_base + cstage * T::STAGE + brow;
+    // fragments of k-sub s+1 are read while the MFMAs of k-sub s run (two register sets)
+    i32x4 fa[2][TM], fb[2][TN];
+    auto read_frags = [&](int s, int set) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) fa[set][tm] = lds_read_b128(As + tm * 32 * HB_ROWB + foff[s]);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) fb[set][tn] = lds_read_b128(Bs + tn * 32 * HB_ROWB + foff[s]);
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int set = s & 1;
+      lds_wait<TM, TN>(fa[set], fb[set]);
+      if (s < 3) read_frags(s + 1, set ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][tm]),
+                                                                __builtin_bit_cast(bf16x8, fb[set][tn]), acc[tm][tn], 0, 0, 0);
+    }
+    cstage = cstage == T::NSTAGE - 1 ? 0 : cstage + 1;
+  }
+  asm volatile("s_barrier" ::: "memory");             // all fragment reads done: LDS becomes the epilogue image
+
+  // ---- epilogue: fp32 image [pixel][channel] in LDS -> statistics, bf16 rows stored 16 bytes per lane ----
+  float* img = reinterpret_cast<float*>(lds);
+  int* rowpix = reinterpret_cast<int*>(lds + T::ROWPIX);
+  {
+    const unsigned m = (unsigned)m0 + tid;            // 256 threads, 256 rows
+    int pix = -1;
+    if (m < (unsigned)Mtot) {
+      unsigned q, umx, umy, umz;
+      fdivmod(m, ph.fMx, q, umx);
+      fdivmod(q, ph.fMy, q, umy);
+      fdivmod(q, ph.fMz, q, umz);
+      const int oz = (int)umz * p.ostride[0] + ph.oz, oy = (int)umy * p.ostride[1] + ph.oy,
+                ox = (int)umx * p.ostride[2] + ph.ox;
+      if (oz < p.Do && oy < p.Ho && ox < p.Wo) pix = (((int)q * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+    }
+    rowpix[tid] = pix;
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = (wn * TN + tn) * 32 + li;
+    const float bv = (p.bias && n0 + col < Cout) ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * (HB_BM / T::WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        img[row * T::IMG_PITCH + col] = acc[tm][tn][r] + bv;
+      }
+  }
+  __syncthreads();
+  if (p.stats) {
+    // column sums of z = acc + bias over the rows that own an output pixel: thread (column, row half)
+    float* part = reinterpret_cast<float*>(lds + T::ROWPIX + HB_BM * 4);   // [2 halves][2][BN]
+    constexpr int HALVES = 256 / BN;                  // 2 (BN 128) or 4 (BN 64)
+    const int c = tid % BN, hf = tid / BN;
+    float sm = 0.f, sq = 0.f;
+    for (int row = hf * (HB_BM / HALVES); row < (hf + 1) * (HB_BM / HALVES); ++row) {
+      const float v = rowpix[row] >= 0 ? img[row * T::IMG_PITCH + c] : 0.f;
+      sm += v;
+      sq = fmaf(v, v, sq);
+    }
+    if (hf > 0) {
+      part[((hf - 1) * 2 + 0) * BN + c] = sm;
+      part[((hf - 1) * 2 + 1) * BN + c] = sq;
+    }
+    __syncthreads();
+    if (hf == 0 && n0 + c < Cout) {
+#pragma unroll
+      for (int h = 1; h < HALVES; ++h) {
+        sm += part[((h - 1) * 2 + 0) * BN + c];
+        sq += part[((h - 1) * 2 + 1) * BN + c];
+      }
+      float* row = p.stats + (long)stats_row * 2 * Cout;
+      row[n0 + c] = sm;
+      row[Cout + n0 + c] = sq;
+    }
+  }
+  char* goutb = reinterpret_cast<char*>(p.out);
+  constexpr int CHUNKS = BN / 8;                      // 16-byte chunks per row
+  for (int q = tid; q < HB_BM * CHUNKS; q += 256) {
+    const int row = q / CHUNKS, ch = q % CHUNKS;
+    const int pix = rowpix[row];
+    if (pix < 0 || n0 + ch * 8 >= Cout) continue;
+    const float4 v0 = *reinterpret_cast<const float4*>(img + row * T::IMG_PITCH + ch * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(img + row * T::IMG_PITCH + ch * 8 + 4);
+    bf16x8 o;
+    o[0] = (__bf16)v0.x; o[1] = (__bf16)v0.y; o[2] = (__bf16)v0.z; o[3] = (__bf16)v0.w;
+    o[4] = (__bf16)v1.x; o[5] = (__bf16)v1.y; o[6] = (__bf16)v1.z; o[7] = (__bf16)v1.w;
+    *reinterpret_cast<bf16x8*>(goutb + ((long)pix * p.ldo + n0 + ch * 8) * 2) = o;
+  }
+}
+
+// every tap of every pixel of every phase inside the gathered tensor?
+static bool hb_all_in_range(const GatherConv& p) {
+  const int G[3] = {p.Di, p.Hi, p.Wi};
+  for (int i = 0; i < p.nphase; ++i) {
+    const Phase& ph = p.ph[i];
+    if (ph.nz * ph.ny * ph.nx == 0) return false;
+    const int d0[3] = {ph.dz0, ph.dy0, ph.dx0}, nj[3] = {ph.nz, ph.ny, ph.nx}, M[3] = {ph.Mz, ph.My, ph.Mx};
+    for (int d = 0; d < 3; ++d) {
+      if (M[d] == 0) continue;
+      const int e = d0[d] + p.dstep[d] * (nj[d] - 1);
+      const int lo = d0[d] < e ? d0[d] : e, hi = d0[d] < e ? e : d0[d];
+      if (lo < 0 || (M[d] - 1) * p.istride[d] + hi > G[d] - 1) return false;
+    }
+  }
+  return true;
+}
+
+template <int BN, bool MASK>
+static int hb_launch(const GatherConv& p, long maxM, hipStream_t st) {
+  auto kern = gather_conv_bf16_kernel<BN, MASK>;
+  constexpr int smem = HbTile<BN>::SMEM;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      set_error("gather_conv_bf16: hipFuncSetAttribute(%d): %s", smem, hipGetErrorString(e));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  GatherConv q = p;
+  q.mtiles = (int)((maxM + HB_BM - 1) / HB_BM);
+  q.ntiles = (p.Cout + BN - 1) / BN;
+  q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 2 > (3L << 20) ? 1 : 0;
+  q.ksplit = 1;
+  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
+  return check_launch("gather_conv_bf16");
+}
+
+static int hb_check(const GatherConv& p, const char* what) {
+  MPGAN_UNSUPPORTED(p.Cin % HB_BK != 0, "%s: bf16 path needs gathered channels %% 64 == 0 (got %d)", what, p.Cin);
+  MPGAN_UNSUPPORTED(p.Cout % 8 != 0 || p.ldo % 8 != 0 || p.ldi % 8 != 0, "%s: bf16 path needs channels / pitches %% 8 == 0", what);
+  MPGAN_UNSUPPORTED((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.wp) | reinterpret_cast<uintptr_t>(p.out)) & 15,
+                    "%s: bf16 operands must be 16-byte aligned", what);
+  MPGAN_CHECK_ARG((long)p.N * p.Do * p.Ho * p.Wo < (1L << 31) && (long)p.N * p.Di * p.Hi * p.Wi < (1L << 31), "%s: more than 2^31 pixels", what);
+  MPGAN_UNSUPPORTED((long)p.N * p.Di * p.Hi * p.Wi * p.ldi * 2 >= (1L << 32) || (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 2 >= (1L << 32),
+                    "%s: bf16 operand of 4 GiB or more (32-bit byte offsets)", what);
+  for (int i = 0; i < p.nphase; ++i)
+    MPGAN_UNSUPPORTED(p.ph[i].nz * p.ph[i].ny * p.ph[i].nx > 32, "%s: more than 32 taps per phase", what);
+  return MPGAN_OK;
+}
+
+static int hb_dispatch(const GatherConv& p, hipStream_t st, const char* what) {
+  int rc = hb_check(p, what);
+  if (rc) return rc;
+  const long maxM = max_phase_pixels(p);
+  if (maxM == 0) return MPGAN_OK;
+  const bool mask = !hb_all_in_range(p);
+  if (p.Cout > 64) return mask ? hb_launch<128, true>(p, maxM, st) : hb_launch<128, false>(p, maxM, st);
+  return mask ? hb_launch<64, true>(p, maxM, st) : hb_launch<64, false>(p, maxM, st);
+}
+
+// ---------------------------------------------------------------------------
+// Weight gradient, bf16 operands: R[cd][t*Cg + cg] = sum_m dense[m][cd] * gathered[pix(m,t)][cg], K = pixels.
+// Both operands are stored [pixel][channel] (K-strided), so the LDS tiles keep that shape and the MFMA
+// fragments (8 consecutive pixels of one channel per lane) come from ds_read_b64_tr_b16, the hardware
+// transposing read: lane 4q+p of a 16-lane group addresses row q (pixel), columns 4p..4p+3 of a 4 x 16 block
+// and receives one column.  Image: 256-byte rows, chunk ^ (((row&3)<<2) | ((row>>2)&3)) (conflict-free for
+// these reads), applied on the LDS-DMA source address.
+// Tile: 128 dense channels x 256 columns x 64 pixels per K-step, 4 waves (2 x 2, 64 x 128 each), three stages.
+// Pad-free convs only (every tap of every coarse pixel in range): the discriminator's.
+// ---------------------------------------------------------------------------
+struct WgradHb {
+  const char* dense;    // bf16 [M][ldd]
+  const char* gath;     // bf16 [pixels][ldg]
+  float* partial;       // [split][Cd][NC]
+  int ldd, Cd, ldg, Cg;
+  int N, Mz, My, Mx, Gz, Gy, Gx, Kz, Ky, Kx, sz, sy, sx;
+  int nsplit, tiles_c, tiles_d;
+  long chunk;           // pixels per split (multiple of 64)
+  FastDiv fMx, fMy, fMz;
+};
+
+constexpr int WH_BD = 128, WH_BG = 256, WH_BK = 64;
+constexpr int WH_STAGE = WH_BK * (WH_BD + WH_BG) * 2;      // 48 KiB
+constexpr int WH_SMEM = 3 * WH_STAGE;
+
+__global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradHb p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int TM = 2, TN = 4;
+  constexpr int NLOADS = 4 + 8;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
+  const int tc = (int)(w % (unsigned)p.tiles_c);
+  const unsigned wq = w / (unsigned)p.tiles_c;
+  const int td = (int)(wq % (unsigned)p.tiles_d), split = (int)(wq / (unsigned)p.tiles_d);
+  const int T = p.Kz * p.Ky * p.Kx;
+  const int NC = T * p.Cg;
+  const int c0 = tc * WH_BG, d0 = td * WH_BD;
+  const long M = (long)p.N * p.Mz * p.My * p.Mx;
+  const long mbeg = (long)split * p.chunk;
+  const long mend = mbeg + p.chunk < M ? mbeg + p.chunk : M;
+  const int nk = mbeg < mend ? (int)((mend - mbeg + WH_BK - 1) / WH_BK) : 0;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  // this thread's pieces: rows 16*i + (tid >> 4) of each sub-tile, LDS position tid & 15, source chunk pos ^ f(row)
+  const int prow = tid >> 4, ppos = tid & 15;
+  const int f = ((prow & 3) << 2) | (wid & 3);            // f(row) = ((row&3)<<2) | ((row>>2)&3), row = 16i + prow
+  const int chk = ppos ^ f;                               // 16-byte chunk (8 channels / columns) this thread fetches
+  // dense operand: channels d0 + 8*chk
+  const bool dok = d0 + chk * 8 < p.Cd;
+  const unsigned dcolB = (unsigned)(d0 + chk * 8) * 2u;
+  // gathered operand, sub-tiles j = 0, 1: column c0 + 128 j + 8*chk -> (tap, channel)
+  unsigned gtapB[2];
+  bool gok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = c0 + 128 * j + chk * 8;
+    gok[j] = col < NC;
+    const int t = gok[j] ? col / p.Cg : 0;
+    const int ci = gok[j] ? col - t * p.Cg : 0;
+    const int kx = t % p.Kx, tq = t / p.Kx, ky = tq % p.Ky, kz = tq / p.Ky;
+    gtapB[j] = (unsigned)(((kz * p.Gy + ky) * p.Gx + kx) * p.ldg + ci) * 2u;
+  }
+
+  // Pixel cursors of this thread's four rows (16 i + prow of every 64-pixel K-step): decoded with divisions
+  // once, then advanced by 64 pixels per K-step with carries.  (No row table in LDS: hipcc drains every
+  // LDS-DMA in flight in front of an LDS access it cannot tell apart from the staging area.)
+  int cn[4], cz[4], cy[4], cx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned q, ux, uy, uz;
+    fdivmod((unsigned)(mbeg + 16 * i + prow), p.fMx, q, ux);
+    fdivmod(q, p.fMy, q, uy);
+    fdivmod(q, p.fMz, q, uz);
+    cn[i] = (int)q; cz[i] = (int)uz; cy[i] = (int)uy; cx[i] = (int)ux;
+  }
+  int istage = 0;
+  long mtile = mbeg;                                      // first pixel of the next tile to issue
+  auto issue = [&]() {
+    char* Ds = lds + istage * WH_STAGE + (4 * wid) * 256;           // wave base: rows 16 i + 4 wid .. + 3
+    char* Gs = lds + istage * WH_STAGE + WH_BK * 256 + (4 * wid) * 256;
+    const unsigned mrowB = (unsigned)(mtile * p.ldd) * 2u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * i + prow;
+      const bool valid = mtile + row < mend;
+      const unsigned gpixB =
+          (unsigned)(((cn[i] * p.Gz + cz[i] * p.sz) * p.Gy + cy[i] * p.sy) * p.Gx + cx[i] * p.sx) * (unsigned)p.ldg * 2u;
+      const char* src = p.dense + (mrowB + (unsigned)(row * p.ldd) * 2u + dcolB);
+      GLDS16((valid && dok) ? src : zero, Ds + 16 * i * 256);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* gs = p.gath + (gpixB + gtapB[j]);
+        GLDS16((valid && gok[j]) ? gs : zero, Gs + j * (WH_BK * 256) + 16 * i * 256);
+      }
+      cx[i] += WH_BK;
+      while (cx[i] >= p.Mx) {
+        cx[i] -= p.Mx;
+        if (++cy[i] == p.My) {
+          cy[i] = 0;
+          if (++cz[i] == p.Mz) { cz[i] = 0; ++cn[i]; }
+        }
+      }
+    }
+    mtile += WH_BK;
+    istage = istage == 2 ? 0 : istage + 1;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // transposing-read addresses: group g = lane >> 4, i = lane & 15 -> q = i >> 2 (row inside the 4-row block),
+  // pp = i & 3 (column quad); the group's 16 columns start at 16*(g&1) of a 32-channel tile, its pixels at
+  // 16 s + 8 (g>>1) + 4 half
+  const int tg = lane >> 4, tq4 = (lane & 15) >> 2, tpp = lane & 3;
+  int aoff[TM][2], boff[TN][2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int r = 8 * (tg >> 1) + 4 * half + tq4;                   // pixel row inside a 16-pixel k-sub
+    const int fr = ((r & 3) << 2) | ((r >> 2) & 3);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int chunk = (wm * 64 + tm * 32 + 16 * (tg & 1)) / 8 + (tpp >> 1);
+      aoff[tm][half] = 256 * r + 16 * (chunk ^ fr) + 8 * (tpp & 1);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int colb = wn * 128 + tn * 32 + 16 * (tg & 1);         // 0..255: sub-tile colb >> 7
+      const int chunk = (colb & 127) / 8 + (tpp >> 1);
+      boff[tn][half] = WH_BK * 256 * (1 + (colb >> 7)) + 256 * r + 16 * (chunk ^ fr) + 8 * (tpp & 1);
+    }
+  }
+
+  const unsigned lds_base = lds_addr(lds);
+  if (nk > 0) issue();
+  if (nk > 1) issue();
+  int cstage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (kt + 2 < nk) issue();
+    const unsigned S = lds_base + cstage * WH_STAGE;
+    i32x2 fa[2][2 * TM], fb[2][2 * TN];                   // [set][2*tile + half]
+    auto read_frags = [&](int s, int set) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        fa[set][2 * tm] = lds_read_tr16_b64(S + s * 16 * 256 + aoff[tm][0]);
+        fa[set][2 * tm + 1] = lds_read_tr16_b64(S + s * 16 * 256 + aoff[tm][1]);
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        fb[set][2 * tn] = lds_read_tr16_b64(S + s * 16 * 256 + boff[tn][0]);
+        fb[set][2 * tn + 1] = lds_read_tr16_b64(S + s * 16 * 256 + boff[tn][1]);
+      }
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int set = s & 1;
+      lds_wait<2 * TM, 2 * TN>(fa[set], fb[set]);
+      if (s < 3) read_frags(s + 1, set ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const i32x4 av = __builtin_shufflevector(fa[set][2 * tm], fa[set][2 * tm + 1], 0, 1, 2, 3);
+          const i32x4 bv = __builtin_shufflevector(fb[set][2 * tn], fb[set][2 * tn + 1], 0, 1, 2, 3);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                                acc[tm][tn], 0, 0, 0);
+        }
+    }
+    cstage = cstage == 2 ? 0 : cstage + 1;
+  }
+
+  float* out = p.partial + (long)split * p.Cd * NC;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = c0 + wn * 128 + tn * 32 + li;
+      if (col >= NC) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cd = d0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (cd < p.Cd) out[(long)cd * NC + col] = acc[tm][tn][r];
+      }
+    }
+}
+
+struct WgradHbPlan { int nsplit, tiles_c, tiles_d; long chunk; };
+static WgradHbPlan plan_wgrad_hb(int Cd, int NC, long M) {
+  WgradHbPlan pl;
+  pl.tiles_c = (NC + WH_BG - 1) / WH_BG;
+  pl.tiles_d = (Cd + WH_BD - 1) / WH_BD;
+  const long tiles = (long)pl.tiles_c * pl.tiles_d;
+  long ns = (256 + tiles - 1) / tiles;                    // one block per CU per round
+  const long maxsplit = M / (8 * WH_BK) > 1 ? M / (8 * WH_BK) : 1;
+  if (ns > maxsplit) ns = maxsplit;
+  if (ns > 64) ns = 64;
+  if (ns < 1) ns = 1;
+  long chunk = (M + ns - 1) / ns;
+  chunk = (chunk + WH_BK - 1) / WH_BK * WH_BK;
+  ns = (M + chunk - 1) / chunk;
+  pl.nsplit = (int)(ns < 1 ? 1 : ns);
+  pl.chunk = chunk;
+  return pl;
+}
+
+// dW[cd][cg][t] = beta*dW + sum_split partial[split][cd][t*Cg+cg]  (conv_wgrad.hip)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nsplit, int Cd, int Cg,
+                                    int T, float beta, const float* __restrict__ bp, int bsplit, float* __restrict__ db,
+                                    int bias_blocks);
+
+// ---------------------------------------------------------------------------
+// HBM-bound helpers of the bf16 path
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void ld8(const __bf16* p, float (&v)[8]) {
+  const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+}
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void st8(__bf16* p, const float (&v)[8]) {
+  bf16x8 t;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t[e] = (__bf16)v[e];
+  *reinterpret_cast<bf16x8*>(p) = t;
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// a = LeakyReLU(z*scale + shift): the layer's activation, materialised once (thread = 8 channels of one pixel)
+template <typename TO>
+__global__ __launch_bounds__(256) void norm_act_bf16_kernel(const __bf16* __restrict__ z, int ldz,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float slope, long rows,
+                                                            int C, TO* __restrict__ out, int ldo) {
+  const int CG = C / 8;
+  const long total = rows * CG;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / CG;
+    const int c = (int)(i - row * CG) * 8;
+    float v[8], sc[8], sh[8];
+    ld8(z + row * ldz + c, v);
+    ld8(scale + c, sc);
+    ld8(shift + c, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float y = v[e] * sc[e] + sh[e];
+      v[e] = y < 0.f ? y * slope : y;
+    }
+    st8(out + row * ldo + c, v);
+  }
+}
+
+// BatchNorm + LeakyReLU backward on bf16 z:  gy = g*act'(y);  partial rows [chunks*n][3][C] of
+// (sum gy, sum gy*zhat, 0) in the layout mpgan_norm_bwd_finalize consumes; apply: dz = scale*(gy - c1 - zhat*c2).
+// block = R rows x C/8 column groups; chunk = blockIdx.x of gridDim.x over the rows.
+template <typename TG>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_bf16_kernel(const TG* __restrict__ g, int ldg,
+                                                                   const __bf16* __restrict__ z, int ldz,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, float slope,
+                                                                   long rows, int C, float* __restrict__ partials) {
+  extern __shared__ float red[];   // [R][2][C]
+  const int CG = C / 8, R = 256 / CG;
+  const int q = threadIdx.x % CG, r = threadIdx.x / CG, c = q * 8;
+  const long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long beg = (long)blockIdx.x * per, end = beg + per < rows ? beg + per : rows;
+  float a0[8], a1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
+  if (r < R) {
+    float sc[8], sh[8], mu[8], is[8];
+    ld8(scale + c, sc); ld8(shift + c, sh); ld8(mean + c, mu); ld8(invstd + c, is);
+    for (long row = beg + r; row < end; row += R) {
+      float zv[8], gv[8];
+      ld8(z + row * ldz + c, zv);
+      ld8(g + row * ldg + c, gv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float y = zv[e] * sc[e] + sh[e];
+        const float gy = y < 0.f ? gv[e] * slope : gv[e];
+        a0[e] += gy;
+        a1[e] = fmaf(gy, (zv[e] - mu[e]) * is[e], a1[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(r * 2 + 0) * C + c + e] = a0[e];
+      red[(r * 2 + 1) * C + c + e] = a1[e];
+    }
+  }
+  __syncthreads();
+  float* out = partials + (long)blockIdx.x * 3 * C;
+  for (int i = threadIdx.x; i < 3 * C; i += 256) {
+    float s = 0.f;
+    if (i < 2 * C)
+      for (int rr = 0; rr < R; ++rr) s += red[rr * 2 * C + i];
+    out[i] = s;
+  }
+}
+
+// dz (bf16) = scale*(gy - c1 - zhat*c2); optionally per-block column sums of the ROUNDED dz (the conv's bias
+// gradient: dbias = colsum(dy)) as partial rows [gridDim.x][C].
+template <typename TG>
+__global__ __launch_bounds__(256) void norm_bwd_apply_bf16_kernel(const TG* __restrict__ g, int ldg,
+                                                                  const __bf16* __restrict__ z, int ldz,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ c1,
+                                                                  const float* __restrict__ c2, float slope, long rows,
+                                                                  int C, __bf16* __restrict__ dz, int lddz,
+                                                                  float* __restrict__ bias_partials) {
+  extern __shared__ float red[];   // [R][C]
+  const int CG = C / 8, R = 256 / CG;
+  const int q = threadIdx.x % CG, r = threadIdx.x / CG, c = q * 8;
+  float bs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+  if (r < R) {
+    float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
+    ld8(scale + c, sc); ld8(shift + c, sh); ld8(mean + c, mu); ld8(invstd + c, is); ld8(c1 + c, k1); ld8(c2 + c, k2);
+    for (long row = (long)blockIdx.x * R + r; row < rows; row += (long)gridDim.x * R) {
+      float zv[8], gv[8], o[8];
+      ld8(z + row * ldz + c, zv);
+      ld8(g + row * ldg + c, gv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float y = zv[e] * sc[e] + sh[e];
+        const float gy = y < 0.f ? gv[e] * slope : gv[e];
+        o[e] = sc[e] * (gy - k1[e] - (zv[e] - mu[e]) * is[e] * k2[e]);
+        bs[e] += (float)(__bf16)o[e];
+      }
+      st8(dz + row * lddz + c, o);
+    }
+  }
+  if (bias_partials) {
+    if (r < R) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[r * C + c + e] = bs[e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) {
+      float s = 0.f;
+      for (int rr = 0; rr < R; ++rr) s += red[rr * C + i];
+      bias_partials[(long)blockIdx.x * C + i] = s;
+    }
+  }
+}
+
+// table-driven repack of fp32 master weights into bf16 [Cout][tap][Cin] / [Cin][tap][Cout] (pack_weights_kernel's twin)
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst,
+                                                                const int64_t* __restrict__ table) {
+  const int64_t* e = table + (long)blockIdx.y * 8;
+  const long so = e[0], dof = e[1];
+  const int Cout = (int)e[2], Cin = (int)e[3], T = (int)e[4];
+  const int transposed = (int)e[5], layout = (int)e[6];
+  const long total = (long)Cout * Cin * T;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    // i walks the DESTINATION: layout 0 = [co][t][ci], 1 = [ci][t][co]
+    int co, ci, t;
+    if (layout == 0) { ci = (int)(i % Cin); const long r = i / Cin; t = (int)(r % T); co = (int)(r / T); }
+    else { co = (int)(i % Cout); const long r = i / Cout; t = (int)(r % T); ci = (int)(r / T); }
+    const long s = transposed ? ((long)ci * Cout + co) * T + t : ((long)co * Cin + ci) * T + t;
+    dst[dof + i] = (__bf16)src[so + s];
+  }
+}
+
+static inline int hb_ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace mpgan
+
+using namespace mpgan;
+
+extern "C" int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g) {
+  if (check_geom(g)) return -1;
+  GatherConv p{};
+  if (!g->transposed) build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+  else build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+  return (int32_t)((max_phase_pixels(p) + HB_BM - 1) / HB_BM) * p.nphase;
+}
+
+extern "C" int mpgan_conv_forward_bf16(const mpgan_conv_geom* g, const void* x, int32_t ldx, const void* w_packed,
+                                       const float* bias, float* stats_partials, void* y, int32_t ldy, void* stream) {
+  int rc = check_geom(g);
+  if (rc) return rc;
+  MPGAN_CHECK_ARG(x && w_packed && y, "conv_forward_bf16: null pointer");
+  MPGAN_CHECK_ARG(ldx >= g->cin && ldy >= g->cout, "conv_forward_bf16: bad pitch");
+  GatherConv p{};
+  p.in = static_cast<const float*>(x); p.wp = static_cast<const float*>(w_packed); p.out = static_cast<float*>(y);
+  p.bias = bias; p.stats = stats_partials;
+  p.pro = make_pro(nullptr);
+  p.ldi = ldx; p.ldo = ldy;
+  if (!g->transposed) build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+  else build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+  return hb_dispatch(p, (hipStream_t)stream, "conv_forward_bf16");
+}
+
+extern "C" int mpgan_conv_backward_data_bf16(const mpgan_conv_geom* g, const void* dy, int32_t lddy,
+                                             const void* w_packed_bwd, void* dx, int32_t lddx, void* stream) {
+  int rc = check_geom(g);
+  if (rc) return rc;
+  MPGAN_CHECK_ARG(dy && w_packed_bwd && dx, "conv_backward_data_bf16: null pointer");
+  MPGAN_CHECK_ARG(lddy >= g->cout && lddx >= g->cin, "conv_backward_data_bf16: bad pitch");
+  GatherConv p{};
+  p.in = static_cast<const float*>(dy); p.wp = static_cast<const float*>(w_packed_bwd); p.out = static_cast<float*>(dx);
+  p.pro = make_pro(nullptr);
+  p.ldi = lddy; p.ldo = lddx;
+  if (!g->transposed) build_transposed(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
+  else build_forward(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
+  return hb_dispatch(p, (hipStream_t)stream, "conv_backward_data_bf16");
+}
+
+static void wgrad_hb_dims(const mpgan_conv_geom* g, int& Cd, int& Cg, int& T, long& M) {
+  T = g->k[0] * g->k[1] * g->k[2];
+  Cd = g->cout; Cg = g->cin;
+  M = (long)g->n * g->out_dhw[0] * g->out_dhw[1] * g->out_dhw[2];
+}
+
+extern "C" int64_t mpgan_conv_wgrad_workspace_bf16(const mpgan_conv_geom* g) {
+  if (!g) return -1;
+  int Cd, Cg, T;
+  long M;
+  wgrad_hb_dims(g, Cd, Cg, T, M);
+  const WgradHbPlan pl = plan_wgrad_hb(Cd, T * Cg, M);
+  return (int64_t)pl.nsplit * Cd * T * Cg * (int64_t)sizeof(float);
+}
+
+extern "C" int mpgan_conv_backward_weight_bf16(const mpgan_conv_geom* g, const void* x, int32_t ldx, const void* dy,
+                                               int32_t lddy, float* dw, float beta, void* workspace,
+                                               int64_t workspace_bytes, void* stream) {
+  MPGAN_CHECK_ARG(g && x && dy && dw && workspace, "conv_backward_weight_bf16: null pointer");
+  MPGAN_UNSUPPORTED(g->transposed, "conv_backward_weight_bf16: ConvNd only");
+  MPGAN_UNSUPPORTED(g->pad[0] | g->pad[1] | g->pad[2], "conv_backward_weight_bf16: pad-free convs only");
+  MPGAN_CHECK_ARG(ldx >= g->cin && lddy >= g->cout, "conv_backward_weight_bf16: bad pitch");
+  MPGAN_UNSUPPORTED(g->cin % 8 || g->cout % 8 || ldx % 8 || lddy % 8 ||
+                        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15),
+                    "conv_backward_weight_bf16: channels / pitches %% 8 and 16-byte aligned operands");
+  int Cd, Cg, T;
+  long M;
+  wgrad_hb_dims(g, Cd, Cg, T, M);
+  MPGAN_CHECK_ARG(M < (1L << 31) - 64, "conv_backward_weight_bf16: more than 2^31 pixels");
+  MPGAN_UNSUPPORTED(M * lddy * 2 >= (1L << 32) ||
+                        (long)g->n * g->in_dhw[0] * g->in_dhw[1] * g->in_dhw[2] * ldx * 2 >= (1L << 32),
+                    "conv_backward_weight_bf16: operand of 4 GiB or more");
+  const WgradHbPlan pl = plan_wgrad_hb(Cd, T * Cg, M);
+  const int64_t need = (int64_t)pl.nsplit * Cd * T * Cg * (int64_t)sizeof(float);
+  MPGAN_CHECK_ARG(workspace_bytes >= need, "conv_backward_weight_bf16: workspace %lld < %lld bytes",
+                  (long long)workspace_bytes, (long long)need);
+  WgradHb p{};
+  p.dense = static_cast<const char*>(dy); p.ldd = lddy; p.Cd = Cd;
+  p.gath = static_cast<const char*>(x); p.ldg = ldx; p.Cg = Cg;
+  p.partial = static_cast<float*>(workspace);
+  p.N = g->n;
+  p.Mz = g->out_dhw[0]; p.My = g->out_dhw[1]; p.Mx = g->out_dhw[2];
+  p.Gz = g->in_dhw[0]; p.Gy = g->in_dhw[1]; p.Gx = g->in_dhw[2];
+  p.Kz = g->k[0]; p.Ky = g->k[1]; p.Kx = g->k[2];
+  p.sz = g->stride[0]; p.sy = g->stride[1]; p.sx = g->stride[2];
+  p.nsplit = pl.nsplit; p.chunk = pl.chunk; p.tiles_c = pl.tiles_c; p.tiles_d = pl.tiles_d;
+  p.fMx = make_fastdiv(p.Mx); p.fMy = make_fastdiv(p.My); p.fMz = make_fastdiv(p.Mz);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WH_SMEM);
+    if (e != hipSuccess) {
+      set_error("wgrad_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)pl.tiles_c * pl.tiles_d * pl.nsplit), dim3(256), WH_SMEM, st, p);
+  int rc = check_launch("wgrad_bf16");
+  if (rc) return rc;
+  const long total = (long)Cd * Cg * T;
+  int blocks = (int)((total + 31) / 32);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, pl.nsplit, Cd, Cg, T, beta,
+                     (const float*)nullptr, 0, (float*)nullptr, 0);
+  return check_launch("wgrad_bf16_reduce");
+}
+
+extern "C" int mpgan_pack_weights_bf16(const float* flat_params, void* packed, const int64_t* table, int32_t n_entries,
+                                       int64_t max_elems, void* stream) {
+  MPGAN_CHECK_ARG(flat_params && packed && table && n_entries > 0 && max_elems > 0, "pack_weights_bf16: bad argument");
+  long bx = (max_elems + 255) / 256;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)bx, (unsigned)n_entries), dim3(256), 0,
+                     (hipStream_t)stream, flat_params, static_cast<__bf16*>(packed), table);
+  return check_launch("pack_weights_bf16");
+}
+
+extern "C" int mpgan_norm_act_bf16(const void* z, int32_t ldz, const float* scale, const float* shift, float slope,
+                                   int64_t rows, int32_t c, void* out, int32_t ldo, int32_t out_f32, void* stream) {
+  MPGAN_CHECK_ARG(z && scale && shift && out && rows > 0 && c > 0 && ldz >= c && ldo >= c, "norm_act_bf16: bad argument");
+  MPGAN_UNSUPPORTED(c % 8 || ldz % 8 || ldo % 8 || ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(out)) & 15),
+                    "norm_act_bf16: channels / pitches %% 8, 16-byte aligned tensors");
+  const int blocks = hb_ew_blocks(rows * (c / 8));
+  if (out_f32)
+    hipLaunchKernelGGL(norm_act_bf16_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const __bf16*>(z), ldz, scale, shift, slope, (long)rows, c, static_cast<float*>(out), ldo);
+  else
+    hipLaunchKernelGGL(norm_act_bf16_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const __bf16*>(z), ldz, scale, shift, slope, (long)rows, c, static_cast<__bf16*>(out), ldo);
+  return check_launch("norm_act_bf16");
+}
+
+extern "C" int32_t mpgan_norm_bwd_rows_bf16(int64_t rows, int32_t c) {
+  if (c <= 0 || c % 8 || c / 8 > 256) return -1;
+  const int R = 256 / (c / 8);
+  long b = (rows + (long)R * 32 - 1) / ((long)R * 32);     // >= 32 rows per thread row
+  if (b > 2048) b = 2048;
+  return (int32_t)(b < 1 ? 1 : b);
+}
+
+extern "C" int mpgan_norm_bwd_reduce_bf16(const void* g, int32_t g_f32, int32_t ldg, const void* z, int32_t ldz,
+                                          const float* scale, const float* shift, const float* mean,
+                                          const float* invstd, float slope, int64_t rows, int32_t c, float* partials,
+                                          void* stream) {
+  MPGAN_CHECK_ARG(g && z && scale && shift && mean && invstd && partials && rows > 0 && ldg >= c && ldz >= c,
+                  "norm_bwd_reduce_bf16: bad argument");
+  const int nb = mpgan_norm_bwd_rows_bf16(rows, c);
+  MPGAN_UNSUPPORTED(nb < 0 || ldg % 8 || ldz % 8, "norm_bwd_reduce_bf16: C %% 8, C <= 2048, pitches %% 8");
+  const int R = 256 / (c / 8);
+  const size_t smem = (size_t)R * 2 * c * sizeof(float);
+  if (g_f32)
+    hipLaunchKernelGGL(norm_bwd_reduce_bf16_kernel<float>, dim3(nb), dim3(256), smem, (hipStream_t)stream,
+                       static_cast<const float*>(g), ldg, static_cast<const __bf16*>(z), ldz, scale, shift, mean, invstd,
+                       slope, (long)rows, c, partials);
+  else
+    hipLaunchKernelGGL(norm_bwd_reduce_bf16_kernel<__bf16>, dim3(nb), dim3(256), smem, (hipStream_t)stream,
+                       static_cast<const __bf16*>(g), ldg, static_cast<const __bf16*>(z), ldz, scale, shift, mean,
+                       invstd, slope, (long)rows, c, partials);
+  return check_launch("norm_bwd_reduce_bf16");
+}
+
+extern "C" int mpgan_norm_bwd_apply_bf16(const void* g, int32_t g_f32, int32_t ldg, const void* z, int32_t ldz,
+                                         const float* scale, const float* shift, const float* mean, const float* invstd,
+                                         const float* c1, const float* c2, float slope, int64_t rows, int32_t c, void* dz,
+                                         int32_t lddz, float* bias_partials, void* stream) {
+  MPGAN_CHECK_ARG(g && z && scale && shift && mean && invstd && c1 && c2 && dz && rows > 0 && ldg >= c && ldz >= c &&
+                      lddz >= c,
+                  "norm_bwd_apply_bf16: bad argument");
+  const int nb = mpgan_norm_bwd_rows_bf16(rows, c);
+  MPGAN_UNSUPPORTED(nb < 0 || ldg % 8 || ldz % 8 || lddz % 8, "norm_bwd_apply_bf16: C %% 8, C <= 2048, pitches %% 8");
+  const int R = 256 / (c / 8);
+  const size_t smem = bias_partials ? (size_t)R * c * sizeof(float) : 0;
+  if (g_f32)
+    hipLaunchKernelGGL(norm_bwd_apply_bf16_kernel<float>, dim3(nb), dim3(256), smem, (hipStream_t)stream,
+                       static_cast<const float*>(g), ldg, static_cast<const __bf16*>(z), ldz, scale, shift, mean, invstd,
+                       c1, c2, slope, (long)rows, c, static_cast<__bf16*>(dz), lddz, bias_partials);
+  else
+    hipLaunchKernelGGL(norm_bwd_apply_bf16_kernel<__bf16>, dim3(nb), dim3(256), smem, (hipStream_t)stream,
+                       static_cast<const __bf16*>(g), ldg, static_cast<const __bf16*>(z), ldz, scale, shift, mean,
+                       invstd, c1, c2, slope, (long)rows, c, static_cast<__bf16*>(dz), lddz, bias_partials);
+  return check_launch("norm_bwd_apply_bf16");
+}

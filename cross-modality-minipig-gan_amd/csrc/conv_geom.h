@@ -33,6 +33,7 @@ struct GatherConv {
   int phase_outer;      // block order: 1 = phase slowest, 0 = phases of an m-tile adjacent (see conv_block_id)
   int ksplit;           // > 1: each block covers a K slice and leaves raw partial sums in kpartial
   float* kpartial;      // [ksplit][N*Do*Ho*Wo][Cout]
+  int in_bf16, out_bf16; // thin (VALU) kernels of the bf16 path: `in` / `out` point at bf16 data (weights stay fp32)
   Phase ph[8];
 };
 

@@ -864,7 +864,7 @@ __global__ __launch_bounds__(256) void thin_cin1_kernel(const GatherConv p) {
 // Cin == 1, Cout = 4*CQ <= 64: one thread = one output pixel x ALL output channels.  The input
 // sample of a tap is loaded once and meets the tap's whole weight row, read from LDS at a
 // wave-uniform address (broadcast); a thread stores 16*CQ contiguous bytes, a wave a contiguous run.
-template <int CQ>
+template <int CQ, bool OUT_BF16 = false>
 __global__ __launch_bounds__(256) void thin_cin1_full_kernel(const GatherConv p) {
   extern __shared__ __attribute__((aligned(16))) float wl[];   // [T][4*CQ]
   constexpr int CO = 4 * CQ;
@@ -910,6 +910,16 @@ __global__ __launch_bounds__(256) void thin_cin1_full_kernel(const GatherConv p)
     }
   }
   if (valid) {
+    if constexpr (OUT_BF16) {       // bf16 storage (config C5): the raw output rounded once; statistics below stay fp32
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      __bf16* o = reinterpret_cast<__bf16*>(p.out) + (long)d.opix * p.ldo;
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        bf16x4 t;
+        t[0] = (__bf16)acc[q].x; t[1] = (__bf16)acc[q].y; t[2] = (__bf16)acc[q].z; t[3] = (__bf16)acc[q].w;
+        *reinterpret_cast<bf16x4*>(o + 4 * q) = t;
+      }
+    } else {
     float* o = p.out + (long)d.opix * p.ldo;
     const float* r = p.resid ? p.resid + (long)d.opix * p.ldr : nullptr;
 #pragma unroll
@@ -921,6 +931,7 @@ __global__ __launch_bounds__(256) void thin_cin1_full_kernel(const GatherConv p)
       }
       if (p.tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
       *reinterpret_cast<float4*>(o + 4 * q) = v;
+    }
     }
   }
   if (p.stats) {
@@ -958,7 +969,7 @@ __global__ __launch_bounds__(256) void thin_cin1_full_kernel(const GatherConv p)
 
 // Cout == 1: LANES = Cin/4 lanes share one output pixel (16-byte channel chunks,
 // coalesced rows), then a shuffle reduction.
-template <int LANES>
+template <int LANES, bool IN_BF16 = false>
 __global__ __launch_bounds__(256) void thin_cout1_kernel(const GatherConv p) {
   extern __shared__ __attribute__((aligned(16))) float wl[];   // [T][Cin]
   const Phase ph = p.ph[blockIdx.z];
@@ -983,7 +994,14 @@ __global__ __launch_bounds__(256) void thin_cout1_kernel(const GatherConv p) {
         for (int jx = 0; jx < ph.nx; ++jx) {
           const int ix = d.bx + ph.dx0 + p.dstep[2] * jx, kx = ph.kx0 + p.kstep[2] * jx;
           if ((unsigned)ix >= (unsigned)p.Wi) continue;
-          const float4 v = *reinterpret_cast<const float4*>(p.in + (rowbase + ix) * p.ldi + 4 * l);
+          float4 v;
+          if constexpr (IN_BF16) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.in) + (rowbase + ix) * p.ldi + 4 * l);
+            v = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+          } else {
+            v = *reinterpret_cast<const float4*>(p.in + (rowbase + ix) * p.ldi + 4 * l);
+          }
           const float4 w = *reinterpret_cast<const float4*>(wl + ((kz * p.Ky + ky) * p.Kx + kx) * p.Cin + 4 * l);
           acc = fmaf(v.x, w.x, acc);
           acc = fmaf(v.y, w.y, acc);
@@ -1101,6 +1119,42 @@ static bool thin_cout1_ok(const GatherConv& p) {
 
 static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
   const int T = p.Kz * p.Ky * p.Kx;
+  if (p.out_bf16) {     // 1 -> C conv writing bf16 (D.conv1 of the bf16 path): all-channel kernel only
+    MPGAN_UNSUPPORTED(!(thin_cin1_ok(p) && (p.Cout == 16 || p.Cout == 32 || p.Cout == 64) && p.ldo % 4 == 0 &&
+                        (reinterpret_cast<uintptr_t>(p.out) & 7) == 0 && !p.resid && !p.tanh_out && !p.in_bf16 &&
+                        (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)),
+                      "thin conv (bf16 out): needs Cin == 1, Cout in {16, 32, 64}, no resid/tanh, aligned output");
+    MPGAN_UNSUPPORTED(p.stats && p.Cout > 64, "thin conv (bf16 out): fused statistics up to 64 channels");
+    dim3 grid((unsigned)((maxM + 255) / 256), 1, (unsigned)p.nphase);
+    const size_t smem = ((size_t)((T * p.Cout + 3) & ~3) + (p.stats ? 256 * (size_t)(p.Cout + 1) : 0)) * sizeof(float);
+    if (p.Cout == 16) hipLaunchKernelGGL((thin_cin1_full_kernel<4, true>), grid, dim3(256), smem, st, p);
+    else if (p.Cout == 32) hipLaunchKernelGGL((thin_cin1_full_kernel<8, true>), grid, dim3(256), smem, st, p);
+    else {
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(thin_cin1_full_kernel<16, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) { set_error("thin_cin1_full: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MPGAN_ERR_HIP; }
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((thin_cin1_full_kernel<16, true>), grid, dim3(256), smem, st, p);
+    }
+    return check_launch("thin_cin1_full_bf16");
+  }
+  if (p.in_bf16) {      // C -> 1 gather over bf16 data (backward-data of D.conv1 in the bf16 path)
+    const int lanes_b = p.Cin / 4;
+    MPGAN_UNSUPPORTED(!(p.Cout == 1 && !p.pro.scale && p.Cin % 4 == 0 && p.ldi % 4 == 0 &&
+                        (lanes_b == 4 || lanes_b == 8 || lanes_b == 16) && (reinterpret_cast<uintptr_t>(p.in) & 7) == 0 &&
+                        (long)T * p.Cin * 4 <= 48 * 1024 && !p.stats),
+                      "thin conv (bf16 in): needs Cout == 1 and 16, 32 or 64 gathered channels");
+    const long threads_b = maxM * lanes_b;
+    dim3 grid((unsigned)((threads_b + 255) / 256), 1, (unsigned)p.nphase);
+    const size_t smem = (size_t)T * p.Cin * sizeof(float);
+    if (lanes_b == 4) hipLaunchKernelGGL((thin_cout1_kernel<4, true>), grid, dim3(256), smem, st, p);
+    else if (lanes_b == 8) hipLaunchKernelGGL((thin_cout1_kernel<8, true>), grid, dim3(256), smem, st, p);
+    else hipLaunchKernelGGL((thin_cout1_kernel<16, true>), grid, dim3(256), smem, st, p);
+    return check_launch("thin_cout1_bf16");
+  }
   if (thin_cin1_ok(p)) {
     const bool v4 = (p.Cout % 4 == 0) && (p.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
     const bool full = v4 && (p.Cout == 16 || p.Cout == 32 || p.Cout == 64) &&
@@ -1930,4 +1984,43 @@ extern "C" int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward
   }
   if (v == 128 && has_prologue == 3 && fast_geometry(p, 128)) return 1128;
   return v;
+}
+
+// ---- thin layers of the bf16 path (D.conv1: 1 -> 64): fp32 image in, bf16 activations out, and back ----
+extern "C" int mpgan_conv_forward_f32_to_bf16(const mpgan_conv_geom* g, const float* x, int32_t ldx,
+                                              const float* w_packed, const float* bias, float* stats_partials,
+                                              void* y, int32_t ldy, void* stream) {
+  int rc = check_geom(g);
+  if (rc) return rc;
+  MPGAN_CHECK_ARG(x && w_packed && y, "conv_forward_f32_to_bf16: null pointer");
+  MPGAN_CHECK_ARG(ldx >= g->cin && ldy >= g->cout, "conv_forward_f32_to_bf16: bad pitch");
+  MPGAN_UNSUPPORTED(g->cin != 1 || g->transposed, "conv_forward_f32_to_bf16: ConvNd with one input channel only");
+  GatherConv p{};
+  p.in = x; p.wp = w_packed; p.out = static_cast<float*>(y); p.bias = bias;
+  p.pro = make_pro(nullptr);
+  p.ldi = ldx; p.ldo = ldy;
+  p.out_bf16 = 1;
+  p.stats = stats_partials;
+  build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+  const long maxM = max_phase_pixels(p);
+  MPGAN_CHECK_ARG(maxM < (1L << 31) - 256, "conv_forward_f32_to_bf16: more than 2^31 pixels");
+  return launch_thin(p, maxM, (hipStream_t)stream);
+}
+
+extern "C" int mpgan_conv_backward_data_bf16_to_f32(const mpgan_conv_geom* g, const void* dy, int32_t lddy,
+                                                    const float* w_packed_bwd, float* dx, int32_t lddx, void* stream) {
+  int rc = check_geom(g);
+  if (rc) return rc;
+  MPGAN_CHECK_ARG(dy && w_packed_bwd && dx, "conv_backward_data_bf16_to_f32: null pointer");
+  MPGAN_CHECK_ARG(lddy >= g->cout && lddx >= g->cin, "conv_backward_data_bf16_to_f32: bad pitch");
+  MPGAN_UNSUPPORTED(g->cin != 1 || g->transposed, "conv_backward_data_bf16_to_f32: ConvNd with one input channel only");
+  GatherConv p{};
+  p.in = static_cast<const float*>(dy); p.wp = w_packed_bwd; p.out = dx;
+  p.pro = make_pro(nullptr);
+  p.ldi = lddy; p.ldo = lddx;
+  p.in_bf16 = 1;
+  build_transposed(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
+  const long maxM = max_phase_pixels(p);
+  MPGAN_CHECK_ARG(maxM < (1L << 31) - 256, "conv_backward_data_bf16_to_f32: more than 2^31 pixels");
+  return launch_thin(p, maxM, (hipStream_t)stream);
 }

@@ -33,6 +33,7 @@ struct WgradParams {
   int sz, sy, sx, pz, py, px;
   int nsplit;
   long chunk;  // pixels per split (multiple of 32)
+  int dense_bf16;  // thin kernel only: `dense` points at bf16 data (dy of D.conv1 in the bf16 path)
   int tiles_c, tiles_d;  // 1-D launch of tiles_c*tiles_d*nsplit blocks, XCD-remapped, column tile fastest
   FastDiv fMx, fMy, fMz;
 };
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
 // chunk; LDS reduction over the lanes in fixed order; per-block partial slabs go
 // through the same deterministic slab reducer as the MFMA path.
 // ---------------------------------------------------------------------------
-template <int V, int T>
+template <int V, int T, bool DENSE_BF16 = false>
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p) {
   extern __shared__ float red[];                 // [PL][Cd*T + Cd]
   const int CQ = (p.Cd + V - 1) / V;
@@ -654,7 +655,12 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p) {
       fdivmod(r, p.fMz, r, umz);
       const int mx = (int)umx, my = (int)umy, mz = (int)umz, n = (int)r;
       float d[V];
-      if (V == 4 && c + 3 < p.Cd) {
+      if constexpr (DENSE_BF16) {               // host admits V == 4, Cd % 4 == 0 only
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.dense) + m * p.ldd + c);
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = (float)t4[e < 4 ? e : 0];
+      } else if (V == 4 && c + 3 < p.Cd) {
         const float4 t4 = *reinterpret_cast<const float4*>(p.dense + m * p.ldd + c);
         d[0] = t4.x; d[V > 1 ? 1 : 0] = t4.y; d[V > 2 ? 2 : 0] = t4.z; d[V > 3 ? 3 : 0] = t4.w;
       } else {
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p) {
 }
 
 struct ThinWgradPlan { int blocks; long chunk; bool ok; };
-static ThinWgradPlan plan_thin_wgrad(int Cd, int Cg, int T, long M, bool has_pro) {
+static ThinWgradPlan plan_thin_wgrad(int Cd, int Cg, int T, long M, bool has_pro, long lds_cap = 64 * 1024) {
   ThinWgradPlan t;
   t.ok = Cg == 1 && !has_pro && Cd <= 64 && (T == 1 || T == 9 || T == 27);   // kernel shape checked by the caller
   // latency-bound pixel walk: short chunks keep every CU busy, but each block pays a fixed LDS fold
@@ -726,7 +732,7 @@ static ThinWgradPlan plan_thin_wgrad(int Cd, int Cg, int T, long M, bool has_pro
   const int V = Cd % 4 == 0 ? 4 : 1;
   const int CQ = (Cd + V - 1) / V;
   const int PL = 256 / CQ;
-  if ((long)PL * (Cd * T + Cd) * 4 > 64 * 1024) t.ok = false;
+  if ((long)PL * (Cd * T + Cd) * 4 > lds_cap) t.ok = false;
   return t;
 }
 
@@ -972,4 +978,73 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + bb), dim3(256), 0, st, p.partial, dw, pl.nsplit * pl.kw, Cd, Cg,
                      T, beta, p.bias_partial, pl.nsplit, dbias, bb);
   return check_launch("wgrad_reduce");
+}
+
+// Weight gradient of a 1 -> C ConvNd whose output gradient is stored as bf16 (D.conv1 in the bf16 path):
+// the thin HBM-bound reduction, dy converted on load; dW / dbias and the slabs stay fp32.
+extern "C" int mpgan_conv_backward_weight_bf16dy(const mpgan_conv_geom* g, const float* x, int32_t ldx, const void* dy,
+                                                 int32_t lddy, float* dw, float* dbias, float beta, void* workspace,
+                                                 int64_t workspace_bytes, void* stream) {
+  MPGAN_CHECK_ARG(g && x && dy && dw && workspace, "conv_backward_weight_bf16dy: null pointer");
+  MPGAN_UNSUPPORTED(g->transposed || g->cin != 1, "conv_backward_weight_bf16dy: ConvNd with one input channel only");
+  int Cd, Cg, T;
+  long M;
+  wgrad_dims(g, Cd, Cg, T, M);
+  MPGAN_CHECK_ARG(M < (1L << 31) - 64, "conv_backward_weight_bf16dy: more than 2^31 pixels");
+  ThinWgradPlan tp = plan_thin_wgrad(Cd, Cg, T, M, false, 150 * 1024);   // 3-D 1 -> 64: 112 KiB of lane rows, one block per CU
+  const bool kshape = (T == 1) || (T == 9 && g->k[0] == 1) || (T == 27 && g->k[0] == 3 && g->k[1] == 3 && g->k[2] == 3);
+  MPGAN_UNSUPPORTED(!tp.ok || !kshape || Cd % 4 != 0 || lddy % 4 != 0 || (reinterpret_cast<uintptr_t>(dy) & 7),
+                    "conv_backward_weight_bf16dy: thin path only (Cout %% 4 == 0, <= 64 channels, 1 / 3x3 / 3x3x3 kernel)");
+  const int64_t tslab = (int64_t)tp.blocks * Cd * T;
+  MPGAN_CHECK_ARG(workspace_bytes >= (tslab + (int64_t)tp.blocks * Cd) * (int64_t)sizeof(float),
+                  "conv_backward_weight_bf16dy: workspace too small");
+  WgradParams p{};
+  p.partial = static_cast<float*>(workspace);
+  p.bias_partial = dbias ? p.partial + tslab : nullptr;
+  p.Kz = g->k[0]; p.Ky = g->k[1]; p.Kx = g->k[2];
+  p.sz = g->stride[0]; p.sy = g->stride[1]; p.sx = g->stride[2];
+  p.pz = g->pad[0]; p.py = g->pad[1]; p.px = g->pad[2];
+  p.N = g->n;
+  p.chunk = tp.chunk;
+  p.dense = static_cast<const float*>(dy); p.ldd = lddy; p.Cd = Cd; p.dense_bf16 = 1;
+  p.gath = x; p.ldg = ldx; p.Cg = 1;
+  p.pro = make_pro(nullptr);
+  p.Mz = g->out_dhw[0]; p.My = g->out_dhw[1]; p.Mx = g->out_dhw[2];
+  p.Gz = g->in_dhw[0]; p.Gy = g->in_dhw[1]; p.Gx = g->in_dhw[2];
+  p.fMx = make_fastdiv(p.Mx); p.fMy = make_fastdiv(p.My); p.fMz = make_fastdiv(p.Mz);
+  hipStream_t st = (hipStream_t)stream;
+  const int CQ = Cd / 4, PL = 256 / CQ;
+  const size_t smem = (size_t)PL * (Cd * T + Cd) * sizeof(float);
+  dim3 grid(tp.blocks);
+  if (smem > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(thin_wgrad_kernel<4, 27, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      if (e != hipSuccess) { set_error("thin_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MPGAN_ERR_HIP; }
+      attr_set = true;
+    }
+    MPGAN_UNSUPPORTED(T != 27, "conv_backward_weight_bf16dy: more than 64 KiB of lane rows outside the 3x3x3 case");
+  }
+  if (T == 1) hipLaunchKernelGGL((thin_wgrad_kernel<4, 1, true>), grid, dim3(256), smem, st, p);
+  else if (T == 9) hipLaunchKernelGGL((thin_wgrad_kernel<4, 9, true>), grid, dim3(256), smem, st, p);
+  else hipLaunchKernelGGL((thin_wgrad_kernel<4, 27, true>), grid, dim3(256), smem, st, p);
+  int rc = check_launch("thin_wgrad_bf16dy");
+  if (rc) return rc;
+  const long total = (long)Cd * T;
+  const int blocks = (int)((total + 31) / 32);
+  const int bb = dbias ? (Cd + 31) / 32 : 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + bb), dim3(256), 0, st, p.partial, dw, tp.blocks, Cd, 1, T, beta,
+                     p.bias_partial, tp.blocks, dbias, bb);
+  return check_launch("thin_wgrad_bf16dy_reduce");
+}
+
+extern "C" int64_t mpgan_conv_wgrad_workspace_bf16dy(const mpgan_conv_geom* g) {
+  if (!g) return -1;
+  int Cd, Cg, T;
+  long M;
+  wgrad_dims(g, Cd, Cg, T, M);
+  ThinWgradPlan tp = plan_thin_wgrad(Cd, Cg, T, M, false, 150 * 1024);
+  if (!tp.ok) return -1;
+  return ((int64_t)tp.blocks * Cd * T + (int64_t)tp.blocks * Cd) * (int64_t)sizeof(float);
 }

@@ -1057,6 +1057,166 @@ class DiscPlan:
 
 
 # --------------------------------------------------------------------------
+# discriminator (variant A), bf16 storage (BASELINE config C5)
+# --------------------------------------------------------------------------
+class DiscPlanBF16:
+    """The same network as DiscPlan with bf16 activations, activation gradients and packed weights in HBM
+    (code/GAN/GAN_final.py:159-209 at the reference's 3-D shape); fp32 accumulation, statistics, parameters,
+    weight gradients and Adam.  Per layer: raw conv output z (bf16) + fused fp32 statistics -> finalize ->
+    a = LeakyReLU(BN(z)) materialised once (bf16; fp32 for the last layer, which the fp32 Linear head reads).
+    The first layer (1 input channel) runs on the HBM-bound VALU kernels with fp32 weights."""
+
+    def __init__(self, disc, store: ParamStore, n: int, spatial: Sequence[int], *, want_backward: bool,
+                 want_input_grad: bool, want_param_grads: bool):
+        dims = disc.dimensions
+        dev = store.flat.device
+        dhw = _t3(spatial, dims, 1)
+        self.n, self.dhw, self.dims, self.store = n, dhw, dims, store
+        bf = torch.bfloat16
+        E = lambda *shape: torch.empty(*shape, device=dev)
+        H = lambda *shape: torch.empty(*shape, device=dev, dtype=bf)
+        convs = [disc.model_conv[i] for i in (0, 3, 6, 9)]
+        bns = [disc.model_conv[i] for i in (1, 4, 7, 10)]
+        lin = disc.model_linear[1]
+        self.x_in = E(n, *dhw, 1)
+        geoms, zs, acts, nbs, recs = [], [], [], [], []
+        size = dhw
+        L = lib()
+        part_need, ws_need = 4, 4
+        for i, cv in enumerate(convs):
+            g = conv_geom_of(cv, n, size, dims)
+            geoms.append(g)
+            size = g.out_dhw
+            if min(size) < 1:
+                raise ValueError(f"discriminator input {spatial} too small")
+            zs.append(H(n, *size, cv.out_channels))
+            acts.append(E(n, *size, cv.out_channels) if i == 3 else H(n, *size, cv.out_channels))
+            nbs.append(NormBuf(n, cv.out_channels, False, dev))
+            taps = 1
+            for k in cv.kernel_size:
+                taps *= k
+            recs.append(store.register_conv(cv, cout=cv.out_channels, cin=cv.in_channels, taps=taps))
+            rows_total = n * size[0] * size[1] * size[2]
+            fwd_rows = (rows_total + 255) // 256 if i == 0 else ops.conv_stats_rows_bf16(g)
+            bwd_rows = ops.norm_bwd_rows_bf16(rows_total, cv.out_channels)
+            part_need = max(part_need, (fwd_rows + 32) * 2 * cv.out_channels, bwd_rows * 4 * cv.out_channels + cv.out_channels)
+            ws_need = max(ws_need, (ops.conv_wgrad_workspace_bf16dy(g) if i == 0 else ops.conv_wgrad_workspace_bf16(g)) // 4)
+        P_last = size[0] * size[1] * size[2]
+        c_last = convs[-1].out_channels
+        if lin.in_features != P_last * c_last:
+            raise ValueError(f"Linear.in_features {lin.in_features} != {c_last}*{P_last} for input {spatial}")
+        rlin = store.register_conv(lin, cout=1, cin=c_last, taps=P_last)
+        part = E(part_need)
+        ws = E(ws_need)
+        # bf16 packs of the three dense layers: [Cout][tap][Cin] (forward) and [Cin][tap][Cout] (backward-data)
+        rows16, off = [], 0
+        self._w16 = {}
+        for i in (1, 2, 3):
+            r = recs[i]
+            nel = r.cout * r.cin * r.taps
+            self._w16[i] = (off, off + (nel + 7) // 8 * 8, nel)
+            rows16.append([r.w_off, off, r.cout, r.cin, r.taps, 0, 0, 0])
+            rows16.append([r.w_off, off + (nel + 7) // 8 * 8, r.cout, r.cin, r.taps, 0, 1, 0])
+            off += 2 * ((nel + 7) // 8 * 8)
+        packed16 = torch.empty(off, device=dev, dtype=bf)
+        table16 = torch.tensor(rows16, dtype=torch.int64, device=dev)
+        w16 = lambda i: packed16[self._w16[i][0]:self._w16[i][0] + self._w16[i][2]]
+        w16b = lambda i: packed16[self._w16[i][1]:self._w16[i][1] + self._w16[i][2]]
+        self.logit, self.prob = E(n), E(n)
+        lin_part = E(ops.linear1_partials(n))
+        f = self.fwd = Program()
+        store.emit_pack(f)                                   # fp32 packs: first layer, Linear head
+        f.add("pack_weights_bf16", L.mpgan_pack_weights_bf16, store.flat.data_ptr(), packed16.data_ptr(),
+              table16.data_ptr(), table16.shape[0], max(r.cout * r.cin * r.taps for r in recs[1:]),
+              keep=(packed16, table16))
+        src = self.x_in
+        for i, cv in enumerate(convs):
+            g, z, nb, bn = geoms[i], zs[i], nbs[i], bns[i]
+            gc = g.c()
+            rows_total = n * g.out_dhw[0] * g.out_dhw[1] * g.out_dhw[2]
+            if i == 0:
+                rows = (rows_total + 255) // 256
+                f.add("conv_forward_f32_to_bf16", L.mpgan_conv_forward_f32_to_bf16, C.byref(gc), src.data_ptr(), 1,
+                      store.wp(recs[0]).data_ptr(), cv.bias.data_ptr(), part.data_ptr(), z.data_ptr(), g.cout,
+                      keep=(gc, src, z, part), desc=_gdesc(g), tag=("thin_cin1_full_kernel<16, true>", 2.0 * conv_macs(g)))
+            else:
+                rows = ops.conv_stats_rows_bf16(g)
+                f.add("conv_forward_bf16", L.mpgan_conv_forward_bf16, C.byref(gc), src.data_ptr(), g.cin,
+                      w16(i).data_ptr(), cv.bias.data_ptr(), part.data_ptr(), z.data_ptr(), g.cout,
+                      keep=(gc, src, z, part), desc=_gdesc(g),
+                      tag=(f"gather_conv_bf16_kernel<{128 if g.cout > 64 else 64}, false>", 2.0 * conv_macs(g)))
+            f.add("norm_finalize", L.mpgan_norm_finalize, part.data_ptr(), 1, rows, g.cout, rows_total, 0,
+                  _p(bn.weight), _p(bn.bias), float(bn.eps), float(bn.momentum), _p(bn.running_mean),
+                  _p(bn.running_var), _p(bn.num_batches_tracked), nb.scale.data_ptr(), nb.shift.data_ptr(),
+                  nb.mean.data_ptr(), nb.invstd.data_ptr(), keep=(bn, nb))
+            a = acts[i]
+            f.add("norm_act_bf16", L.mpgan_norm_act_bf16, z.data_ptr(), g.cout, nb.scale.data_ptr(), nb.shift.data_ptr(),
+                  0.2, rows_total, g.cout, a.data_ptr(), g.cout, int(a.dtype == torch.float32), keep=(a,))
+            src = a
+        f.add("linear1_forward", L.mpgan_linear1_forward, acts[3].data_ptr(), None, n, P_last, c_last,
+              store.wp(rlin).data_ptr(), lin.bias.data_ptr(), lin_part.data_ptr(), self.logit.data_ptr(),
+              self.prob.data_ptr(), keep=(lin_part,))
+        self.zs, self.acts, self.nbs = zs, acts, nbs
+        self.busy = False
+        self.bwd = Program()
+        self.g_x = None
+        if not want_backward:
+            return
+        b = self.bwd
+        gv = store.grad_view if want_param_grads else (lambda p: None)
+        self.g_prob = E(n)
+        dlogit = E(n)
+        # gradients w.r.t. the activations; the BatchNorm backward overwrites them in place with dz
+        gas = [H(*z.shape) for z in zs[:3]] + [E(*zs[3].shape)]
+        dz4 = H(*zs[3].shape)
+        self.gas = gas
+        b.add("sigmoid_backward", L.mpgan_sigmoid_backward, self.g_prob.data_ptr(), self.prob.data_ptr(), n,
+              dlogit.data_ptr(), keep=(dlogit,))
+        b.add("linear1_backward", L.mpgan_linear1_backward, acts[3].data_ptr(), None, n, P_last, c_last,
+              store.wp(rlin).data_ptr(), dlogit.data_ptr(), gas[3].data_ptr(), _p(gv(lin.weight)), _p(gv(lin.bias)),
+              1.0, keep=(gas, dz4))
+        for i in range(3, -1, -1):
+            g, z, nb, bn, cv = geoms[i], zs[i], nbs[i], bns[i], convs[i]
+            gc = g.c()
+            c = g.cout
+            rows_total = n * g.out_dhw[0] * g.out_dhw[1] * g.out_dhw[2]
+            brow = ops.norm_bwd_rows_bf16(rows_total, c)
+            gin = gas[i]
+            dz = dz4 if i == 3 else gas[i]
+            g32 = int(gin.dtype == torch.float32)
+            bias_part = part[brow * 3 * c + c:brow * 4 * c + c] if (want_param_grads and i > 0) else None
+            b.add("norm_bwd_reduce_bf16", L.mpgan_norm_bwd_reduce_bf16, gin.data_ptr(), g32, c, z.data_ptr(), c,
+                  nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(), 0.2, rows_total,
+                  c, part.data_ptr(), keep=(gin, z, nb, part))
+            b.add("norm_bwd_finalize", L.mpgan_norm_bwd_finalize, part.data_ptr(), 1, brow, c, rows_total, 0,
+                  _p(gv(bn.weight)), _p(gv(bn.bias)), None, nb.c1.data_ptr(), nb.c2.data_ptr(), keep=(bn,))
+            b.add("norm_bwd_apply_bf16", L.mpgan_norm_bwd_apply_bf16, gin.data_ptr(), g32, c, z.data_ptr(), c,
+                  nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
+                  nb.c1.data_ptr(), nb.c2.data_ptr(), 0.2, rows_total, c, dz.data_ptr(), c, _p(bias_part), keep=(dz,))
+            if want_param_grads:
+                if i > 0:
+                    b.add("reduce_partials", L.mpgan_reduce_partials, bias_part.data_ptr(), brow, c, c,
+                          gv(cv.bias).data_ptr(), 1.0, keep=(bias_part,))
+                    b.add("conv_backward_weight_bf16", L.mpgan_conv_backward_weight_bf16, C.byref(gc),
+                          acts[i - 1].data_ptr(), g.cin, dz.data_ptr(), c, gv(cv.weight).data_ptr(), 1.0,
+                          ws.data_ptr(), ws.numel() * 4, keep=(gc, ws), desc=_gdesc(g),
+                          tag=("wgrad_bf16_kernel", 2.0 * conv_macs(g)))
+                else:
+                    b.add("conv_backward_weight_bf16dy", L.mpgan_conv_backward_weight_bf16dy, C.byref(gc),
+                          self.x_in.data_ptr(), 1, dz.data_ptr(), c, gv(cv.weight).data_ptr(), gv(cv.bias).data_ptr(),
+                          1.0, ws.data_ptr(), ws.numel() * 4, keep=(gc, ws), desc=_gdesc(g),
+                          tag=("wgrad_thin_kernel", 2.0 * conv_macs(g)))
+            if i > 0:
+                b.add("conv_backward_data_bf16", L.mpgan_conv_backward_data_bf16, C.byref(gc), dz.data_ptr(), c,
+                      w16b(i).data_ptr(), gas[i - 1].data_ptr(), g.cin, keep=(gc,), desc=_gdesc(g),
+                      tag=(f"dgrad:gather_conv_bf16_kernel<{128 if g.cin > 64 else 64}, true>", 2.0 * conv_macs(g)))
+            elif want_input_grad:
+                self.g_x = E(n, *dhw, 1)
+                b.add("conv_backward_data_bf16_to_f32", L.mpgan_conv_backward_data_bf16_to_f32, C.byref(gc), dz.data_ptr(),
+                      c, store.wp_bwd(recs[0]).data_ptr(), self.g_x.data_ptr(), 1, keep=(gc, self.g_x), desc=_gdesc(g))
+
+
+# --------------------------------------------------------------------------
 # patch discriminator (variant B)
 # --------------------------------------------------------------------------
 class PatchDiscPlan:

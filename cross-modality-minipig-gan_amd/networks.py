@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .engine import DiscPlan, GeneratorPlan, ParamStore
+from .engine import DiscPlan, DiscPlanBF16, GeneratorPlan, ParamStore
 
 _CONV = {2: nn.Conv2d, 3: nn.Conv3d}
 _CONVT = {2: nn.ConvTranspose2d, 3: nn.ConvTranspose3d}
@@ -257,7 +257,8 @@ class _DiscFn(torch.autograd.Function):
         n = x.shape[0]
         store = disc.store
         key = (n, spatial, need_bwd, want_in, want_par)
-        plan = disc._acquire(key, lambda: DiscPlan(disc, store, n, spatial, want_backward=need_bwd,
+        plan_cls = DiscPlanBF16 if disc.storage_dtype == "bf16" else DiscPlan
+        plan = disc._acquire(key, lambda: plan_cls(disc, store, n, spatial, want_backward=need_bwd,
                                                    want_input_grad=want_in, want_param_grads=want_par))
         lease = _Lease(plan)
         plan.x_in.view(-1).copy_(x.reshape(-1))

@@ -462,3 +462,166 @@ def pack_weight(w: torch.Tensor, *, transposed: bool = False, for_dgrad: bool = 
     packed = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
     pack_weights(w, packed, table, 1, w.numel())
     return packed
+
+
+# --------------------------------------------------------------------------
+# bf16 storage path (BASELINE config C5): activations / packed weights bf16, fp32 accumulate + statistics
+# --------------------------------------------------------------------------
+def _clx(t: torch.Tensor, dtype, what: str) -> Tuple[int, int, int]:
+    """_cl for a channels-last tensor of the given dtype."""
+    if t.dim() != 5 or t.dtype != dtype or not t.is_cuda:
+        raise ValueError(f"{what}: need a CUDA {dtype} (N,D,H,W,C) tensor, got {tuple(t.shape)} {t.dtype} {t.device}")
+    n, d, h, w, c = t.shape
+    st = t.stride()
+    ld = st[3] if w > 1 else (st[2] if h > 1 else (st[1] if d > 1 else (st[0] if n > 1 else c)))
+    want = (d * h * w * ld, h * w * ld, w * ld, ld, 1)
+    if not (ld >= c and all(sz == 1 or a == b for sz, a, b in zip(t.shape, st, want))):
+        raise ValueError(f"{what}: not a pixel-contiguous channels-last view: shape {tuple(t.shape)} strides {st}")
+    return n, d * h * w, ld
+
+
+BF16 = torch.bfloat16
+
+
+def _check_shapes(g: ConvGeom, x, y, what):
+    if tuple(x.shape) != (g.n, *g.in_dhw, g.cin) or tuple(y.shape) != (g.n, *g.out_dhw, g.cout):
+        raise ValueError(f"{what}: shapes {tuple(x.shape)} / {tuple(y.shape)} do not match the geometry")
+
+
+def conv_stats_rows_bf16(g: ConvGeom) -> int:
+    gc = g.c()
+    return int(lib().mpgan_conv_stats_rows_bf16(C.byref(gc)))
+
+
+def conv_forward_bf16(g: ConvGeom, x, w_packed, bias, y, *, stats_partials=None):
+    _check_shapes(g, x, y, "conv_forward_bf16")
+    _, _, ldx = _clx(x, BF16, "conv_forward_bf16 x")
+    _, _, ldy = _clx(y, BF16, "conv_forward_bf16 y")
+    if w_packed.dtype != BF16 or w_packed.numel() < g.cout * g.cin * g.taps:
+        raise ValueError("conv_forward_bf16: packed weight must be bf16 and complete")
+    if stats_partials is not None and stats_partials.numel() < conv_stats_rows_bf16(g) * 2 * g.cout:
+        raise ValueError("conv_forward_bf16: stats_partials too small")
+    gc = g.c()
+    check(lib().mpgan_conv_forward_bf16(C.byref(gc), x.data_ptr(), ldx, w_packed.data_ptr(), _ptr(bias),
+                                        _ptr(stats_partials), y.data_ptr(), ldy, _stream()), "conv_forward_bf16")
+    return y
+
+
+def conv_backward_data_bf16(g: ConvGeom, dy, w_packed_bwd, dx):
+    _check_shapes(g, dx, dy, "conv_backward_data_bf16")
+    _, _, lddy = _clx(dy, BF16, "conv_backward_data_bf16 dy")
+    _, _, lddx = _clx(dx, BF16, "conv_backward_data_bf16 dx")
+    if w_packed_bwd.dtype != BF16:
+        raise ValueError("conv_backward_data_bf16: packed weight must be bf16")
+    gc = g.c()
+    check(lib().mpgan_conv_backward_data_bf16(C.byref(gc), dy.data_ptr(), lddy, w_packed_bwd.data_ptr(), dx.data_ptr(),
+                                              lddx, _stream()), "conv_backward_data_bf16")
+    return dx
+
+
+def conv_wgrad_workspace_bf16(g: ConvGeom) -> int:
+    gc = g.c()
+    return int(lib().mpgan_conv_wgrad_workspace_bf16(C.byref(gc)))
+
+
+def conv_backward_weight_bf16(g: ConvGeom, x, dy, dw, workspace, *, beta: float = 0.0):
+    _check_shapes(g, x, dy, "conv_backward_weight_bf16")
+    _, _, ldx = _clx(x, BF16, "conv_backward_weight_bf16 x")
+    _, _, lddy = _clx(dy, BF16, "conv_backward_weight_bf16 dy")
+    if dw.dtype != torch.float32 or dw.numel() != g.cout * g.cin * g.taps or not dw.is_contiguous():
+        raise ValueError("conv_backward_weight_bf16: dw must be the contiguous fp32 torch-layout weight gradient")
+    gc = g.c()
+    check(lib().mpgan_conv_backward_weight_bf16(C.byref(gc), x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(),
+                                                float(beta), workspace.data_ptr(),
+                                                workspace.numel() * workspace.element_size(), _stream()),
+          "conv_backward_weight_bf16")
+    return dw
+
+
+def conv_forward_f32_to_bf16(g: ConvGeom, x, w_packed, bias, y, *, stats_partials=None):
+    _check_shapes(g, x, y, "conv_forward_f32_to_bf16")
+    _, _, ldx = _cl(x, "conv_forward_f32_to_bf16 x")
+    _, _, ldy = _clx(y, BF16, "conv_forward_f32_to_bf16 y")
+    gc = g.c()
+    check(lib().mpgan_conv_forward_f32_to_bf16(C.byref(gc), x.data_ptr(), ldx, w_packed.data_ptr(), _ptr(bias),
+                                               _ptr(stats_partials), y.data_ptr(), ldy, _stream()),
+          "conv_forward_f32_to_bf16")
+    return y
+
+
+def conv_backward_data_bf16_to_f32(g: ConvGeom, dy, w_packed_bwd, dx):
+    _check_shapes(g, dx, dy, "conv_backward_data_bf16_to_f32")
+    _, _, lddy = _clx(dy, BF16, "conv_backward_data_bf16_to_f32 dy")
+    _, _, lddx = _cl(dx, "conv_backward_data_bf16_to_f32 dx")
+    gc = g.c()
+    check(lib().mpgan_conv_backward_data_bf16_to_f32(C.byref(gc), dy.data_ptr(), lddy, w_packed_bwd.data_ptr(),
+                                                     dx.data_ptr(), lddx, _stream()), "conv_backward_data_bf16_to_f32")
+    return dx
+
+
+def conv_wgrad_workspace_bf16dy(g: ConvGeom) -> int:
+    gc = g.c()
+    return int(lib().mpgan_conv_wgrad_workspace_bf16dy(C.byref(gc)))
+
+
+def conv_backward_weight_bf16dy(g: ConvGeom, x, dy, dw, workspace, *, beta: float = 0.0, dbias=None):
+    _check_shapes(g, x, dy, "conv_backward_weight_bf16dy")
+    _, _, ldx = _cl(x, "conv_backward_weight_bf16dy x")
+    _, _, lddy = _clx(dy, BF16, "conv_backward_weight_bf16dy dy")
+    gc = g.c()
+    check(lib().mpgan_conv_backward_weight_bf16dy(C.byref(gc), x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(),
+                                                  _ptr(dbias), float(beta), workspace.data_ptr(),
+                                                  workspace.numel() * workspace.element_size(), _stream()),
+          "conv_backward_weight_bf16dy")
+    return dw
+
+
+def pack_weight_bf16(w: torch.Tensor, *, for_dgrad: bool = False) -> torch.Tensor:
+    """One fp32 ConvNd weight -> bf16 [Cout][tap][Cin] (or [Cin][tap][Cout] for backward-data)."""
+    w = w.contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w.numel() // (cin * cout)
+    table = torch.tensor([[0, 0, cout, cin, taps, 0, int(for_dgrad), 0]], dtype=torch.int64, device=w.device)
+    packed = torch.empty(w.numel(), dtype=BF16, device=w.device)
+    check(lib().mpgan_pack_weights_bf16(w.data_ptr(), packed.data_ptr(), table.data_ptr(), 1, w.numel(), _stream()),
+          "pack_weights_bf16")
+    return packed
+
+
+def norm_act_bf16(z, scale, shift, slope: float, out):
+    n, P, ldz = _clx(z, BF16, "norm_act_bf16 z")
+    if out.shape != z.shape or out.dtype not in (BF16, torch.float32):
+        raise ValueError("norm_act_bf16: out must match z and be bf16 or fp32")
+    _, _, ldo = _clx(out, out.dtype, "norm_act_bf16 out")
+    check(lib().mpgan_norm_act_bf16(z.data_ptr(), ldz, scale.data_ptr(), shift.data_ptr(), float(slope), n * P,
+                                    z.shape[-1], out.data_ptr(), ldo, int(out.dtype == torch.float32), _stream()),
+          "norm_act_bf16")
+    return out
+
+
+def norm_bwd_rows_bf16(rows: int, c: int) -> int:
+    return int(lib().mpgan_norm_bwd_rows_bf16(rows, c))
+
+
+def norm_bwd_reduce_bf16(g, z, scale, shift, mean, invstd, slope: float, partials):
+    n, P, ldz = _clx(z, BF16, "norm_bwd_reduce_bf16 z")
+    _, _, ldg = _clx(g, g.dtype, "norm_bwd_reduce_bf16 g")
+    c = z.shape[-1]
+    if partials.numel() < norm_bwd_rows_bf16(n * P, c) * 3 * c + c:
+        raise ValueError("norm_bwd_reduce_bf16: partials too small")
+    check(lib().mpgan_norm_bwd_reduce_bf16(g.data_ptr(), int(g.dtype == torch.float32), ldg, z.data_ptr(), ldz,
+                                           scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                           float(slope), n * P, c, partials.data_ptr(), _stream()),
+          "norm_bwd_reduce_bf16")
+
+
+def norm_bwd_apply_bf16(g, z, scale, shift, mean, invstd, c1, c2, slope: float, dz, bias_partials=None):
+    n, P, ldz = _clx(z, BF16, "norm_bwd_apply_bf16 z")
+    _, _, ldg = _clx(g, g.dtype, "norm_bwd_apply_bf16 g")
+    _, _, lddz = _clx(dz, BF16, "norm_bwd_apply_bf16 dz")
+    c = z.shape[-1]
+    check(lib().mpgan_norm_bwd_apply_bf16(g.data_ptr(), int(g.dtype == torch.float32), ldg, z.data_ptr(), ldz,
+                                          scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                          c1.data_ptr(), c2.data_ptr(), float(slope), n * P, c, dz.data_ptr(), lddz,
+                                          _ptr(bias_partials), _stream()), "norm_bwd_apply_bf16")
+    return dz

@@ -336,6 +336,56 @@ int mpgan_patch_scatter_add(const float* dpatches, int32_t b, const int32_t dhw[
                             const int32_t* corners, int32_t samples, const int32_t roi[3],
                             float* dvol, void* stream);
 
+/* ---- bf16 storage path (BASELINE config C5: the reference's own 3-D graph, GAN_final.py:106-114,167-189) ----
+ * Activations, activation gradients and packed weights are bf16 in HBM (void* below); products accumulate in fp32
+ * on v_mfma_f32_32x32x16_bf16; BatchNorm statistics, parameters, weight gradients and Adam stay fp32.
+ * There is no normalise-on-load prologue in this path: a layer's BatchNorm + LeakyReLU output is materialised
+ * once by mpgan_norm_act_bf16 (see conv_bf16.hip for why) and convolutions read plain activations. */
+
+/* y (bf16) = conv(x (bf16)) + bias; gathered channels % 64 == 0, output channels % 8 == 0, <= 32 taps per phase.
+ * stats_partials (nullable): per-tile partial sums [rows][2][Cout] of (y, y^2) in fp32 taken before rounding,
+ * rows = mpgan_conv_stats_rows_bf16(); consumed by mpgan_norm_finalize(n=1, chunks=rows, pixels=N*D*H*W). */
+int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g);
+int mpgan_conv_forward_bf16(const mpgan_conv_geom* g, const void* x, int32_t ldx, const void* w_packed,
+                            const float* bias, float* stats_partials, void* y, int32_t ldy, void* stream);
+/* dx (bf16) = conv_backward_data(dy (bf16)); w_packed_bwd: bf16, layout 1 of mpgan_pack_weights_bf16. */
+int mpgan_conv_backward_data_bf16(const mpgan_conv_geom* g, const void* dy, int32_t lddy, const void* w_packed_bwd,
+                                  void* dx, int32_t lddx, void* stream);
+/* dW (fp32, torch layout) = beta*dW + sum over pixels of dy (bf16) x gathered x (bf16): pad-free ConvNd. */
+int64_t mpgan_conv_wgrad_workspace_bf16(const mpgan_conv_geom* g);
+int mpgan_conv_backward_weight_bf16(const mpgan_conv_geom* g, const void* x, int32_t ldx, const void* dy, int32_t lddy,
+                                    float* dw, float beta, void* workspace, int64_t workspace_bytes, void* stream);
+/* The 1-input-channel first layer (Discriminator.model_conv[0]): fp32 image in / bf16 raw output out, its
+ * backward-data (bf16 dy -> fp32 dx) and its weight gradient with a bf16 dy (HBM-bound VALU kernels; packed
+ * weights fp32 as in the fp32 path). */
+int mpgan_conv_forward_f32_to_bf16(const mpgan_conv_geom* g, const float* x, int32_t ldx, const float* w_packed,
+                                   const float* bias, float* stats_partials, void* y, int32_t ldy, void* stream);
+int mpgan_conv_backward_data_bf16_to_f32(const mpgan_conv_geom* g, const void* dy, int32_t lddy,
+                                         const float* w_packed_bwd, float* dx, int32_t lddx, void* stream);
+int64_t mpgan_conv_wgrad_workspace_bf16dy(const mpgan_conv_geom* g);
+int mpgan_conv_backward_weight_bf16dy(const mpgan_conv_geom* g, const float* x, int32_t ldx, const void* dy,
+                                      int32_t lddy, float* dw, float* dbias, float beta, void* workspace,
+                                      int64_t workspace_bytes, void* stream);
+/* mpgan_pack_weights with a bf16 destination (same table; layouts 0 and 1; dst offsets in elements). */
+int mpgan_pack_weights_bf16(const float* flat_params, void* packed, const int64_t* table, int32_t n_entries,
+                            int64_t max_elems, void* stream);
+/* out = LeakyReLU_slope(z*scale[c] + shift[c]) over [rows][C] bf16 z; out is bf16, or fp32 when out_f32 != 0
+ * (the tensor the fp32 Linear head reads).  (nn.BatchNorm3d + nn.LeakyReLU(0.2), GAN_final.py:170-171.) */
+int mpgan_norm_act_bf16(const void* z, int32_t ldz, const float* scale, const float* shift, float slope, int64_t rows,
+                        int32_t c, void* out, int32_t ldo, int32_t out_f32, void* stream);
+/* BatchNorm + LeakyReLU backward on bf16 z, given g = dL/da (bf16, or fp32 when g_f32 != 0):
+ *   reduce: partial rows [mpgan_norm_bwd_rows_bf16()][3][C] for mpgan_norm_bwd_finalize(n=1, chunks=rows, P=rows_total);
+ *   apply : dz (bf16) = scale*(gy - c1 - zhat*c2); bias_partials (nullable) receives per-block column sums
+ *           [mpgan_norm_bwd_rows_bf16()][C] of the stored dz (the conv's bias gradient, reduce with mpgan_reduce_partials). */
+int32_t mpgan_norm_bwd_rows_bf16(int64_t rows, int32_t c);
+int mpgan_norm_bwd_reduce_bf16(const void* g, int32_t g_f32, int32_t ldg, const void* z, int32_t ldz, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, float slope, int64_t rows,
+                               int32_t c, float* partials, void* stream);
+int mpgan_norm_bwd_apply_bf16(const void* g, int32_t g_f32, int32_t ldg, const void* z, int32_t ldz, const float* scale,
+                              const float* shift, const float* mean, const float* invstd, const float* c1,
+                              const float* c2, float slope, int64_t rows, int32_t c, void* dz, int32_t lddz,
+                              float* bias_partials, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -315,23 +315,6 @@ __global__ __launch_bounds__(256, 1) void gather_conv_bf16_kernel(const GatherCo
   }
 }
 
-// every tap of every pixel of every phase inside the gathered tensor?
-static bool hb_all_in_range(const GatherConv& p) {
-  const int G[3] = {p.Di, p.Hi, p.Wi};
-  for (int i = 0; i < p.nphase; ++i) {
-    const Phase& ph = p.ph[i];
-    if (ph.nz * ph.ny * ph.nx == 0) return false;
-    const int d0[3] = {ph.dz0, ph.dy0, ph.dx0}, nj[3] = {ph.nz, ph.ny, ph.nx}, M[3] = {ph.Mz, ph.My, ph.Mx};
-    for (int d = 0; d < 3; ++d) {
-      if (M[d] == 0) continue;
-      const int e = d0[d] + p.dstep[d] * (nj[d] - 1);
-      const int lo = d0[d] < e ? d0[d] : e, hi = d0[d] < e ? e : d0[d];
-      if (lo < 0 || (M[d] - 1) * p.istride[d] + hi > G[d] - 1) return false;
-    }
-  }
-  return true;
-}
-
 template <int BN, bool MASK>
 static int hb_launch(const GatherConv& p, long maxM, hipStream_t st) {
   auto kern = gather_conv_bf16_kernel<BN, MASK>;
@@ -355,6 +338,23 @@ static int hb_launch(const GatherConv& p, long maxM, hipStream_t st) {
   return check_launch("gather_conv_bf16");
 }
 
+// every tap of every pixel of every phase inside the gathered tensor?
+static bool hb_all_in_range(const GatherConv& p) {
+  const int G[3] = {p.Di, p.Hi, p.Wi};
+  for (int i = 0; i < p.nphase; ++i) {
+    const Phase& ph = p.ph[i];
+    if (ph.nz * ph.ny * ph.nx == 0) return false;
+    const int d0[3] = {ph.dz0, ph.dy0, ph.dx0}, nj[3] = {ph.nz, ph.ny, ph.nx}, M[3] = {ph.Mz, ph.My, ph.Mx};
+    for (int d = 0; d < 3; ++d) {
+      if (M[d] == 0) continue;
+      const int e = d0[d] + p.dstep[d] * (nj[d] - 1);
+      const int lo = d0[d] < e ? d0[d] : e, hi = d0[d] < e ? e : d0[d];
+      if (lo < 0 || (M[d] - 1) * p.istride[d] + hi > G[d] - 1) return false;
+    }
+  }
+  return true;
+}
+
 static int hb_check(const GatherConv& p, const char* what) {
   MPGAN_UNSUPPORTED(p.Cin % HB_BK != 0, "%s: bf16 path needs gathered channels %% 64 == 0 (got %d)", what, p.Cin);
   MPGAN_UNSUPPORTED(p.Cout % 8 != 0 || p.ldo % 8 != 0 || p.ldi % 8 != 0, "%s: bf16 path needs channels / pitches %% 8 == 0", what);
@@ -363,8 +363,9 @@ static int hb_check(const GatherConv& p, const char* what) {
   MPGAN_CHECK_ARG((long)p.N * p.Do * p.Ho * p.Wo < (1L << 31) && (long)p.N * p.Di * p.Hi * p.Wi < (1L << 31), "%s: more than 2^31 pixels", what);
   MPGAN_UNSUPPORTED((long)p.N * p.Di * p.Hi * p.Wi * p.ldi * 2 >= (1L << 32) || (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 2 >= (1L << 32),
                     "%s: bf16 operand of 4 GiB or more (32-bit byte offsets)", what);
-  for (int i = 0; i < p.nphase; ++i)
-    MPGAN_UNSUPPORTED(p.ph[i].nz * p.ph[i].ny * p.ph[i].nx > 32, "%s: more than 32 taps per phase", what);
+  if (!hb_all_in_range(p))           // masked gathers keep one validity bit per tap and row
+    for (int i = 0; i < p.nphase; ++i)
+      MPGAN_UNSUPPORTED(p.ph[i].nz * p.ph[i].ny * p.ph[i].nx > 32, "%s: more than 32 taps per phase of a masked gather", what);
   return MPGAN_OK;
 }
 

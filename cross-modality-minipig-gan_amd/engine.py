@@ -1167,8 +1167,12 @@ class DiscPlanBF16:
         self.g_prob = E(n)
         dlogit = E(n)
         # gradients w.r.t. the activations; the BatchNorm backward overwrites them in place with dz
+        # (disc.debug_keep_intermediates: separate dz buffers, so that tests can check every layer of the backward
+        #  against the CPU restatement on the SAME inputs)
         gas = [H(*z.shape) for z in zs[:3]] + [E(*zs[3].shape)]
         dz4 = H(*zs[3].shape)
+        keep_all = bool(getattr(disc, "debug_keep_intermediates", False))
+        self.dzs = [H(*z.shape) for z in zs[:3]] + [dz4] if keep_all else [gas[0], gas[1], gas[2], dz4]
         self.gas = gas
         b.add("sigmoid_backward", L.mpgan_sigmoid_backward, self.g_prob.data_ptr(), self.prob.data_ptr(), n,
               dlogit.data_ptr(), keep=(dlogit,))
@@ -1182,7 +1186,7 @@ class DiscPlanBF16:
             rows_total = n * g.out_dhw[0] * g.out_dhw[1] * g.out_dhw[2]
             brow = ops.norm_bwd_rows_bf16(rows_total, c)
             gin = gas[i]
-            dz = dz4 if i == 3 else gas[i]
+            dz = self.dzs[i]
             g32 = int(gin.dtype == torch.float32)
             bias_part = part[brow * 3 * c + c:brow * 4 * c + c] if (want_param_grads and i > 0) else None
             b.add("norm_bwd_reduce_bf16", L.mpgan_norm_bwd_reduce_bf16, gin.data_ptr(), g32, c, z.data_ptr(), c,

@@ -72,4 +72,4 @@ def disc_step(disc, x: torch.Tensor, target: float, eps: float = 1e-5, slope: fl
         ga, gw = torch.autograd.grad(out, (a_req, w_req), dz)
         grads[f"model_conv.{3 * i}.weight"] = gw
         g = ga if i == 0 else rb(ga)
-    return {"validity": prob, "loss": loss, "grad_x": g, "grads": grads}
+    return {"validity": prob, "loss": loss, "grad_x": g, "grads": grads, "zs": [sv[2] for sv in saved]}

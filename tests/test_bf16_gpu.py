@@ -217,15 +217,24 @@ def _run_ours_bf16(shape, dims, rd, x, target=0.9):
     return d, v.detach().cpu(), loss.item(), xg.grad.cpu()
 
 
-@pytest.mark.parametrize("dims,size,n", [(2, 40, 3), (3, 24, 2), (2, 96, 2)], ids=["2d", "3d", "2d-96"])
+@pytest.mark.parametrize("dims,size,n", [(2, 40, 3), (3, 24, 2), (2, 96, 2), (3, 48, 1)], ids=["2d", "3d", "2d-96", "3d-48"])
 def test_discriminator_bf16_storage_matches_its_cpu_restatement(dims, size, n):
     """Whole discriminator in bf16-storage mode, forward + backward, against oracle/bf16_emul.py: the CPU
     restatement of the SAME storage contract (fp32 arithmetic, a bf16 rounding exactly where the HIP path stores
-    a tensor).  What is left between the two is fp32 accumulation order, which moves a stored value by one bf16
-    ulp when it sits on a rounding boundary: validity to 2e-3, every gradient tensor to 2e-2 relative L2.
-    The distance of that contract to the pure-fp32 oracle is printed (the precision cost of bf16 storage: on
-    maps this small BatchNorm's backward cancels heavily and the early layers' gradients move by tens of per
-    cent, which is why the fp32 oracle cannot be the checker here)."""
+    a tensor).
+
+    What two correct implementations of that contract can agree on: a rounding to bf16 turns an fp32-level
+    difference d between them (accumulation order) into a one-ulp flip in a fraction d/ulp of the stored
+    elements, i.e. sqrt(d*ulp) in L2 -- after three layers the two sides' activations differ at the bf16 noise
+    level itself (measured: perturbing the restatement's conv outputs by 1e-7 moves its own gradients by
+    2-10 %), and BatchNorm's backward, which subtracts the two dominant components of the head's gradient,
+    amplifies that by ~30x on these closed-form weights.  So:
+      * forward: validity and loss to 2e-3, every stored raw conv output z_i to 5e-3 relative L2;
+      * the head's and the last BatchNorm weight's gradients (no cancellation yet) to 1e-2;
+      * every other gradient tensor only as a sanity bound: no further from the restatement than the
+        restatement's own distance to the pure-fp32 oracle (printed as the precision cost of bf16 storage).
+    The well-conditioned check of the backward pass is the layer-by-layer test below (same inputs on both
+    sides); the kernels themselves are pinned bit-exactly by the integer tests above."""
     from oracle import bf16_emul as E
     from oracle import refmodel as R
     shape = (1,) + (size,) * dims
@@ -238,28 +247,93 @@ def test_discriminator_bf16_storage_matches_its_cpu_restatement(dims, size, n):
     d, v, loss, gx = _run_ours_bf16(shape, dims, rd, x)
     np.testing.assert_allclose(v.numpy(), ref["validity"].numpy(), atol=2e-3)
     np.testing.assert_allclose(loss, ref["loss"].item(), rtol=2e-3)
-    errs = {}
-    for name, p in d.named_parameters():
-        if name in PRE_BN_BIAS:
-            continue          # pre-BatchNorm biases: true gradient zero, both sides hold rounding noise
-        errs[name] = _rel(p.grad.cpu(), ref["grads"][name])
-    errs["input"] = _rel(gx, ref["grad_x"])
+    plan = [pl for pool in d._plans.values() for pl in pool][0]
+    for i, z in enumerate(plan.zs):
+        assert _rel(from_cl(z.float(), dims), ref["zs"][i]) <= 5e-3, (i, _rel(from_cl(z.float(), dims), ref["zs"][i]))
     xr = x.clone().requires_grad_(True)
     F.binary_cross_entropy(rd(xr), torch.full((n, 1), 0.9)).backward()
-    cost = {name: round(_rel(ref["grads"][name], p.grad), 4) for name, p in rd.named_parameters() if name not in PRE_BN_BIAS}
+    errs, cost = {}, {}
+    for name, p in rd.named_parameters():
+        if name in PRE_BN_BIAS:
+            continue          # pre-BatchNorm biases: true gradient zero, both sides hold rounding noise
+        errs[name] = _rel(dict(d.named_parameters())[name].grad.cpu(), ref["grads"][name])
+        cost[name] = _rel(ref["grads"][name], p.grad)
+    errs["input"], cost["input"] = _rel(gx, ref["grad_x"]), _rel(ref["grad_x"], xr.grad)
     print("ours vs bf16 restatement:", {k: round(e, 5) for k, e in errs.items()})
-    print("bf16 restatement vs fp32 oracle (precision cost):", cost)
+    print("bf16 restatement vs fp32 oracle (precision cost):", {k: round(e, 4) for k, e in cost.items()})
     for name, e in errs.items():
-        assert e <= 2e-2, (name, e)
+        tight = name.startswith("model_linear") or name == "model_conv.10.weight"
+        assert e <= (1e-2 if tight else cost[name] + 2e-2), (name, e, cost[name])
 
 
-def test_discriminator_128cubed_bf16_at_the_reference_shape(golden_dir):
-    """Config C5's discriminator at the reference's true shape (1,1,128,128,128), bf16-storage mode:
-      * against the CPU restatement of the storage contract (about half a minute of host time): validity,
-        loss, every gradient tensor by relative L2;
-      * against the fixture produced by the REFERENCE's own fp32 Discriminator: validity / loss to 2e-2 and
-        the input gradient's |.|-sum to 5e-2 (what bf16 storage costs at this size)."""
+@pytest.mark.parametrize("dims,size,n", [(2, 64, 3), (3, 40, 2)], ids=["2d", "3d"])
+def test_discriminator_bf16_backward_layer_by_layer(dims, size, n):
+    """The backward pass of the bf16 discriminator checked ONE LAYER AT A TIME on the tensors the HIP path itself
+    stored (teacher forcing): for every layer the CPU restatement's formulas are applied to the GPU's own inputs
+    of that layer -- incoming activation gradient, stored z, statistics, stored input activation, packed
+    weights -- and compared with what the GPU produced.  No chaos can build up across layers here, so every
+    kernel's output is held at its own rounding level: bf16 tensors to 4e-3*|ref| + 1e-3*max|ref| elementwise
+    (one rounding to bf16 of a value whose fp32 accumulation order differs), fp32 reductions to 2e-3 relative
+    L2."""
     from oracle import bf16_emul as E
+    from oracle import refmodel as R
+    from mpgan_amd.gan import adversarial_loss
+    from mpgan_amd.networks import Discriminator
+    shape = (1,) + (size,) * dims
+    rd = R.Discriminator(shape, dimensions=dims)
+    R.closed_form_fill_(rd)
+    d = Discriminator(shape, dimensions=dims, storage_dtype="bf16")
+    d.load_state_dict(rd.state_dict())
+    d.cuda().train()
+    d.debug_keep_intermediates = True
+    gen = torch.Generator().manual_seed(6)
+    x = (torch.rand(n, *shape, generator=gen) * 2 - 1).cuda().requires_grad_(True)
+    v = d(x)
+    adversarial_loss(v, torch.full_like(v, 0.9)).backward()
+    plan = [pl for pool in d._plans.values() for pl in pool][0]
+    conv = F.conv2d if dims == 2 else F.conv3d
+    convs = [rd.model_conv[i] for i in (0, 3, 6, 9)]
+    red = [0] + list(range(2, 2 + dims))
+    shp = [1, -1] + [1] * dims
+    grads = {k: p.grad.cpu() for k, p in d.named_parameters()}
+
+    def close_bf16(got, ref, what):
+        e = (got - ref).abs()
+        assert (e <= 4e-3 * ref.abs() + 1e-3 * ref.abs().max()).all(), (what, e.max().item(), ref.abs().max().item())
+
+    for i in range(3, -1, -1):
+        nb, cv = plan.nbs[i], convs[i]
+        z = from_cl(plan.zs[i].float(), dims)
+        g_in = from_cl(plan.gas[i].float(), dims)
+        scale, shift, mean, invstd = (t.cpu() for t in (nb.scale, nb.shift, nb.mean, nb.invstd))
+        y = z * scale.view(shp) + shift.view(shp)
+        gy = torch.where(y < 0, g_in * 0.2, g_in)
+        zh = (z - mean.view(shp)) * invstd.view(shp)
+        cnt = z.numel() / z.shape[1]
+        s1, s2 = gy.sum(red), (gy * zh).sum(red)
+        dz_ref = E.rb(scale.view(shp) * (gy - (s1 / cnt).view(shp) - zh * (s2 / cnt).view(shp)))
+        dz = from_cl(plan.dzs[i].float(), dims)
+        close_bf16(dz, dz_ref, f"dz{i}")
+        # fp32 sums with cancellation: allowed error = 2e-3 of the result + 1e-5 of the summed magnitudes
+        for pname, got, ref, mag in ((f"model_conv.{3 * i + 1}.weight", grads[f"model_conv.{3 * i + 1}.weight"], s2, (gy * zh).abs().sum(red)),
+                                     (f"model_conv.{3 * i + 1}.bias", grads[f"model_conv.{3 * i + 1}.bias"], s1, gy.abs().sum(red))):
+            assert (got - ref).norm().item() <= 2e-3 * ref.norm().item() + 1e-5 * mag.norm().item(), (pname, (got - ref).norm().item(), ref.norm().item())
+        a_in = x.detach().cpu() if i == 0 else from_cl(plan.acts[i - 1].float(), dims)
+        w = cv.weight.detach() if i == 0 else E.rb(cv.weight.detach())
+        a_req, w_req = a_in.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ga_ref, gw_ref = torch.autograd.grad(conv(a_req, w_req, None, stride=cv.stride), (a_req, w_req), dz)
+        assert _rel(grads[f"model_conv.{3 * i}.weight"], gw_ref) <= 2e-3, (i, "dW", _rel(grads[f"model_conv.{3 * i}.weight"], gw_ref))
+        if i > 0:
+            close_bf16(from_cl(plan.gas[i - 1].float(), dims), E.rb(ga_ref), f"ga{i - 1}")
+        else:
+            assert _rel(x.grad.cpu(), ga_ref) <= 2e-3, ("dx", _rel(x.grad.cpu(), ga_ref))
+
+
+def test_discriminator_128cubed_bf16_against_the_reference_fixture(golden_dir):
+    """Config C5's discriminator at the reference's true shape (1,1,128,128,128), bf16-storage mode, against the
+    fixture produced by the REFERENCE's own fp32 Discriminator: validity / loss to 2e-2, the input gradient's
+    and the head's |.|-sums to 5e-2, the other gradient summaries to 0.25 (the precision cost of bf16 storage at
+    this size; see the test above for why the gradient of this network is that sensitive)."""
     from oracle import refmodel as R
     from oracle.make_golden import summarize
     fx = np.load(os.path.join(golden_dir, "disc_variant_a_128.npz"))
@@ -271,11 +345,11 @@ def test_discriminator_128cubed_bf16_at_the_reference_shape(golden_dir):
     np.testing.assert_allclose(v.numpy(), fx["validity"], atol=2e-2)
     np.testing.assert_allclose(loss, float(fx["loss"]), rtol=2e-2)
     np.testing.assert_allclose(summarize(gx)[1], fx["grad_x"][1], rtol=5e-2)
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
-    ref = E.disc_step(shell, x, 0.9)
-    np.testing.assert_allclose(v.numpy(), ref["validity"].numpy(), atol=2e-3)
-    errs = {name: _rel(p.grad.cpu(), ref["grads"][name]) for name, p in d.named_parameters() if name not in PRE_BN_BIAS}
-    errs["input"] = _rel(gx, ref["grad_x"])
-    print("128^3 ours vs bf16 restatement:", {k: round(e, 5) for k, e in errs.items()})
-    for name, e in errs.items():
-        assert e <= 2e-2, (name, e)
+    dev = {}
+    for name, p in d.named_parameters():
+        if name in PRE_BN_BIAS:
+            continue
+        got, want = summarize(p.grad.cpu())[1], fx["grad__" + name][1]
+        dev[name] = abs(got - want) / abs(want)
+        assert dev[name] <= (5e-2 if name.startswith("model_linear") else 0.25), (name, got, want)
+    print("128^3 |grad|-sum deviation from the reference's fp32 fixture:", {k: round(e, 4) for k, e in dev.items()})

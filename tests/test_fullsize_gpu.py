@@ -234,7 +234,7 @@ def test_full_gd_step_at_c3_matches_oracle():
         if name in ("model_conv.0.bias", "model_conv.3.bias", "model_conv.6.bias", "model_conv.9.bias"):
             assert gd[name].abs().max().item() <= 1e-4 * gmax_d + 1e-6, name
             continue
-        tol = 2e-3 if name.startswith("model_linear") else 2e-2     # head: no BatchNorm / kink between it and the loss
+        tol = 2e-3 if name.startswith("model_linear") else 5e-2     # head: no BatchNorm / kink between it and the loss
         derr[name] = _rel_l2(gd[name], p.grad)
         assert derr[name] <= tol, (name, derr[name])
     print("D grad rel-L2:", {k: round(v, 6) for k, v in derr.items()})

@@ -272,9 +272,9 @@ def test_discriminator_bf16_backward_layer_by_layer(dims, size, n):
     stored (teacher forcing): for every layer the CPU restatement's formulas are applied to the GPU's own inputs
     of that layer -- incoming activation gradient, stored z, statistics, stored input activation, packed
     weights -- and compared with what the GPU produced.  No chaos can build up across layers here, so every
-    kernel's output is held at its own rounding level: bf16 tensors to 4e-3*|ref| + 1e-3*max|ref| elementwise
-    (one rounding to bf16 of a value whose fp32 accumulation order differs), fp32 reductions to 2e-3 relative
-    L2."""
+    kernel's output is held at its own rounding level: bf16 tensors to 8e-3*|ref| + 1e-3*max|ref| elementwise
+    (ONE bf16 ulp, 2^-7 relative at worst: a value whose fp32 accumulation order differs can land on either side
+    of a rounding boundary), fp32 reductions to 2e-3 relative L2."""
     from oracle import bf16_emul as E
     from oracle import refmodel as R
     from mpgan_amd.gan import adversarial_loss
@@ -299,7 +299,7 @@ def test_discriminator_bf16_backward_layer_by_layer(dims, size, n):
 
     def close_bf16(got, ref, what):
         e = (got - ref).abs()
-        assert (e <= 4e-3 * ref.abs() + 1e-3 * ref.abs().max()).all(), (what, e.max().item(), ref.abs().max().item())
+        assert (e <= 8e-3 * ref.abs() + 1e-3 * ref.abs().max()).all(), (what, e.max().item(), ref.abs().max().item())
 
     for i in range(3, -1, -1):
         nb, cv = plan.nbs[i], convs[i]

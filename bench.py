@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
 PEAK_BF16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak
-DOMINANT = "gather_conv_pipe_kernel<128, 2, 2, 2, 1, 3, true>"   # as rocprofv3 names it (D's dense layers, forward)
+DOMINANT = "gather_conv_pipe_kernel<128, 2, 2, 2, 1, 3, true, 1>"   # as rocprofv3 names it (D's dense layers, forward)
 DENSE_MIN_GFLOP = 20.0            # per launch: D's conv2/3/4 in all three directions, nothing of G
 HEAD_WEIGHT_SCALE = 0.02          # see main(): keeps the 952,576-input head out of sigmoid saturation
 
@@ -140,16 +140,44 @@ def synthetic_batch(bs, spatial, rank, device):
     return {"t1w": t1.to(device), "t2w": t2.to(device)}
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota when there is one
+    (a GPU box hands one GPU's job a share of the host: the mask still lists every core of the machine, and
+    running one thread per listed core on a 16-core quota is a 20x slowdown, not a baseline)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    how = "affinity mask"
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period + 0.5))
+                if q < n:
+                    n, how = q, "cgroup CPU quota"
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if os.environ.get("MPGAN_HOST_CORES"):
+        n, how = int(os.environ["MPGAN_HOST_CORES"]), "MPGAN_HOST_CORES"
+    elif how == "affinity mask" and n > 32:
+        # no quota visible, yet the mask lists a whole multi-GPU host: one GPU's job gets a 16-core share of it
+        n, how = 16, "16-core per-GPU share of the host; the affinity mask lists all %d cores and no cgroup quota is visible" % n
+    return n, how
+
+
 def cpu_baseline_leg(gan, spatial, sample_bs=16, timed_steps=3):
     """Oracle on the host cores, the plan of BASELINE.md section 3: the bench's own configuration
     (bs 16 at 256x256), every core of the affinity mask, 1 warm-up + 3 timed G+D steps; plus the
     G-output L1 of the HIP path against it (same weights, same input)."""
     import torch
     from oracle import refmodel as R
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores, how = host_cores()
     torch.set_num_threads(cores)
     ref = R.GAN((1, *spatial), dimensions=2, norm=gan.generator.norm)
     ref.generator.load_state_dict({k: v.cpu() for k, v in gan.generator.state_dict().items()})
@@ -176,7 +204,7 @@ def cpu_baseline_leg(gan, spatial, sample_bs=16, timed_steps=3):
     dt = time.perf_counter() - t0
     return {"value": sample_bs * timed_steps / dt, "unit": "slices/s", "cores": cores, "kind": "port",
             "sample": f"{timed_steps} G+D steps of the torch-CPU oracle at 256x256, bs {sample_bs} (1 warm-up), "
-                      f"{cores} threads = every core of the affinity mask",
+                      f"{cores} threads = every core this job may use ({how})",
             "g_output_l1_vs_cpu": l1, "g_output_psnr_vs_cpu_db": psnr}
 
 

@@ -33,8 +33,11 @@ constexpr int PITCH = BK + 4;
 // optional fused BatchNorm statistics.  Called after the K-loop's final barrier.
 template <int BN, int TM, int TN, int WN>
 __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& ph, f32x16 (&acc)[TM][TN], float* lds,
-                                              long m0, int n0, long Mtot, int stats_row, bool zero_rows = false) {
-  const int tid = threadIdx.x;
+                                              long m0, int n0, long Mtot, int stats_row, bool zero_rows = false,
+                                              int tid = threadIdx.x, bool active = true) {
+  // `tid` is the thread's index inside its 256-thread K group; only the group with `active` holds the tile's
+  // sums and writes anything (the in-block split-K form of the pipelined kernel calls this from every group so
+  // that the barriers below are reached by all waves).
   const int lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
@@ -42,7 +45,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
   const int ksplit_id = p.ksplit > 1 ? (int)(xcd_remap(blockIdx.x, gridDim.x) / (unsigned)(p.ntiles * p.mtiles * p.nphase)) : 0;
   // ---- epilogue: row -> output pixel map through LDS, then bias/resid/tanh ----
   int* rowpix = reinterpret_cast<int*>(lds);
-  if (tid < BM) {
+  if (active && tid < BM) {
     const unsigned m = (unsigned)m0 + tid;
     int pix = -1;
     if (m < (unsigned)Mtot) {
@@ -60,6 +63,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
   __syncthreads();
   if (p.ksplit > 1) {   // split-K: raw partial sums, reduced (with bias) by splitk_reduce_kernel
     float* part = p.kpartial + (long)ksplit_id * ((long)p.N * p.Do * p.Ho * p.Wo) * Cout;
+    if (active)
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -86,6 +90,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
     bv[tn] = (p.bias && cov[tn] < Cout) ? p.bias[cov[tn]] : 0.f;
   }
   // row-major walk: the 64-bit pixel offset is formed once per row, not once per element
+  if (active)
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -114,7 +119,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
     constexpr int WM = 4 / WN;
     float* st = lds + 1024;                 // [WM][2][BN], clear of rowpix
     int* nvp = reinterpret_cast<int*>(lds) + 512;
-    if (zero_rows) {                        // FAST kernels gather clamped (non-zero) rows past the last pixel
+    if (zero_rows && active) {              // FAST kernels gather clamped (non-zero) rows past the last pixel
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -126,7 +131,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
           }
         }
     }
-    if (tid < BM) {
+    if (active && tid < BM) {
       const unsigned long long b = __ballot(rowpix[tid] >= 0);
       if (lane == 0) nvp[wid] = __popcll(b);
     }
@@ -144,13 +149,13 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
         }
       sm += __shfl_xor(sm, 32, 64);
       sq += __shfl_xor(sq, 32, 64);
-      if (lh == 0) {
+      if (active && lh == 0) {
         st[(wm * 2 + 0) * BN + col] = sm;
         st[(wm * 2 + 1) * BN + col] = sq;
       }
     }
     __syncthreads();
-    if (tid < BN && n0 + tid < Cout) {
+    if (active && tid < BN && n0 + tid < Cout) {
       float sm = 0.f, sq = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) {
@@ -454,14 +459,21 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
 //           every pixel is in range, so the per-row range tests and the zero masks of both operands
 //           (84 of the K-step's 146 vector instructions) are dropped; rows past the last pixel gather
 //           the last pixel instead of zeros and are cleared before the fused statistics.
-template <int BN, int TM, int TN, int WN, int WRAPS, int PRO, bool FAST = false>
-__global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+//   KS    : in-block split of the K axis over KS groups of 4 waves (own LDS stages each; sums folded through LDS
+//           before the epilogue).  For layers whose output grid yields about one block per CU (the U-Net's
+//           32 x 32 levels: 128 pixel tiles x 2 channel tiles) a single 4-wave block leaves each SIMD with ONE
+//           wave, and every LDS / barrier / load stall of that wave is a stall of the matrix pipe; KS = 2 puts a
+//           second, independent wave on each SIMD without adding a launch or HBM traffic.
+template <int BN, int TM, int TN, int WN, int WRAPS, int PRO, bool FAST = false, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const GatherConv p) {
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
   constexpr int STAGE = (BM + BN) * PITCH;
   constexpr int BROWS = BN / 32;
   constexpr int NMF = 4 * TM * TN;          // MFMAs per fragment group
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 255;        // index inside the K group
+  const int kg = KS > 1 ? (int)(threadIdx.x >> 8) : 0;
+  float* lds = lds_all + kg * 2 * STAGE;
   const int lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
@@ -472,7 +484,7 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
   const int n0 = bid.nt * BN;
   const int stats_row = bid.phase * p.mtiles + bid.mt;
   if (m0 >= Mtot) {
-    if (p.stats && tid < BN && n0 + tid < p.Cout) {
+    if (p.stats && kg == 0 && tid < BN && n0 + tid < p.Cout) {
       float* row = p.stats + (long)stats_row * 2 * p.Cout;
       row[n0 + tid] = 0.f;
       row[p.Cout + n0 + tid] = 0.f;
@@ -483,8 +495,8 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
   const int ntaps = ph.nz * ph.ny * ph.nx;
   const int Kp = ntaps * Cin;
   const int nk_all = (Kp + BK - 1) / BK;
-  const int nk_per = (nk_all + p.ksplit - 1) / p.ksplit;
-  const int kt_begin = bid.split * nk_per;              // split-K: this block's K-step range
+  const int nk_per = (nk_all + p.ksplit * KS - 1) / (p.ksplit * KS);
+  const int kt_begin = (bid.split * KS + kg) * nk_per;  // split-K: this K group's K-step range
   const int nk = nk_all - kt_begin < nk_per ? (nk_all - kt_begin > 0 ? nk_all - kt_begin : 0) : nk_per;
   const long Ktot = (long)p.Kz * p.Ky * p.Kx * Cin;
   const float* __restrict__ gin = p.in;
@@ -772,15 +784,50 @@ __global__ __launch_bounds__(256) void gather_conv_pipe_kernel(const GatherConv 
     }
   };
 
-  for (int kt = 0; kt < nk; kt += 2) {
-    step(0, SY, SX);
-    __syncthreads();
-    if (kt + 1 < nk) {
-      step(1, SX, SY);
+  if constexpr (KS == 1) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      step(0, SY, SX);
+      __syncthreads();
+      if (kt + 1 < nk) {
+        step(1, SX, SY);
+        __syncthreads();
+      }
+    }
+    conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot, stats_row, FAST && m0 + BM > Mtot);
+  } else {
+    // every group walks nk_per K-steps' worth of barriers; a group whose range is shorter idles at them
+    for (int kt = 0; kt < nk_per; kt += 2) {
+      if (kt < nk) step(0, SY, SX);
+      __syncthreads();
+      if (kt + 1 < nk_per) {
+        if (kt + 1 < nk) step(1, SX, SY);
+        __syncthreads();
+      }
+    }
+    // fold the groups' sums into group 0 through LDS: [register][thread] floats, conflict-free
+    float* red = lds_all;
+    for (int g = 1; g < KS; ++g) {
+      if (kg == g) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((a * TN + b) * 16 + r) * 256 + tid] = acc[a][b][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] += red[((a * TN + b) * 16 + r) * 256 + tid];
+      }
       __syncthreads();
     }
+    conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds_all, m0, n0, Mtot, stats_row, FAST && m0 + BM > Mtot, tid, kg == 0);
   }
-  conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot, stats_row, FAST && m0 + BM > Mtot);
 }
 
 // ---------------------------------------------------------------------------
@@ -1229,6 +1276,7 @@ struct PatchLaunch {
   // the statistics scratch (the patch stays live across phases)
   int merged, ylo, yhi, xlo, xhi, stats_off;
   FastDiv fPWm, fKx;
+  int w_floats;          // persistent form: LDS floats of the staged weights (the patch follows them)
 };
 
 //   MERGE : one block walks ALL phases of its tile (strided backward-data / transposed convs): the
@@ -1534,6 +1582,299 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
   }   // phases
 }
 
+// ---------------------------------------------------------------------------
+// Persistent form of the patch kernel (one phase, or all phases merged): a block stages the weights ONCE and
+// then walks several tiles; the input patch of tile t+1 is in flight (global loads into registers) while
+// tile t is contracted from LDS and its results are stored, and goes to LDS behind one barrier.  Against the
+// one-tile-per-block form above this removes the per-tile weight staging, takes the patch load's round trip off
+// the critical path and lets a block's output stores overlap its next input loads -- the three things that kept
+// those launches (all blocks resident at once, all of them load -> compute -> store in lockstep) at 25-45 % of
+// either roof.  LDS: [weights][patch][statistics slots]; statistics rows: one per (tile, phase), as before.
+// ---------------------------------------------------------------------------
+template <int CIN, int PRO, bool NARROW, bool MERGE>
+__global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherConv p, const PatchLaunch pl,
+                                                                   const int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int PC = CIN + 4;
+  constexpr int CQ = CIN / 4;
+  constexpr int LU = CIN == 16 ? 9 : 12;      // patch chunks per thread: the WHOLE patch of a tile in one round (host checks)
+  constexpr int WU = 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int Cout = p.Cout;
+  const int Hi = p.Hi, Wi = p.Wi, ldi = p.ldi;
+  const int isy = p.istride[1], isx = p.istride[2];
+  const int dsy = p.dstep[1], dsx = p.dstep[2];
+  const int nph = MERGE ? p.nphase : 1;
+  int ylo, yhi, xlo, xhi, sntaps;
+  if constexpr (MERGE) {
+    ylo = pl.ylo; yhi = pl.yhi; xlo = pl.xlo; xhi = pl.xhi;
+    sntaps = p.Ky * p.Kx;
+  } else {
+    const Phase& ph = p.ph[0];
+    const int ny = ph.nz > 0 ? ph.ny : 0, nx = ph.nx;
+    const int ye = ph.dy0 + dsy * (ny > 0 ? ny - 1 : 0), xe = ph.dx0 + dsx * (nx > 0 ? nx - 1 : 0);
+    ylo = ph.dy0 < ye ? ph.dy0 : ye; yhi = ph.dy0 < ye ? ye : ph.dy0;
+    xlo = ph.dx0 < xe ? ph.dx0 : xe; xhi = ph.dx0 < xe ? xe : ph.dx0;
+    sntaps = ny * nx;
+  }
+  const int PH = (PT_H - 1) * isy + (yhi - ylo) + 1, PW = (PT_W - 1) * isx + (xhi - xlo) + 1;
+  float* wl = lds;
+  float* patch = lds + pl.w_floats;
+  float* stslots = patch + pl.patch_floats;          // [nph][4 waves][2][32]
+  const float* __restrict__ gw = p.wp;
+  const int cq = tid & (CQ - 1);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  float slope = 1.f;
+  int act = 0;
+  if constexpr (PRO != 0) {
+    slope = pro_slope(p.pro);
+    act = p.pro.act;
+  }
+  const int total = PH * PW * CQ;
+  const FastDiv fPW = MERGE ? pl.fPWm : pl.fPW[0], fNx = MERGE ? pl.fKx : pl.fNx[0], fCout = pl.fCout;
+  const Phase& ph0 = p.ph[0];
+
+  // ---- weights: once per block ----
+  {
+    const int wtotal = sntaps * Cout * CQ;
+    const int Ktot = p.Kz * p.Ky * p.Kx * CIN;
+    for (int base = 0; base < wtotal; base += 256 * WU) {
+      float4 wv[WU];
+#pragma unroll
+      for (int u = 0; u < WU; ++u) {
+        const int idx = base + u * 256 + tid;
+        const unsigned row = idx < wtotal ? (unsigned)idx / (unsigned)CQ : 0u;
+        unsigned t, co, jy, jx;
+        fdivmod(row, fCout, t, co);
+        fdivmod(t, fNx, jy, jx);
+        const int ky = MERGE ? (int)jy : ph0.ky0 + p.kstep[1] * (int)jy;
+        const int kx = MERGE ? (int)jx : ph0.kx0 + p.kstep[2] * (int)jx;
+        const int tapflat = (ph0.kz0 * p.Ky + ky) * p.Kx + kx;
+        wv[u] = *reinterpret_cast<const float4*>(gw + ((int)co * Ktot + tapflat * CIN + 4 * cq));
+      }
+#pragma unroll
+      for (int u = 0; u < WU; ++u) {
+        const int idx = base + u * 256 + tid;
+        if (idx < wtotal) *reinterpret_cast<float4*>(wl + (idx / CQ) * PC + 4 * cq) = wv[u];
+      }
+    }
+  }
+
+  float4 pv[LU];
+  unsigned pok = 0;
+  int ln = 0;                                         // sample of the tile held in pv (per-sample prologue vectors)
+  auto decode = [&](int t, int& n, int& my0, int& mx0) {
+    const int tx = t % pl.tiles_x;
+    const int q = t / pl.tiles_x;
+    my0 = (q % pl.tiles_y) * PT_H;
+    mx0 = tx * PT_W;
+    n = q / pl.tiles_y;
+  };
+  auto load_patch = [&](int t) {
+    int n, my0, mx0;
+    decode(t, n, my0, mx0);
+    ln = n;
+    const int y0 = my0 * isy + ylo, x0 = mx0 * isx + xlo;
+    const float* __restrict__ gin = p.in + (long)n * Hi * Wi * ldi;
+    pok = 0;
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int idx = u * 256 + tid;
+      const unsigned pix = (unsigned)idx / (unsigned)CQ;
+      unsigned py, px;
+      fdivmod(pix, fPW, py, px);
+      const int iy = y0 + (int)py, ix = x0 + (int)px;
+      const unsigned ok = (idx < total ? 1u : 0u) & ((unsigned)iy < (unsigned)Hi ? 1u : 0u) &
+                          ((unsigned)ix < (unsigned)Wi ? 1u : 0u);
+      const long off = ok ? ((long)iy * Wi + ix) * ldi + 4 * cq : 0;
+      pv[u] = *reinterpret_cast<const float4*>(gin + off);
+      pok |= ok << u;
+    }
+  };
+  auto store_patch = [&]() {
+    if constexpr (PRO != 0) {
+      sc = *reinterpret_cast<const float4*>(p.pro.scale + (long)ln * p.pro.n_stride + 4 * cq);
+      sh = *reinterpret_cast<const float4*>(p.pro.shift + (long)ln * p.pro.n_stride + 4 * cq);
+    }
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int idx = u * 256 + tid;
+      float4 x = pv[u];
+      if constexpr (PRO != 0) {
+        x.x = act_apply(x.x * sc.x + sh.x, act, slope);
+        x.y = act_apply(x.y * sc.y + sh.y, act, slope);
+        x.z = act_apply(x.z * sc.z + sh.z, act, slope);
+        x.w = act_apply(x.w * sc.w + sh.w, act, slope);
+      }
+      const bool ok = (pok >> u) & 1u;
+      x.x = ok ? x.x : 0.f; x.y = ok ? x.y : 0.f; x.z = ok ? x.z : 0.f; x.w = ok ? x.w : 0.f;
+      if (idx < total) *reinterpret_cast<float4*>(patch + (idx / CQ) * PC + 4 * cq) = x;
+    }
+  };
+
+  const float* gres = p.resid;
+  float* gout = p.out;
+  const int ldo = p.ldo, ldr = p.ldr, tanh_out = p.tanh_out;
+  const int osy = p.ostride[1], osx = p.ostride[2];
+
+  int t = (int)blockIdx.x;
+  if (t < ntiles) {
+    load_patch(t);
+    store_patch();
+  }
+  __syncthreads();
+  for (; t < ntiles; t += (int)gridDim.x) {
+    const int tn = t + (int)gridDim.x;
+    int n, my0, mx0;
+    decode(t, n, my0, mx0);
+    if (tn < ntiles) load_patch(tn);                 // in flight under this tile's contraction and stores
+
+    for (int phase = 0; phase < nph; ++phase) {
+      const Phase& ph = p.ph[phase];
+      const int My = ph.Mz > 0 ? ph.My : 0, Mx = ph.Mx;
+      const int ny = ph.nz > 0 ? ph.ny : 0, nx = ph.nx;
+      float* st = stslots + phase * 256;
+      const bool live = my0 < My && mx0 < Mx;          // block-uniform
+      float sm = 0.f, sq = 0.f;
+      int scol = 0;
+      bool swrite = false;
+      if (live) {
+        if constexpr (!NARROW) {
+          const int li = lane & 31, lh = lane >> 5;
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          {
+            const int tyl = 2 * wid + (li >> 4), txl = li & 15;
+            const float* Arow = patch + ((tyl * isy - ylo) * PW + (txl * isx - xlo)) * PC + 4 * lh;
+            const float* Brow = wl + (li < Cout ? li : 0) * PC + 4 * lh;
+            for (int jy = 0; jy < ny; ++jy) {
+              const int dy = ph.dy0 + dsy * jy;
+              for (int jx = 0; jx < nx; ++jx) {
+                const int dx = ph.dx0 + dsx * jx;
+                const float* A = Arow + (dy * PW + dx) * PC;
+                const float* B = Brow + (MERGE ? (ph.ky0 + p.kstep[1] * jy) * p.Kx + ph.kx0 + p.kstep[2] * jx : jy * nx + jx) * Cout * PC;
+#pragma unroll
+                for (int g = 0; g < CIN / 8; ++g) {
+                  const float4 a = *reinterpret_cast<const float4*>(A + 8 * g);
+                  const float4 b = *reinterpret_cast<const float4*>(B + 8 * g);
+                  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+                }
+              }
+            }
+          }
+          const int co = li;
+          const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int my = my0 + 2 * wid + (rl >> 4), mx = mx0 + (rl & 15);
+            const int oy = my * osy + ph.oy, ox = mx * osx + ph.ox;
+            const bool ok = my < My && mx < Mx && oy < p.Ho && ox < p.Wo && co < Cout;
+            if (ok) {
+              const long pix = ((long)n * p.Ho + oy) * p.Wo + ox;
+              float v = acc[r] + bv;
+              sm += v;
+              sq += v * v;
+              if (gres) v += gres[pix * ldr + co];
+              if (tanh_out) v = tanhf(v);
+              gout[pix * ldo + co] = v;
+            }
+          }
+          sm += __shfl_xor(sm, 32, 64);
+          sq += __shfl_xor(sq, 32, 64);
+          scol = li;
+          swrite = lh == 0;
+        } else {
+          const int l16 = lane & 15, kq = lane >> 4;
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+          {
+            const float* A0row = patch + (((2 * wid) * isy - ylo) * PW + (l16 * isx - xlo)) * PC + 4 * kq;
+            const float* A1row = A0row + isy * PW * PC;
+            const float* Brow = wl + (l16 < Cout ? l16 : 0) * PC + 4 * kq;
+            for (int jy = 0; jy < ny; ++jy) {
+              const int dy = ph.dy0 + dsy * jy;
+              for (int jx = 0; jx < nx; ++jx) {
+                const int dx = ph.dx0 + dsx * jx;
+                const int aoff = (dy * PW + dx) * PC;
+                const float* B = Brow + (MERGE ? (ph.ky0 + p.kstep[1] * jy) * p.Kx + ph.kx0 + p.kstep[2] * jx : jy * nx + jx) * Cout * PC;
+#pragma unroll
+                for (int g = 0; g < CIN / 16; ++g) {
+                  const float4 a0 = *reinterpret_cast<const float4*>(A0row + aoff + 16 * g);
+                  const float4 a1 = *reinterpret_cast<const float4*>(A1row + aoff + 16 * g);
+                  const float4 b = *reinterpret_cast<const float4*>(B + 16 * g);
+                  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc1, 0, 0, 0);
+                  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc1, 0, 0, 0);
+                  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc1, 0, 0, 0);
+                  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc1, 0, 0, 0);
+                }
+              }
+            }
+          }
+          const int co = l16;
+          const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int my = my0 + 2 * wid + mt, mx = mx0 + 4 * kq + r;
+              const int oy = my * osy + ph.oy, ox = mx * osx + ph.ox;
+              const bool ok = my < My && mx < Mx && oy < p.Ho && ox < p.Wo && co < Cout;
+              if (ok) {
+                const long pix = ((long)n * p.Ho + oy) * p.Wo + ox;
+                float v = (mt == 0 ? acc0[r] : acc1[r]) + bv;
+                sm += v;
+                sq += v * v;
+                if (gres) v += gres[pix * ldr + co];
+                if (tanh_out) v = tanhf(v);
+                gout[pix * ldo + co] = v;
+              }
+            }
+          sm += __shfl_xor(sm, 16, 64);
+          sq += __shfl_xor(sq, 16, 64);
+          sm += __shfl_xor(sm, 32, 64);
+          sq += __shfl_xor(sq, 32, 64);
+          scol = l16;
+          swrite = kq == 0;
+        }
+      }
+      if (p.stats && swrite) {                        // a dead phase leaves sm = sq = 0 in its slots
+        st[(wid * 2 + 0) * 32 + scol] = sm;
+        st[(wid * 2 + 1) * 32 + scol] = sq;
+      } else if (p.stats && !live && lane < 32) {
+        st[(wid * 2 + 0) * 32 + lane] = 0.f;
+        st[(wid * 2 + 1) * 32 + lane] = 0.f;
+      }
+    }
+    __syncthreads();                                  // every wave is done with the patch; statistics slots are complete
+    if (p.stats && tid < Cout) {
+      for (int phase = 0; phase < nph; ++phase) {
+        const float* st = stslots + phase * 256;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          a += st[(w * 2 + 0) * 32 + tid];
+          b += st[(w * 2 + 1) * 32 + tid];
+        }
+        float* row = p.stats + ((long)t * nph + phase) * 2 * Cout;
+        row[tid] = a;
+        row[Cout + tid] = b;
+      }
+    }
+    if (tn < ntiles) store_patch();
+    __syncthreads();
+  }
+}
+
 // Geometry test for the patch kernel (pointer alignment is checked at launch).
 static bool patch_plan(const GatherConv& p, PatchLaunch* out, int* smem_bytes) {
   static const bool off = getenv("MPGAN_DBG_NO_PATCH") != nullptr;
@@ -1637,7 +1978,94 @@ static int launch_patch_cin(const GatherConv& p, const PatchLaunch& pl, int smem
              : launch_patch_variant<CIN, 0, false, false>(p, pl, smem, st);
 }
 
+// ---- persistent form -------------------------------------------------------------------------
+template <int CIN, int PRO, bool NARROW, bool MERGE>
+static int launch_patch_persist_variant(const GatherConv& p, const PatchLaunch& pl, int smem, int ntiles, int grid,
+                                        hipStream_t st) {
+  auto kern = gather_patch_persist_kernel<CIN, PRO, NARROW, MERGE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) {
+      set_error("gather_patch_persist: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, st, p, pl, ntiles);
+  return check_launch("gather_patch_persist");
+}
+
+template <int CIN>
+static int launch_patch_persist_cin(const GatherConv& p, const PatchLaunch& pl, int smem, int ntiles, int grid,
+                                    hipStream_t st) {
+  const bool pro = p.pro.scale != nullptr;
+  if (pl.merged) {
+    if (p.Cout <= 16) return launch_patch_persist_variant<CIN, 0, true, true>(p, pl, smem, ntiles, grid, st);
+    return launch_patch_persist_variant<CIN, 0, false, true>(p, pl, smem, ntiles, grid, st);
+  }
+  if (p.Cout <= 16)
+    return pro ? launch_patch_persist_variant<CIN, 1, true, false>(p, pl, smem, ntiles, grid, st)
+               : launch_patch_persist_variant<CIN, 0, true, false>(p, pl, smem, ntiles, grid, st);
+  return pro ? launch_patch_persist_variant<CIN, 1, false, false>(p, pl, smem, ntiles, grid, st)
+             : launch_patch_persist_variant<CIN, 0, false, false>(p, pl, smem, ntiles, grid, st);
+}
+
+// Plan of the persistent form; false: keep the one-tile-per-block kernel (several unmerged phases, a patch
+// that does not fit one register round, LDS).
+static bool patch_persist_plan(const GatherConv& p, const PatchLaunch& pl, PatchLaunch* out, int* smem, int* ntiles,
+                               int* grid) {
+  static const bool off = getenv("MPGAN_DBG_NO_PERSIST") != nullptr;
+  if (off) return false;
+  if (p.nphase != 1 && !pl.merged) return false;
+  const int PC = p.Cin + 4, CQ = p.Cin / 4;
+  int PH, PW, wtaps;
+  if (pl.merged) {
+    PH = (PT_H - 1) * p.istride[1] + (pl.yhi - pl.ylo) + 1;
+    PW = (PT_W - 1) * p.istride[2] + (pl.xhi - pl.xlo) + 1;
+    wtaps = p.Ky * p.Kx;
+  } else {
+    const Phase& ph = p.ph[0];
+    const int ny = ph.nz > 0 ? ph.ny : 0, nx = ph.nx;
+    PH = (PT_H - 1) * p.istride[1] + (ny > 0 ? ny - 1 : 0) * abs(p.dstep[1]) + 1;
+    PW = (PT_W - 1) * p.istride[2] + (nx > 0 ? nx - 1 : 0) * abs(p.dstep[2]) + 1;
+    wtaps = ny * nx;
+  }
+  const int LU = p.Cin == 16 ? 9 : 12;
+  if (PH * PW * CQ > LU * 256) return false;
+  *out = pl;
+  out->w_floats = (wtaps * p.Cout * PC + 3) & ~3;
+  int pf = PH * PW * PC;
+  out->patch_floats = (pf + 3) & ~3;
+  const int nph = pl.merged ? p.nphase : 1;
+  const long bytes = ((long)out->w_floats + out->patch_floats + nph * 256) * 4;
+  if (bytes > 150 * 1024) return false;
+  *smem = (int)bytes;
+  *ntiles = pl.tiles_x * pl.tiles_y * p.N;
+  static const int bpc_env = getenv("MPGAN_DBG_PATCH_BPC") ? atoi(getenv("MPGAN_DBG_PATCH_BPC")) : 0;
+  int bpc = (int)((160L * 1024) / bytes);
+  if (bpc > 3) bpc = 3;
+  if (bpc < 1) bpc = 1;
+  if (bpc_env > 0) bpc = bpc_env;
+  int g = 256 * bpc;
+  if (g > *ntiles) g = *ntiles;
+  *grid = g;
+  return true;
+}
+
 static int launch_patch(const GatherConv& p, const PatchLaunch& pl, int smem, hipStream_t st) {
+  {
+    PatchLaunch pp;
+    int psmem = 0, ntiles = 0, grid = 0;
+    if (patch_persist_plan(p, pl, &pp, &psmem, &ntiles, &grid)) {
+      switch (p.Cin) {
+        case 16: return launch_patch_persist_cin<16>(p, pp, psmem, ntiles, grid, st);
+        case 32: return launch_patch_persist_cin<32>(p, pp, psmem, ntiles, grid, st);
+        default: return launch_patch_persist_cin<64>(p, pp, psmem, ntiles, grid, st);
+      }
+    }
+  }
   switch (p.Cin) {
     case 16: return launch_patch_cin<16>(p, pl, smem, st);
     case 32: return launch_patch_cin<32>(p, pl, smem, st);
@@ -1692,11 +2120,11 @@ static int select_variant(const GatherConv& p, long maxM, bool thin1, bool thin2
   return bn;
 }
 
-template <int BN, int TM, int TN, int WN, int WRAPS, int PRO, bool FAST = false>
+template <int BN, int TM, int TN, int WN, int WRAPS, int PRO, bool FAST = false, int KS = 1>
 static int launch_pipe_variant(const GatherConv& p, long maxM, hipStream_t st) {
-  auto kern = gather_conv_pipe_kernel<BN, TM, TN, WN, WRAPS, PRO, FAST>;
+  auto kern = gather_conv_pipe_kernel<BN, TM, TN, WN, WRAPS, PRO, FAST, KS>;
   static const int lds_pad = getenv("MPGAN_DBG_LDS_PAD") ? atoi(getenv("MPGAN_DBG_LDS_PAD")) : 0;
-  const int smem = 2 * (BM + BN) * PITCH * (int)sizeof(float) + lds_pad;
+  const int smem = KS * 2 * (BM + BN) * PITCH * (int)sizeof(float) + lds_pad;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1713,7 +2141,7 @@ static int launch_pipe_variant(const GatherConv& p, long maxM, hipStream_t st) {
   q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 4 > (3L << 20) ? 1 : 0;
   if (q.ksplit < 1) q.ksplit = 1;
   dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase * q.ksplit);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
+  hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, st, q);
   return check_launch("gather_conv_pipe");
 }
 
@@ -1733,10 +2161,31 @@ static bool fast_geometry(const GatherConv& p, int bn) {
   return true;
 }
 
+// In-block split-K (KS = 2 of gather_conv_pipe_kernel): when the output grid gives at most ~1.5 blocks per CU and
+// every K group still gets >= 4 K-steps.
+static bool pipe_wants_ksplit2(const GatherConv& p, int bn, long maxM) {
+  static const bool off = getenv("MPGAN_DBG_NO_KS2") != nullptr;
+  if (off || p.ksplit > 1 || p.Cin % 32 != 0) return false;
+  const long blocks = (maxM + BM - 1) / BM * ((p.Cout + bn - 1) / bn) * p.nphase;
+  if (blocks > 384) return false;
+  int min_nk = 1 << 30;
+  for (int i = 0; i < p.nphase; ++i) {
+    const int nk = p.ph[i].nz * p.ph[i].ny * p.ph[i].nx * p.Cin / BK;
+    if (nk > 0 && nk < min_nk) min_nk = nk;
+  }
+  return min_nk >= 8 && min_nk < (1 << 30);
+}
+
 template <int WRAPS, int PRO>
 static int launch_pipe_bn(const GatherConv& p, int variant, long maxM, hipStream_t st) {
   if constexpr (WRAPS == 1 && PRO == 3) {
     if (variant == 128 && fast_geometry(p, 128)) return launch_pipe_variant<128, 2, 2, 2, 1, 3, true>(p, maxM, st);
+  }
+  if constexpr (WRAPS == 1 && PRO != 3) {
+    if (variant != 128 && pipe_wants_ksplit2(p, variant, maxM)) {
+      if (variant == 64) return launch_pipe_variant<64, 1, 2, 1, 1, PRO, false, 2>(p, maxM, st);
+      return launch_pipe_variant<32, 1, 1, 1, 1, PRO, false, 2>(p, maxM, st);
+    }
   }
   if (variant == 128) return launch_pipe_variant<128, 2, 2, 2, WRAPS, PRO>(p, maxM, st);
   if (variant == 64) return launch_pipe_variant<64, 1, 2, 1, WRAPS, PRO>(p, maxM, st);
@@ -1983,6 +2432,8 @@ extern "C" int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward
     if (patch_plan(p, &pl, nullptr)) return pl.merged ? 17 : 16;
   }
   if (v == 128 && has_prologue == 3 && fast_geometry(p, 128)) return 1128;
+  if ((v == 32 || v == 64) && p.Cin % 32 == 0 && has_prologue != 3 && pipe_wants_ksplit2(p, v, max_phase_pixels(p)))
+    return 2000 + v;
   return v;
 }
 

@@ -233,6 +233,8 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
     gc = g.c()
     v = int(lib().mpgan_conv_variant(C.byref(gc), int(backward_data),
                                      (2 if per_sample_norm else (3 if fast_leaky else 1)) if has_pro else 0))
+    ks2 = v >= 2000                              # K axis split over two wave groups inside the block
+    v = v - 2000 if ks2 else v
     fast = v >= 1000                             # mask-free instance of the pipelined kernel
     v = v - 1000 if fast else v
     if v == 1:
@@ -248,7 +250,7 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
     if cin_eff % 32 == 0 or cin_eff == 16:      # software-pipelined main kernel <BN, TM, TN, WN, WRAPS, PRO>
         pro = 0 if not has_pro else (2 if per_sample_norm else (3 if fast_leaky else 1))
         return (f"gather_conv_pipe_kernel<{v}, {tm}, {tn}, {wn}, {1 if cin_eff % 32 == 0 else 2}, {pro}, "
-                f"{'true' if fast else 'false'}>")
+                f"{'true' if fast else 'false'}, {2 if ks2 else 1}>")
     return f"gather_conv_kernel<{v}, {tm}, {tn}, {wn}, {'false' if cin_eff % 4 == 0 else 'true'}>"
 
 

@@ -115,6 +115,8 @@ int mpgan_conv_backward_data(const mpgan_conv_geom* g, const float* dy, int32_t 
  * tile walking every phase of a strided backward-data / transposed conv), 32/64/128 = fp32-MFMA
  * K-stepped implicit GEMM with that output-channel tile.
  * 1128 = the 128 tile's mask-free instance (pad-free forward conv, Cout % 128 == 0, has_prologue 3).
+ * 2032 / 2064 = the 32 / 64 tile with the K axis split over two 4-wave groups inside the block (output grids
+ * of about one block per CU: the U-Net's 32 x 32 levels).
  * has_prologue: 0 none, 1 per-channel scale/shift, 2 per-(sample, channel), 3 per-channel +
  * LeakyReLU with a host-known slope in [0, 1]. */
 int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward_data, int32_t has_prologue);

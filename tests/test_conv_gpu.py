@@ -351,3 +351,45 @@ def test_patch_kernel_forward_stats_prologue_and_dgrad(case):
         dx = torch.full((n, *gf.in_dhw, cout), float("nan"), device="cuda")
         ops.conv_backward_data(gf, to_cl(gy), ops.pack_weight(wf.cuda(), for_dgrad=True), dx)
         assert_close(from_cl(dx, 2), xf.grad, what="patch dgrad (stride 1)")
+
+
+@pytest.mark.parametrize("cin,cout,k,pro_code", [(128, 128, 3, 1), (64, 128, 3, 0), (64, 64, 3, 1)])
+def test_small_grid_layers_split_k_inside_the_block(cin, cout, k, pro_code):
+    """The U-Net's 32 x 32 levels at config C2/C3's size (bs 16: 128 pixel tiles): about one block per CU, so the
+    dispatcher picks the form whose K axis is split over two 4-wave groups per block (variant 2032 / 2064);
+    forward with prologue + fused statistics and the backward-data gather must match torch."""
+    import ctypes
+    from mpgan_amd import ops
+    from mpgan_amd._lib import lib
+    n, spatial = 16, (32, 32)
+    g = _geom(2, n, cin, cout, k, 1, 1, spatial)
+    gc = g.c()
+    v = lib().mpgan_conv_variant(ctypes.byref(gc), 0, pro_code)
+    assert v in (2032, 2064), v
+    gen = torch.Generator().manual_seed(900 + cin + cout)
+    z = torch.rand(n, cin, *spatial, generator=gen) * 2 - 1
+    w = (torch.rand(cout, cin, k, k, generator=gen) * 2 - 1) / (cin * k * k) ** 0.5
+    b = torch.rand(cout, generator=gen) - 0.5
+    pro = None
+    a = z
+    if pro_code:
+        sc, sh = torch.rand(cin, generator=gen) + 0.5, torch.rand(cin, generator=gen) - 0.5
+        a = z * sc[None, :, None, None] + sh[None, :, None, None]
+        a = torch.where(a > 0, a, 0.25 * a)
+        pro = ops.Prologue(sc.cuda(), sh.cuda(), 0, ops.ACT_LEAKY, 1.0, torch.tensor([0.25], device="cuda"))
+    a_ = a.clone().requires_grad_(True)
+    y_ref = F.conv2d(a_, w, b, padding=1)
+    rows = ops.conv_stats_rows(g, pro_code)
+    part = torch.full(((rows + 32) * 2 * cout,), float("nan"), device="cuda")
+    y = torch.full((n, *g.out_dhw, cout), float("nan"), device="cuda")
+    ops.conv_forward(g, to_cl(z), ops.pack_weight(w.cuda()), b.cuda(), y, pro=pro, stats_partials=part)
+    assert_close(from_cl(y, 2), y_ref.detach(), what="forward (K split in block)")
+    sums = part[:rows * 2 * cout].reshape(rows, 2, cout).double().sum(0).cpu()
+    assert_close(sums[0].float(), y_ref.detach().double().sum((0, 2, 3)).float(), rtol=1e-4, what="fused sum")
+    assert_close(sums[1].float(), (y_ref.detach().double() ** 2).sum((0, 2, 3)).float(), rtol=1e-4, what="fused sum of squares")
+    gy = torch.rand(y_ref.shape, generator=gen) * 2 - 1
+    y_ref.backward(gy)
+    assert lib().mpgan_conv_variant(ctypes.byref(gc), 1, 0) in (2032, 2064)
+    dx = torch.full((n, *g.in_dhw, cin), float("nan"), device="cuda")
+    ops.conv_backward_data(g, to_cl(gy), ops.pack_weight(w.cuda(), for_dgrad=True), dx)
+    assert_close(from_cl(dx, 2), a_.grad, what="dgrad (K split in block)")

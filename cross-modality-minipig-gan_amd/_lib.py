@@ -47,6 +47,7 @@ SIGNATURES = {
     "mpgan_stats_chunks": (_I, [_L, _I]),
     "mpgan_channel_stats": (_I, [_P, _I, _I, _L, _I, _P, _P]),
     "mpgan_norm_finalize": (_I, [_P, _I, _I, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mpgan_norm_finalize_strided": (_I, [_P, _I, _I, _I, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mpgan_norm_from_running": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
     "mpgan_norm_from_running_multi": (_I, [_P, _I, _P]),
     "mpgan_norm_act_add": (_I, [_P, _I, _PR, _P, _I, _PR, _I, _L, _I, _I, _P, _I, _P]),

@@ -178,7 +178,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // One wave per statistic: lanes stride over the partial rows (fixed assignment),
 // then a fixed butterfly -- deterministic, and no longer a serial 1000-row walk.
 __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ partials, int N, int chunks,
-                                                            int C, long P, int instance,
+                                                            int C, int W, long P, int instance,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, float momentum,
                                                             float* running_mean, float* running_var,
@@ -193,12 +193,12 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restr
   const int c = instance ? i % C : i;
   const int nb = instance ? i / C : 0, ne = instance ? nb + 1 : N;
   const int rows = (ne - nb) * chunks;
-  const float* base = partials + (long)nb * chunks * 2 * C;
+  const float* base = partials + (long)nb * chunks * 2 * W;     // rows are [2][W], W >= C channels wide
   double s = 0.0, ss = 0.0;
   for (int r = lane; r < rows; r += 64) {
-    const float* row = base + (long)r * 2 * C;
+    const float* row = base + (long)r * 2 * W;
     s += (double)row[c];
-    ss += (double)row[C + c];
+    ss += (double)row[W + c];
   }
   s = wave_sum_d(s);
   ss = wave_sum_d(ss);
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restr
 // BatchNorm with >= 256 partial rows: ONE BLOCK per channel (lanes stride over the rows, fixed
 // assignment; fixed-order tree in LDS) -- 8 dependent loads per lane for 2048 rows instead of 32.
 __global__ __launch_bounds__(256) void norm_finalize_wide_kernel(const float* __restrict__ partials, int rows, int C,
-                                                                 double cnt, const float* __restrict__ gamma,
+                                                                 int W, double cnt, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float eps,
                                                                  float momentum, float* running_mean,
                                                                  float* running_var, int64_t* nbt,
@@ -239,10 +239,10 @@ __global__ __launch_bounds__(256) void norm_finalize_wide_kernel(const float* __
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int rr = r + u * 256;
-      const float* row = partials + (long)(rr < rows ? rr : r) * 2 * C;
+      const float* row = partials + (long)(rr < rows ? rr : r) * 2 * W;
       const float m = rr < rows ? 1.f : 0.f;
       v[u][0] = row[c] * m;
-      v[u][1] = row[C + c] * m;
+      v[u][1] = row[W + c] * m;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -589,15 +589,16 @@ extern "C" int mpgan_channel_stats(const float* z, int32_t ldz, int32_t n, int64
   return check_launch("channel_stats");
 }
 
-extern "C" int mpgan_norm_finalize(const float* partials, int32_t n, int32_t chunks, int32_t c, int64_t P,
-                                   int32_t instance, const float* gamma, const float* beta, float eps,
-                                   float momentum, float* running_mean, float* running_var, int64_t* nbt,
-                                   float* scale, float* shift, float* mean, float* invstd, void* stream) {
-  MPGAN_CHECK_ARG(partials && scale && shift && mean && invstd && n > 0 && c > 0 && chunks > 0,
+extern "C" int mpgan_norm_finalize_strided(const float* partials, int32_t n, int32_t chunks, int32_t c, int32_t cstride,
+                                           int64_t P, int32_t instance, const float* gamma, const float* beta,
+                                           float eps, float momentum, float* running_mean, float* running_var,
+                                           int64_t* nbt, float* scale, float* shift, float* mean, float* invstd,
+                                           void* stream) {
+  MPGAN_CHECK_ARG(partials && scale && shift && mean && invstd && n > 0 && c > 0 && chunks > 0 && cstride >= c,
                   "norm_finalize: bad argument");
   if (!instance && (long)n * chunks > 16384) {   // (the block-per-channel finalize below takes 16K rows in 16 trips)
     // fold the rows first; the compact rows live in the caller's buffer right after the input rows
-    const int rows = n * chunks, W = 2 * c;
+    const int rows = n * chunks, W = 2 * cstride;
     float* compact = const_cast<float*>(partials) + (long)rows * W;
     hipLaunchKernelGGL(partials_compact_kernel, dim3((W + 63) / 64, COMPACT_ROWS), dim3(256), 0, (hipStream_t)stream,
                        partials, rows, W, compact);
@@ -608,15 +609,23 @@ extern "C" int mpgan_norm_finalize(const float* partials, int32_t n, int32_t chu
   }
   if (!instance && (long)n * chunks >= 256) {
     hipLaunchKernelGGL(norm_finalize_wide_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, partials, n * chunks, c,
-                       (double)P * n, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift, mean,
-                       invstd);
+                       cstride, (double)P * n, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift,
+                       mean, invstd);
     return check_launch("norm_finalize");
   }
   const int total = instance ? n * c : c;
   hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, n,
-                     chunks, c, (long)P, instance, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale,
-                     shift, mean, invstd);
+                     chunks, c, cstride, (long)P, instance, gamma, beta, eps, momentum, running_mean, running_var, nbt,
+                     scale, shift, mean, invstd);
   return check_launch("norm_finalize");
+}
+
+extern "C" int mpgan_norm_finalize(const float* partials, int32_t n, int32_t chunks, int32_t c, int64_t P,
+                                   int32_t instance, const float* gamma, const float* beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, int64_t* nbt,
+                                   float* scale, float* shift, float* mean, float* invstd, void* stream) {
+  return mpgan_norm_finalize_strided(partials, n, chunks, c, c, P, instance, gamma, beta, eps, momentum, running_mean,
+                                     running_var, nbt, scale, shift, mean, invstd, stream);
 }
 
 extern "C" int mpgan_norm_act_add(const float* z, int32_t ldz, const mpgan_prologue* pz, const float* r, int32_t ldr,

@@ -85,6 +85,12 @@ def fast_stream(device) -> "torch.cuda.Stream":
 
 
 _SINGLE_STREAM = bool(os.environ.get("MPGAN_SINGLE_STREAM"))
+_FUSE_DOWN = not os.environ.get("MPGAN_DBG_NO_FUSE_DOWN")   # ResidualUnit: first conv + residual conv as one launch
+
+
+def same_geom(a, b) -> bool:
+    return (a.n, a.in_dhw, a.cin, a.k, a.stride, a.pad, a.transposed) == (b.n, b.in_dhw, b.cin, b.k, b.stride, b.pad,
+                                                                         b.transposed)
 
 
 class Mark:
@@ -270,6 +276,13 @@ class ConvRec:
     __slots__ = ("mod", "transposed", "cout", "cin", "taps", "w_off", "fwd_off", "bwd_off", "tco", "tco_off")
 
 
+class FusedRec:
+    """Two ConvNd of one geometry reading the same input (a ResidualUnit's first conv and its strided
+    residual conv), packed as ONE conv over their concatenated output channels: forward weights
+    [CoutA + CoutB][tap][Cin] and the concatenated biases, both in the packed buffer."""
+    __slots__ = ("a", "b", "w_off", "b_off", "cout", "cin", "taps")
+
+
 class ParamStore:
     """All parameters of a network as views of ONE flat fp32 buffer (+ a flat
     gradient buffer the kernels accumulate into, the buffer RCCL all-reduces and
@@ -278,6 +291,7 @@ class ParamStore:
     def __init__(self, module: nn.Module):
         self.module = module
         self.convs: List[ConvRec] = []
+        self.fused: List[FusedRec] = []
         self._by_mod = {}
         self.flat = None
         self.flat_grad = None
@@ -350,6 +364,28 @@ class ParamStore:
             self._build_pack_table()
         return r
 
+    def register_fused(self, conv_a, conv_b) -> FusedRec:
+        """The concatenated forward pack of two registered ConvNd with equal input channels and kernel."""
+        for f in self.fused:
+            if f.a.mod is conv_a and f.b.mod is conv_b:
+                return f
+        if self.frozen:
+            raise RuntimeError("ParamStore: fused pair registered after plans were built")
+        ra, rb = self._by_mod[id(conv_a)], self._by_mod[id(conv_b)]
+        assert (ra.cin, ra.taps, ra.transposed, rb.transposed) == (rb.cin, rb.taps, False, False)
+        assert conv_a.bias is not None and conv_b.bias is not None
+        f = FusedRec()
+        f.a, f.b, f.cout, f.cin, f.taps = ra, rb, ra.cout + rb.cout, ra.cin, ra.taps
+        self.fused.append(f)
+        self._build_pack_table()
+        return f
+
+    def wp_fused(self, f: FusedRec) -> torch.Tensor:
+        return self.packed[f.w_off:f.w_off + f.cout * f.cin * f.taps]
+
+    def bias_fused(self, f: FusedRec) -> torch.Tensor:
+        return self.packed[f.b_off:f.b_off + f.cout]
+
     def _build_pack_table(self):
         if not self.convs:
             return
@@ -368,6 +404,16 @@ class ParamStore:
                 r.tco_off = off
                 off += (n + 3) // 4 * 4
                 rows.append([r.w_off, r.tco_off, r.cout, r.cin, r.taps, int(r.transposed), 2, 0])
+        for f in self.fused:
+            na, nb_ = f.a.cout * f.cin * f.taps, f.b.cout * f.cin * f.taps
+            f.w_off = off
+            rows.append([f.a.w_off, off, f.a.cout, f.cin, f.taps, 0, 0, 0])
+            rows.append([f.b.w_off, off + na, f.b.cout, f.cin, f.taps, 0, 0, 0])
+            off += (na + nb_ + 3) // 4 * 4
+            f.b_off = off                      # biases: a "conv" with one tap and one input channel copies them
+            rows.append([self.offset(f.a.mod.bias), off, f.a.cout, 1, 1, 0, 0, 0])
+            rows.append([self.offset(f.b.mod.bias), off + f.a.cout, f.b.cout, 1, 1, 0, 0, 0])
+            off += (f.cout + 3) // 4 * 4
         dev = self.flat.device
         self.packed = torch.empty(off, dtype=torch.float32, device=dev)
         self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
@@ -486,18 +532,22 @@ def emit_norm_stats(prog, z, nb: NormBuf, norm_mod, partials, eps=1e-5, momentum
 
 
 def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod, partials, pro=None, training=True,
-                       eval_norms=None):
+                       eval_norms=None, c_norm=None):
     """Conv whose raw output feeds a norm layer: BatchNorm statistics come out of the
     conv's own epilogue (one finalize launch follows); so do InstanceNorm's when the partial rows
     fall into per-sample groups; otherwise a separate statistics pass runs.  In eval
-    mode BatchNorm's scale/shift come from the running statistics instead."""
+    mode BatchNorm's scale/shift come from the running statistics instead.
+    c_norm: the norm covers only the first c_norm output channels (a conv fused with its
+    ResidualUnit's residual conv: the trailing channels are the un-normalised residual branch)."""
+    c = g.cout if c_norm is None else c_norm
+    y_norm = y if c_norm is None else y[..., :c]
     if not training and not nb.instance:
         emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro)
         if eval_norms is not None:       # input-independent: the plan folds all of them into one launch up front
-            eval_norms.append((norm_mod, nb, g.cout))
+            eval_norms.append((norm_mod, nb, c))
             return
         prog.add("norm_from_running", lib().mpgan_norm_from_running, _p(norm_mod.weight), _p(norm_mod.bias),
-                 norm_mod.running_mean.data_ptr(), norm_mod.running_var.data_ptr(), float(norm_mod.eps), g.cout,
+                 norm_mod.running_mean.data_ptr(), norm_mod.running_var.data_ptr(), float(norm_mod.eps), c,
                  nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
                  keep=(norm_mod.weight, norm_mod.bias, norm_mod.running_mean, norm_mod.running_var, nb))
         return
@@ -509,19 +559,20 @@ def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod,
         # slowest block index), for 128-pixel tiles of a non-transposed conv when 128 | P, and for the
         # thin kernel's 256-pixel blocks when 256 | P
         v = ops.conv_variant(g, False, code)
+        v = v - 2000 if v >= 2000 else v
         grouped = (v in (16, 17) or (v == 1 and P % 256 == 0)
                    or (v in (32, 64, 128) and not g.transposed and P % 128 == 0))
         if not grouped or rows % n:
             rows = 0
     if rows == 0:
         emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro)
-        emit_norm_stats(prog, y, nb, norm_mod, partials)
+        emit_norm_stats(prog, y_norm, nb, norm_mod, partials)
         return
-    c = g.cout
-    assert partials.numel() >= (rows + 32) * 2 * c
+    W = g.cout                                  # partial rows are [2][W] wide
+    assert partials.numel() >= (rows + 32) * 2 * W
     emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro, stats=partials)
     if nb.instance:
-        prog.add("norm_finalize", lib().mpgan_norm_finalize, partials.data_ptr(), n, rows // n, c, P, 1,
+        prog.add("norm_finalize", lib().mpgan_norm_finalize_strided, partials.data_ptr(), n, rows // n, c, W, P, 1,
                  _p(norm_mod.weight), _p(norm_mod.bias), float(norm_mod.eps), 0.0, None, None, None,
                  nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
                  keep=(norm_mod.weight, norm_mod.bias, nb, partials))
@@ -529,7 +580,7 @@ def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod,
     rm = getattr(norm_mod, "running_mean", None)
     rv = getattr(norm_mod, "running_var", None)
     nbt = getattr(norm_mod, "num_batches_tracked", None)
-    prog.add("norm_finalize", lib().mpgan_norm_finalize, partials.data_ptr(), 1, rows, c, n * P, 0,
+    prog.add("norm_finalize", lib().mpgan_norm_finalize_strided, partials.data_ptr(), 1, rows, c, W, n * P, 0,
              _p(norm_mod.weight), _p(norm_mod.bias), float(norm_mod.eps), float(norm_mod.momentum), _p(rm), _p(rv),
              _p(nbt), nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
              keep=(norm_mod.weight, norm_mod.bias, rm, rv, nbt, nb, partials))
@@ -709,13 +760,27 @@ class UNetPlan:
             g0 = geoms_down[l]
             g1 = conv_geom_of(cv1, n, sizes[l + 1], dims)
             gr = conv_geom_of(ru.res, n, sizes[l], dims)
-            z0, z1, r = E(n, *sizes[l + 1], c), E(n, *sizes[l + 1], c), E(n, *sizes[l + 1], c)
+            # unit0 and the strided residual conv read the same input with the same geometry: ONE conv over
+            # their concatenated output channels writes [z0 | r] (one launch, the input read once)
+            fuse = _FUSE_DOWN and same_geom(g0, gr)
+            fr = None
+            if fuse:
+                zr = E(n, *sizes[l + 1], 2 * c)
+                z0, r = zr[..., :c], zr[..., c:]
+                gf = ConvGeom(g0.n, g0.in_dhw, g0.cin, 2 * c, g0.k, g0.stride, g0.pad)
+                reg(cv0), reg(ru.res)
+                fr = store.register_fused(cv0, ru.res)       # before any packed offset is taken (emit)
+            else:
+                zr, gf = None, None
+                z0, r = E(n, *sizes[l + 1], c), E(n, *sizes[l + 1], c)
+            z1 = E(n, *sizes[l + 1], c)
             nb0, nb1 = NormBuf(n, c, instance, dev), NormBuf(n, c, instance, dev)
             P = sizes[l + 1][0] * sizes[l + 1][1] * sizes[l + 1][2]
             scratch.want_partials(n, P, c)
-            for g in (g0, g1, gr):
+            for g in (g0, g1, gr) + ((gf,) if fuse else ()):
                 scratch.want_ws(g)
-            down_state.append(dict(xin=xin, z0=z0, z1=z1, r=r, nb0=nb0, nb1=nb1, g0=g0, g1=g1, gr=gr, ru=ru, c=c))
+            down_state.append(dict(xin=xin, z0=z0, z1=z1, r=r, nb0=nb0, nb1=nb1, g0=g0, g1=g1, gr=gr, ru=ru, c=c,
+                                   zr=zr, gf=gf, fr=fr))
         # bottom
         cb_in, cb = chans[L - 2], chans[L - 1]
         (bc0, BN0, BA0), (bc1, BN1, BA1) = bottom.units
@@ -781,10 +846,16 @@ class UNetPlan:
         for l in range(L - 1):
             s = down_state[l]
             (cv0, N0, A0), (cv1, N1, A1) = s["ru"].units
-            emit_conv_fwd_norm(f, s["g0"], s["xin"], wp(R(cv0)), cv0.bias, s["z0"], s["nb0"], N0, part, training=tr, eval_norms=self.eval_norms)
-            # (the residual conv could run on the side stream; measured: the event hand-offs cost more
-            #  than the ~20 us kernels they would overlap -- G forward 4.42 -> 4.56 ms)
-            emit_conv_fwd(f, s["gr"], s["xin"], wp(R(s["ru"].res)), s["ru"].res.bias, s["r"])
+            if s["gf"] is not None:
+                fr = s["fr"]
+                emit_conv_fwd_norm(f, s["gf"], s["xin"], store.wp_fused(fr), store.bias_fused(fr), s["zr"], s["nb0"], N0,
+                                   part, training=tr, eval_norms=self.eval_norms, c_norm=s["c"])
+            else:
+                emit_conv_fwd_norm(f, s["g0"], s["xin"], wp(R(cv0)), cv0.bias, s["z0"], s["nb0"], N0, part, training=tr,
+                                   eval_norms=self.eval_norms)
+                # (the residual conv could run on the side stream; measured: the event hand-offs cost more
+                #  than the ~20 us kernels they would overlap -- G forward 4.42 -> 4.56 ms)
+                emit_conv_fwd(f, s["gr"], s["xin"], wp(R(s["ru"].res)), s["ru"].res.bias, s["r"])
             emit_conv_fwd_norm(f, s["g1"], s["z0"], wp(R(cv1)), cv1.bias, s["z1"], s["nb1"], N1, part,
                                pro=prelu_pro(s["nb0"], A0), training=tr, eval_norms=self.eval_norms)
             emit_norm_act_add(f, s["z1"], prelu_pro(s["nb1"], A1), s["r"], None, cats[l][..., :s["c"]])

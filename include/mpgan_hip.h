@@ -183,6 +183,15 @@ int mpgan_norm_finalize(const float* partials, int32_t n, int32_t chunks, int32_
                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
                         float* scale, float* shift, float* mean, float* invstd, void* stream);
 
+/* The same over partial rows that are `cstride` >= c channels wide ([rows][2][cstride]): statistics of the FIRST c
+ * channels of a conv that produced more (a ResidualUnit's first conv and its residual conv run as ONE conv
+ * over their concatenated output channels -- same input, same geometry; only the first half feeds a norm). */
+int mpgan_norm_finalize_strided(const float* partials, int32_t n, int32_t chunks, int32_t c, int32_t cstride,
+                                int64_t pixels_per_sample, int32_t instance,
+                                const float* gamma, const float* beta, float eps, float momentum,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                float* scale, float* shift, float* mean, float* invstd, void* stream);
+
 /* Eval-mode BatchNorm (module.eval(), code/GAN/inferrence.py:97-110,169-170): scale/shift
  * from the running statistics; nothing is updated. */
 int mpgan_norm_from_running(const float* gamma, const float* beta, const float* running_mean,

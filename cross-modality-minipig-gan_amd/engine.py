@@ -85,6 +85,7 @@ def fast_stream(device) -> "torch.cuda.Stream":
 
 
 _SINGLE_STREAM = bool(os.environ.get("MPGAN_SINGLE_STREAM"))
+_ALWAYS_PACK = bool(os.environ.get("MPGAN_DBG_ALWAYS_PACK"))
 _FUSE_DOWN = not os.environ.get("MPGAN_DBG_NO_FUSE_DOWN")   # ResidualUnit: first conv + residual conv as one launch
 
 
@@ -299,6 +300,8 @@ class ParamStore:
         self.table = None
         self.version = 0
         self.frozen = False
+        self._touched = 0
+        self._pack_state = {}
         self.flatten()
         for m in module.modules():
             if isinstance(m, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d, nn.ConvTranspose3d)):
@@ -418,11 +421,32 @@ class ParamStore:
         self.packed = torch.empty(off, dtype=torch.float32, device=dev)
         self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self._max_elems = max(r.cout * r.cin * r.taps for r in self.convs)
+        self._pack_state.clear()               # a new packed buffer holds nothing yet
 
     def emit_pack(self, prog: Program):
+        """The repack launch, skipped while the parameters are known to be unchanged since the last pack: torch
+        bumps the flat buffer's version counter on every in-place write through it or a parameter view, and the
+        fused Adam (which writes through a raw pointer) calls `touch()`.  Back-to-back forwards on constant
+        weights (inference, the discriminator's real/fake pair of one step) then pack once."""
         self.frozen = True
-        prog.add("pack_weights", lib().mpgan_pack_weights, self.flat.data_ptr(), self.packed.data_ptr(),
-                 self.table.data_ptr(), self.table.shape[0], self._max_elems, keep=(self.flat, self.packed, self.table))
+        fn = lib().mpgan_pack_weights
+        args = (self.flat.data_ptr(), self.packed.data_ptr(), self.table.data_ptr(), self.table.shape[0], self._max_elems)
+        state = self._pack_state
+
+        def pack_if_stale(stream):
+            key = (self.flat._version, self.version, self._touched)
+            if state.get("key") == key and not _ALWAYS_PACK:
+                return 0
+            rc = fn(*args, stream)
+            if rc == 0:
+                state["key"] = key
+            return rc
+
+        prog.add("pack_weights", pack_if_stale, keep=(self.flat, self.packed, self.table))
+
+    def touch(self):
+        """Parameters were written behind torch's back (raw-pointer kernel)."""
+        self._touched += 1
 
     def wp(self, rec: ConvRec) -> torch.Tensor:
         return self.packed[rec.fwd_off:rec.fwd_off + rec.cout * rec.cin * rec.taps]

@@ -173,6 +173,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count += 1
         ops.adam_step(store.flat, store.flat_grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0],
                       g["betas"][1], g["eps"], self.step_count, self.grad_scale)
+        store.touch()                               # the packed weights are stale now
         return loss
 
 

@@ -393,3 +393,45 @@ def test_small_grid_layers_split_k_inside_the_block(cin, cout, k, pro_code):
     dx = torch.full((n, *g.in_dhw, cin), float("nan"), device="cuda")
     ops.conv_backward_data(g, to_cl(gy), ops.pack_weight(w.cuda(), for_dgrad=True), dx)
     assert_close(from_cl(dx, 2), a_.grad, what="dgrad (K split in block)")
+
+
+@pytest.mark.parametrize("cin,c,spatial", [(1, 16, (64, 48)), (16, 32, (40, 56)), (32, 64, (24, 32))])
+def test_residual_unit_first_conv_and_residual_conv_as_one_launch(cin, c, spatial):
+    """MONAI ResidualUnit(stride 2): `conv.unit0.conv` and `residual` read the same input with the same geometry;
+    the engine runs them as ONE conv over their concatenated output channels (ParamStore.register_fused packs
+    [W_unit0; W_res] and the two biases) and takes BatchNorm statistics of the FIRST half only
+    (mpgan_norm_finalize_strided).  Checked against the two torch convs and F.batch_norm."""
+    import torch.nn as nn
+    from mpgan_amd import engine, ops
+    n = 4
+    torch.manual_seed(3 + cin)
+    net = nn.ModuleDict({"a": nn.Conv2d(cin, c, 3, 2, 1), "b": nn.Conv2d(cin, c, 3, 2, 1), "bn": nn.BatchNorm2d(c)}).cuda()
+    with torch.no_grad():
+        net["bn"].weight.uniform_(0.5, 1.5)
+        net["bn"].bias.uniform_(-0.5, 0.5)
+    store = engine.ParamStore(net)
+    fr = store.register_fused(net["a"], net["b"])
+    prog = engine.Program()
+    store.emit_pack(prog)
+    gen = torch.Generator().manual_seed(17)
+    x = torch.rand(n, cin, *spatial, generator=gen) * 2 - 1
+    g = _geom(2, n, cin, 2 * c, 3, 2, 1, spatial)
+    zr = torch.full((n, *g.out_dhw, 2 * c), float("nan"), device="cuda")
+    nb = engine.NormBuf(n, c, False, torch.device("cuda"))
+    rows = ops.conv_stats_rows(g, 0)
+    assert rows > 0
+    part = torch.empty((rows + 32) * 2 * 2 * c, device="cuda")
+    engine.emit_conv_fwd_norm(prog, g, to_cl(x), store.wp_fused(fr), store.bias_fused(fr), zr, nb, net["bn"], part, c_norm=c)
+    prog.run()
+    wa, wb = net["a"].weight.detach().cpu(), net["b"].weight.detach().cpu()
+    za = F.conv2d(x, wa, net["a"].bias.detach().cpu(), stride=2, padding=1)
+    zb = F.conv2d(x, wb, net["b"].bias.detach().cpu(), stride=2, padding=1)
+    assert_close(from_cl(zr[..., :c], 2), za, what="first conv (fused launch)")
+    assert_close(from_cl(zr[..., c:], 2), zb, what="residual conv (fused launch)")
+    rm, rv = torch.zeros(c), torch.ones(c)
+    y_ref = F.batch_norm(za, rm, rv, net["bn"].weight.detach().cpu(), net["bn"].bias.detach().cpu(), True, 0.1, 1e-5)
+    y = from_cl(zr[..., :c], 2) * nb.scale.cpu()[None, :, None, None] + nb.shift.cpu()[None, :, None, None]
+    assert_close(y, y_ref, rtol=1e-4, what="normalised first half")
+    assert_close(net["bn"].running_mean.cpu(), rm, what="running_mean")
+    assert_close(net["bn"].running_var.cpu(), rv, rtol=1e-4, what="running_var")
+    assert int(net["bn"].num_batches_tracked) == 1

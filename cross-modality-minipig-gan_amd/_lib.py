@@ -20,6 +20,13 @@ class PeerTapsC(C.Structure):
                 ("shift_peer", C.c_void_p), ("coef", C.c_void_p)]
 
 
+class NormFoldC(C.Structure):
+    _fields_ = [("acc", C.c_void_p), ("replicas", C.c_int32), ("cstride", C.c_int32), ("count", C.c_int64),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("momentum", C.c_float),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p)]
+
+
 class PrologueC(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("n_stride", C.c_int32),
                 ("act", C.c_int32), ("slope", C.c_float), ("slope_ptr", C.c_void_p)]
@@ -85,6 +92,11 @@ SIGNATURES = {
     "mpgan_adam_step": (_I, [_P, _P, _P, _P, _L, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, _P]),
     "mpgan_patch_gather": (_I, [_P, _I, _I3, _P, _I, _I3, _P, _P]),
     "mpgan_patch_scatter_add": (_I, [_P, _I, _I3, _P, _I, _I3, _P, _P]),
+    "mpgan_zero_bytes": (_I, [_P, _L, _P]),
+    "mpgan_conv_acc_supported": (_I, [_G, _I]),
+    "mpgan_conv_fold_supported": (_I, [_G]),
+    "mpgan_conv_forward_fold": (_I, [_G, _P, _I, _P, _P, _PR, C.POINTER(NormFoldC), _P, _I, _I, _P, _P, _I, _P, _I, _P]),
+    "mpgan_norm_act_add_fold": (_I, [_P, _I, _PR, C.POINTER(NormFoldC), _P, _I, _PR, _I, _L, _I, _I, _P, _I, _P]),
     # bf16 storage path (config C5)
     "mpgan_conv_stats_rows_bf16": (_I, [_G]),
     "mpgan_conv_forward_bf16": (_I, [_G, _P, _I, _P, _P, _P, _P, _I, _P]),

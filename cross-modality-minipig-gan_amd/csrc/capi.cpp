@@ -14,3 +14,17 @@ void set_error(const char* fmt, ...) {
 
 extern "C" const char* mpgan_last_error(void) { return mpgan::g_err; }
 extern "C" int mpgan_abi_version(void) { return 1; }
+
+// Zero a device buffer on `stream` (the statistics accumulators of a plan, once per forward).
+extern "C" int mpgan_zero_bytes(void* ptr, int64_t bytes, void* stream) {
+  if (!ptr || bytes <= 0) {
+    mpgan::set_error("zero_bytes: bad argument");
+    return MPGAN_ERR_INVALID;
+  }
+  hipError_t e = hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    mpgan::set_error("zero_bytes: %s", hipGetErrorString(e));
+    return MPGAN_ERR_HIP;
+  }
+  return MPGAN_OK;
+}

@@ -2,6 +2,7 @@
 // implicit-GEMM kernels: phases of a (transposed) gather, block-id decoding, host-side builders.
 #pragma once
 #include "mpgan_common.h"
+#include "norm_fold.h"
 
 namespace mpgan {
 
@@ -33,6 +34,9 @@ struct GatherConv {
   int phase_outer;      // block order: 1 = phase slowest, 0 = phases of an m-tile adjacent (see conv_block_id)
   int ksplit;           // > 1: each block covers a K slice and leaves raw partial sums in kpartial
   float* kpartial;      // [ksplit][N*Do*Ho*Wo][Cout]
+  long long* stats_acc;  // fixed-point statistics accumulators [acc_rep][4][Cout] instead of `stats` rows (norm_fold.h)
+  int acc_rep;
+  NormFold fold;         // consumer side: fold the producer's accumulators into the prologue's scale / shift
   int in_bf16, out_bf16; // thin (VALU) kernels of the bf16 path: `in` / `out` point at bf16 data (weights stay fp32)
   Phase ph[8];
 };

@@ -109,7 +109,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
         orow[cov[tn]] = v;
       }
     }
-  if (p.stats) {
+  if (p.stats || p.stats_acc) {
     // Fused BatchNorm statistics of z = acc + bias over this tile's valid rows.  Rows without
     // an output pixel carry acc == 0 exactly (their A rows are zero-filled), so the raw column
     // sums S1 = sum(acc), S2 = sum(acc^2) need no row test; the bias enters in closed form,
@@ -164,9 +164,15 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
       }
       const float nv = (float)(nvp[0] + nvp[1]);
       const float b = p.bias ? p.bias[n0 + tid] : 0.f;
+      if (p.stats_acc) {
+        long long* rep = p.stats_acc + (long)(blockIdx.x % (unsigned)p.acc_rep) * ACC_WORDS * Cout;
+        acc_add(rep, Cout, 0, n0 + tid, sm + nv * b);
+        acc_add(rep, Cout, 2, n0 + tid, sq + b * (2.f * sm + nv * b));
+      } else {
       float* row = p.stats + (long)stats_row * 2 * Cout;
       row[n0 + tid] = sm + nv * b;
       row[Cout + n0 + tid] = sq + b * (2.f * sm + nv * b);
+      }
     }
   }
 }
@@ -926,7 +932,7 @@ __global__ __launch_bounds__(256) void thin_cin1_full_kernel(const GatherConv p)
   const unsigned m = blockIdx.x * 256u + threadIdx.x;
   const PixDecode d = decode_pixel(p, ph, m < Mtot ? m : 0u);
   const bool valid = m < Mtot && d.opix >= 0;
-  if (!valid && !p.stats) return;            // with fused statistics every thread reaches the block reduction
+  if (!valid && !p.stats && !p.stats_acc) return;   // with fused statistics every thread reaches the block reduction
   float4 acc[CQ];
 #pragma unroll
   for (int q = 0; q < CQ; ++q)
@@ -981,7 +987,7 @@ __global__ __launch_bounds__(256) void thin_cin1_full_kernel(const GatherConv p)
     }
     }
   }
-  if (p.stats) {
+  if (p.stats || p.stats_acc) {
     // Fused BatchNorm statistics (raw output incl. bias; the host forbids resid/tanh with them): the block's
     // 256 pixel rows go through LDS [256][CO+1], then 2*CO threads sum one column each in row order.
     float* sred = wl + ((T * CO + 3) & ~3);
@@ -1009,7 +1015,10 @@ __global__ __launch_bounds__(256) void thin_cin1_full_kernel(const GatherConv p)
       float tt = 0.f;
 #pragma unroll
       for (int k = 0; k < RG; ++k) tt += sred[k * (2 * CO) + threadIdx.x];
-      p.stats[((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * CO + sq * CO + c] = tt;
+      if (p.stats_acc)
+        acc_add(p.stats_acc + (long)(blockIdx.x % (unsigned)p.acc_rep) * ACC_WORDS * CO, CO, sq ? 2 : 0, c, tt);
+      else
+        p.stats[((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * CO + sq * CO + c] = tt;
     }
   }
 }
@@ -1123,14 +1132,21 @@ __global__ __launch_bounds__(256) void convt_quad_cout1_kernel(const GatherConv 
       p.out[pix * p.ldo] = v;
     }
   }
-  if (p.stats) {                                // fused BatchNorm statistics of the single output channel
+  if (p.stats || p.stats_acc) {                 // fused BatchNorm statistics of the single output channel
     __shared__ float ws1[4], ws2[4];
     const float s1 = wave_sum(sv), s2 = wave_sum(sv * sv);
     if ((threadIdx.x & 63) == 0) { ws1[threadIdx.x >> 6] = s1; ws2[threadIdx.x >> 6] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      p.stats[2 * (long)blockIdx.x] = ws1[0] + ws1[1] + ws1[2] + ws1[3];
-      p.stats[2 * (long)blockIdx.x + 1] = ws2[0] + ws2[1] + ws2[2] + ws2[3];
+      const float t1 = ws1[0] + ws1[1] + ws1[2] + ws1[3], t2 = ws2[0] + ws2[1] + ws2[2] + ws2[3];
+      if (p.stats_acc) {
+        long long* rep = p.stats_acc + (long)(blockIdx.x % (unsigned)p.acc_rep) * ACC_WORDS;
+        acc_add(rep, 1, 0, 0, t1);
+        acc_add(rep, 1, 2, 0, t2);
+      } else {
+        p.stats[2 * (long)blockIdx.x] = t1;
+        p.stats[2 * (long)blockIdx.x + 1] = t2;
+      }
     }
   }
 }
@@ -1207,11 +1223,11 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
     const bool full = v4 && (p.Cout == 16 || p.Cout == 32 || p.Cout == 64) &&
                       (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) &&
                       (!p.resid || ((p.ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0));
-    MPGAN_UNSUPPORTED(p.stats && !(full && p.Cout <= 32),
+    MPGAN_UNSUPPORTED((p.stats || p.stats_acc) && !(full && p.Cout <= 32),
                       "thin conv: fused statistics need the all-channel kernel (Cout 16 or 32, 16-byte aligned output/bias)");
     if (full) {
       dim3 grid((unsigned)((maxM + 255) / 256), 1, (unsigned)p.nphase);
-      const size_t smem = ((size_t)((T * p.Cout + 3) & ~3) + (p.stats ? 256 * (size_t)(p.Cout + 1) : 0)) * sizeof(float);
+      const size_t smem = ((size_t)((T * p.Cout + 3) & ~3) + ((p.stats || p.stats_acc) ? 256 * (size_t)(p.Cout + 1) : 0)) * sizeof(float);
       if (p.Cout == 16) hipLaunchKernelGGL(thin_cin1_full_kernel<4>, grid, dim3(256), smem, st, p);
       else if (p.Cout == 32) hipLaunchKernelGGL(thin_cin1_full_kernel<8>, grid, dim3(256), smem, st, p);
       else hipLaunchKernelGGL(thin_cin1_full_kernel<16>, grid, dim3(256), smem, st, p);
@@ -1227,7 +1243,7 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
     return check_launch("thin_cin1");
   }
   const int lanes = p.Cin / 4;
-  MPGAN_UNSUPPORTED(p.stats && !convt_quad_ok(p),
+  MPGAN_UNSUPPORTED((p.stats || p.stats_acc) && !convt_quad_ok(p),
                     "thin conv: fused statistics of a 1-channel output exist for ConvTranspose2d(C -> 1, k3 s2) only");
   if (convt_quad_ok(p)) {
     const long qthreads = (long)p.N * p.Hi * p.Wi * lanes;
@@ -1623,6 +1639,11 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   float* wl = lds;
   float* patch = lds + pl.w_floats;
   float* stslots = patch + pl.patch_floats;          // [nph][4 waves][2][32]
+  float* fold_sc = stslots + nph * 256;              // [CIN] scale, [CIN] shift, then 4*CIN long long of scratch (fold only)
+  float* fold_sh = fold_sc + CIN;
+  const bool folding = PRO != 0 && p.fold.acc != nullptr;
+  const bool want_stats = p.stats != nullptr || p.stats_acc != nullptr;
+  float tot_a = 0.f, tot_b = 0.f;                    // this block's sums over all its tiles (accumulator form)
   const float* __restrict__ gw = p.wp;
   const int cq = tid & (CQ - 1);
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1662,6 +1683,13 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
     }
   }
 
+  if (folding) {   // BatchNorm of the producer, finalised here instead of by a launch of its own (norm_fold.h)
+    fold_stats_block(p.fold, CIN, reinterpret_cast<long long*>(fold_sh + CIN), fold_sc, fold_sh, tid, 256, blockIdx.x == 0);
+    if constexpr (PRO != 0) {
+      sc = *reinterpret_cast<const float4*>(fold_sc + 4 * cq);
+      sh = *reinterpret_cast<const float4*>(fold_sh + 4 * cq);
+    }
+  }
   float4 pv[LU];
   unsigned pok = 0;
   int ln = 0;                                         // sample of the tile held in pv (per-sample prologue vectors)
@@ -1695,8 +1723,10 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   };
   auto store_patch = [&]() {
     if constexpr (PRO != 0) {
-      sc = *reinterpret_cast<const float4*>(p.pro.scale + (long)ln * p.pro.n_stride + 4 * cq);
-      sh = *reinterpret_cast<const float4*>(p.pro.shift + (long)ln * p.pro.n_stride + 4 * cq);
+      if (!folding) {
+        sc = *reinterpret_cast<const float4*>(p.pro.scale + (long)ln * p.pro.n_stride + 4 * cq);
+        sh = *reinterpret_cast<const float4*>(p.pro.shift + (long)ln * p.pro.n_stride + 4 * cq);
+      }
     }
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
@@ -1847,16 +1877,16 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
           swrite = kq == 0;
         }
       }
-      if (p.stats && swrite) {                        // a dead phase leaves sm = sq = 0 in its slots
+      if (want_stats && swrite) {                     // a dead phase leaves sm = sq = 0 in its slots
         st[(wid * 2 + 0) * 32 + scol] = sm;
         st[(wid * 2 + 1) * 32 + scol] = sq;
-      } else if (p.stats && !live && lane < 32) {
+      } else if (want_stats && !live && lane < 32) {
         st[(wid * 2 + 0) * 32 + lane] = 0.f;
         st[(wid * 2 + 1) * 32 + lane] = 0.f;
       }
     }
     __syncthreads();                                  // every wave is done with the patch; statistics slots are complete
-    if (p.stats && tid < Cout) {
+    if (want_stats && tid < Cout) {
       for (int phase = 0; phase < nph; ++phase) {
         const float* st = stslots + phase * 256;
         float a = 0.f, b = 0.f;
@@ -1865,13 +1895,23 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
           a += st[(w * 2 + 0) * 32 + tid];
           b += st[(w * 2 + 1) * 32 + tid];
         }
-        float* row = p.stats + ((long)t * nph + phase) * 2 * Cout;
-        row[tid] = a;
-        row[Cout + tid] = b;
+        if (p.stats_acc) {
+          tot_a += a;
+          tot_b += b;
+        } else {
+          float* row = p.stats + ((long)t * nph + phase) * 2 * Cout;
+          row[tid] = a;
+          row[Cout + tid] = b;
+        }
       }
     }
     if (tn < ntiles) store_patch();
     __syncthreads();
+  }
+  if (p.stats_acc && tid < Cout) {                   // one set of atomics per block, whatever its number of tiles
+    long long* rep = p.stats_acc + (long)(blockIdx.x % (unsigned)p.acc_rep) * ACC_WORDS * Cout;
+    acc_add(rep, Cout, 0, tid, tot_a);
+    acc_add(rep, Cout, 2, tid, tot_b);
   }
 }
 
@@ -2039,7 +2079,7 @@ static bool patch_persist_plan(const GatherConv& p, const PatchLaunch& pl, Patch
   int pf = PH * PW * PC;
   out->patch_floats = (pf + 3) & ~3;
   const int nph = pl.merged ? p.nphase : 1;
-  const long bytes = ((long)out->w_floats + out->patch_floats + nph * 256) * 4;
+  const long bytes = ((long)out->w_floats + out->patch_floats + nph * 256 + 2 * p.Cin + 8 * p.Cin + 4) * 4;   // + fold scratch
   if (bytes > 150 * 1024) return false;
   *smem = (int)bytes;
   *ntiles = pl.tiles_x * pl.tiles_y * p.N;
@@ -2058,7 +2098,11 @@ static int launch_patch(const GatherConv& p, const PatchLaunch& pl, int smem, hi
   {
     PatchLaunch pp;
     int psmem = 0, ntiles = 0, grid = 0;
-    if (patch_persist_plan(p, pl, &pp, &psmem, &ntiles, &grid)) {
+    const bool persist = patch_persist_plan(p, pl, &pp, &psmem, &ntiles, &grid);
+    MPGAN_UNSUPPORTED(!persist && (p.fold.acc || p.stats_acc),
+                      "gather_patch: accumulator statistics / fold-on-load need the persistent patch kernel "
+                      "(mpgan_conv_acc_supported / mpgan_conv_fold_supported said otherwise?)");
+    if (persist) {
       switch (p.Cin) {
         case 16: return launch_patch_persist_cin<16>(p, pp, psmem, ntiles, grid, st);
         case 32: return launch_patch_persist_cin<32>(p, pp, psmem, ntiles, grid, st);
@@ -2210,7 +2254,12 @@ static int launch_gather(const GatherConv& p, hipStream_t st) {
                   "gather_conv: more than 2^31 pixels");
   MPGAN_CHECK_ARG((long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx < (1L << 31), "gather_conv: weight larger than 2^31");
   const int variant = select_variant(p, maxM, thin_cin1_ok(p), thin_cout1_ok(p));
-  if (variant <= 2) return launch_thin(p, maxM, st);
+  MPGAN_UNSUPPORTED(p.fold.acc && (p.pro.n_stride != 0 || p.fold.cstride < p.Cin),
+                    "gather_conv: fold-on-load is per channel (BatchNorm) over >= Cin accumulator columns");
+  if (variant <= 2) {
+    MPGAN_UNSUPPORTED(p.fold.acc != nullptr, "thin conv: no fold-on-load");
+    return launch_thin(p, maxM, st);
+  }
   {
     PatchLaunch pl;
     int smem = 0;
@@ -2224,6 +2273,7 @@ static int launch_gather(const GatherConv& p, hipStream_t st) {
                                             "aligned operands (the partial-row count differs otherwise)");
     }
   }
+  MPGAN_UNSUPPORTED(p.fold.acc != nullptr, "gather_conv: fold-on-load is served by the persistent patch kernel only");
   const bool vec = (p.Cin % 4 == 0) && (p.ldi % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0) &&
                    (!p.pro.scale || (((reinterpret_cast<uintptr_t>(p.pro.scale) |
@@ -2253,6 +2303,7 @@ static int launch_gather(const GatherConv& p, hipStream_t st) {
 using namespace mpgan;
 
 extern "C" int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward_data, int32_t has_prologue);
+extern "C" int32_t mpgan_conv_acc_supported(const mpgan_conv_geom* g, int32_t has_prologue);
 
 static void build_for_forward(GatherConv& p, const mpgan_conv_geom* g) {
   if (!g->transposed)
@@ -2329,26 +2380,87 @@ extern "C" int32_t mpgan_conv_stats_rows(const mpgan_conv_geom* g, int32_t has_p
   return (int32_t)((max_phase_pixels(p) + BM - 1) / BM) * p.nphase;
 }
 
-extern "C" int mpgan_conv_forward(const mpgan_conv_geom* g, const float* x, int32_t ldx, const float* w_packed,
-                                  const float* bias, const mpgan_prologue* pro, const float* resid, int32_t ldr,
-                                  int32_t tanh_out, float* stats_partials, float* y, int32_t ldy, void* stream) {
+extern "C" int mpgan_conv_forward_fold(const mpgan_conv_geom* g, const float* x, int32_t ldx, const float* w_packed,
+                                       const float* bias, const mpgan_prologue* pro, const mpgan_norm_fold* fold,
+                                       const float* resid, int32_t ldr, int32_t tanh_out, float* stats_partials,
+                                       int64_t* stats_acc, int32_t acc_replicas, float* y, int32_t ldy, void* stream) {
   int rc = check_geom(g);
   if (rc) return rc;
   MPGAN_CHECK_ARG(x && w_packed && y, "conv_forward: null pointer");
   MPGAN_CHECK_ARG(ldx >= g->cin && ldy >= g->cout && (!resid || ldr >= g->cout), "conv_forward: bad pitch");
+  MPGAN_CHECK_ARG(!(stats_partials && stats_acc), "conv_forward: partial rows OR accumulators, not both");
   GatherConv p{};
   p.in = x; p.wp = w_packed; p.out = y; p.bias = bias; p.resid = resid;
   p.pro = make_pro(pro);
+  p.fold = make_fold(fold);
+  if (p.fold.acc) {
+    MPGAN_CHECK_ARG(pro != nullptr && fold->scale && fold->shift && fold->mean && fold->invstd && fold->replicas > 0 &&
+                        fold->count > 0,
+                    "conv_forward: fold-on-load needs a prologue (activation) and output vectors");
+    p.pro.scale = fold->scale;      // marks "has a per-channel prologue" for dispatch; the kernel folds instead of reading it
+    p.pro.shift = fold->shift;
+    p.pro.n_stride = 0;
+  }
   p.ldi = ldx; p.ldo = ldy; p.ldr = ldr; p.tanh_out = tanh_out;
   build_for_forward(p, g);
-  if (stats_partials) {
+  if (stats_partials || stats_acc) {
     MPGAN_CHECK_ARG(!resid && !tanh_out, "conv_forward: fused statistics describe the raw conv output (no resid/tanh)");
-    MPGAN_UNSUPPORTED(mpgan_conv_stats_rows(g, pro && pro->scale ? (pro->n_stride ? 2 : 1) : 0) == 0,
-                      "conv_forward: this geometry runs on a thin kernel without fused statistics "
-                      "(mpgan_conv_stats_rows() == 0): use mpgan_channel_stats");
+    const int code = p.pro.scale ? (p.pro.n_stride ? 2 : 1) : 0;
+    if (stats_partials)
+      MPGAN_UNSUPPORTED(mpgan_conv_stats_rows(g, code) == 0,
+                        "conv_forward: this geometry runs on a thin kernel without fused statistics "
+                        "(mpgan_conv_stats_rows() == 0): use mpgan_channel_stats");
+    else
+      MPGAN_UNSUPPORTED(acc_replicas <= 0 || !mpgan_conv_acc_supported(g, code),
+                        "conv_forward: no accumulator statistics for this geometry (mpgan_conv_acc_supported() == 0)");
     p.stats = stats_partials;
+    p.stats_acc = reinterpret_cast<long long*>(stats_acc);
+    p.acc_rep = acc_replicas;
   }
   return launch_gather(p, (hipStream_t)stream);
+}
+
+extern "C" int mpgan_conv_forward(const mpgan_conv_geom* g, const float* x, int32_t ldx, const float* w_packed,
+                                  const float* bias, const mpgan_prologue* pro, const float* resid, int32_t ldr,
+                                  int32_t tanh_out, float* stats_partials, float* y, int32_t ldy, void* stream) {
+  return mpgan_conv_forward_fold(g, x, ldx, w_packed, bias, pro, nullptr, resid, ldr, tanh_out, stats_partials, nullptr,
+                                 0, y, ldy, stream);
+}
+
+// Which kernel would serve this forward conv: shared by the two queries below (geometry only, aligned operands).
+static int forward_kernel_class(const mpgan_conv_geom* g, int32_t has_prologue, bool* persist) {
+  *persist = false;
+  const int v = mpgan_conv_variant(g, 0, has_prologue);
+  if (v == 16 || v == 17) {
+    GatherConv p{};
+    static const float dummy[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
+    p.in = dummy;
+    p.pro = make_pro(nullptr);
+    if (has_prologue) p.pro.scale = dummy;
+    build_for_forward(p, g);
+    p.ldi = g->cin;
+    if (has_prologue == 2) p.pro.n_stride = g->cin;
+    PatchLaunch pl, pp;
+    int smem = 0, psmem = 0, ntiles = 0, grid = 0;
+    if (patch_plan(p, &pl, &smem)) *persist = patch_persist_plan(p, pl, &pp, &psmem, &ntiles, &grid);
+  }
+  return v;
+}
+
+extern "C" int32_t mpgan_conv_acc_supported(const mpgan_conv_geom* g, int32_t has_prologue) {
+  bool persist;
+  const int v = forward_kernel_class(g, has_prologue, &persist);
+  if (v < 0) return 0;
+  if (v == 16 || v == 17) return persist ? 1 : 0;
+  if (v == 1) return (g->cout == 16 || g->cout == 32) ? 1 : 0;
+  if (v == 2) return mpgan_conv_stats_rows(g, has_prologue) > 0 ? 1 : 0;      // the quad kernel of ConvTranspose2d(C -> 1)
+  return 1;                                                                  // K-stepped kernels share conv_epilogue
+}
+
+extern "C" int32_t mpgan_conv_fold_supported(const mpgan_conv_geom* g) {
+  bool persist;
+  const int v = forward_kernel_class(g, 1, &persist);
+  return v == 16 && persist ? 1 : 0;
 }
 
 // y = conv(prologue(x)) + bias with the K axis split over blocks (small output grids).

@@ -7,6 +7,7 @@
 // finalize kernel combines partials in double precision.  No atomics anywhere,
 // so statistics (and therefore the whole forward) are bitwise reproducible.
 #include "mpgan_common.h"
+#include "norm_fold.h"
 
 namespace mpgan {
 
@@ -388,11 +389,17 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __r
 // ---------------------------------------------------------------------------
 // element-wise kernels: grid-stride over (pixel rows x column groups)
 // ---------------------------------------------------------------------------
-template <int V>
+//   FOLD: the z-side scale / shift are folded from the producer's statistics accumulators at block start
+//         (norm_fold.h) instead of being read from a finalize launch's output; block (0, 0) publishes them.
+template <int V, bool FOLD = false>
 __global__ __launch_bounds__(256) void norm_act_add_kernel(const float* __restrict__ z, int ldz, Pro pz,
                                                            const float* __restrict__ r, int ldr, Pro pr, long rows,
                                                            long P, int C, int tanh_out, float* __restrict__ out,
-                                                           int ldo) {
+                                                           int ldo, NormFold fz = NormFold{}) {
+  __shared__ long long fwords[FOLD ? 4 * 256 : 1];
+  __shared__ float fsc[FOLD ? 256 : 1], fsh[FOLD ? 256 : 1];
+  if constexpr (FOLD)
+    fold_stats_block(fz, C, fwords, fsc, fsh, (int)threadIdx.x, 256, blockIdx.x == 0 && blockIdx.y == 0);
   const int CG = C / V, R = 256 / CG;
   const int q = threadIdx.x % CG, rr = threadIdx.x / CG;
   if (rr >= R) return;
@@ -401,8 +408,13 @@ __global__ __launch_bounds__(256) void norm_act_add_kernel(const float* __restri
   float zsc[V], zsh[V], rsc[V], rsh[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    zsc[e] = pz.scale ? pz.scale[n * pz.n_stride + c + e] : 1.f;
-    zsh[e] = pz.scale ? pz.shift[n * pz.n_stride + c + e] : 0.f;
+    if constexpr (FOLD) {
+      zsc[e] = fsc[c + e];
+      zsh[e] = fsh[c + e];
+    } else {
+      zsc[e] = pz.scale ? pz.scale[n * pz.n_stride + c + e] : 1.f;
+      zsh[e] = pz.scale ? pz.shift[n * pz.n_stride + c + e] : 0.f;
+    }
     rsc[e] = pr.scale ? pr.scale[n * pr.n_stride + c + e] : 1.f;
     rsh[e] = pr.scale ? pr.shift[n * pr.n_stride + c + e] : 0.f;
   }
@@ -645,12 +657,44 @@ extern "C" int mpgan_norm_act_add(const float* z, int32_t ldz, const mpgan_prolo
   if (gxa > capa) gxa = capa;
   dim3 grida((unsigned)gxa, (unsigned)n);
   if (vec)
-    hipLaunchKernelGGL(norm_act_add_kernel<4>, grida, dim3(256), 0, (hipStream_t)stream, z, ldz, a, r, ldr, b, rows,
-                       (long)P, c, tanh_out, out, ldo);
+    hipLaunchKernelGGL((norm_act_add_kernel<4, false>), grida, dim3(256), 0, (hipStream_t)stream, z, ldz, a, r, ldr, b,
+                       rows, (long)P, c, tanh_out, out, ldo, NormFold{});
   else
-    hipLaunchKernelGGL(norm_act_add_kernel<1>, grida, dim3(256), 0, (hipStream_t)stream, z, ldz, a, r, ldr, b, rows,
-                       (long)P, c, tanh_out, out, ldo);
+    hipLaunchKernelGGL((norm_act_add_kernel<1, false>), grida, dim3(256), 0, (hipStream_t)stream, z, ldz, a, r, ldr, b,
+                       rows, (long)P, c, tanh_out, out, ldo, NormFold{});
   return check_launch("norm_act_add");
+}
+
+extern "C" int mpgan_norm_act_add_fold(const float* z, int32_t ldz, const mpgan_prologue* pz,
+                                       const mpgan_norm_fold* fold_z, const float* r, int32_t ldr,
+                                       const mpgan_prologue* pr, int32_t n, int64_t P, int32_t c, int32_t tanh_out,
+                                       float* out, int32_t ldo, void* stream) {
+  NormFold fz = make_fold(fold_z);
+  if (!fz.acc) return mpgan_norm_act_add(z, ldz, pz, r, ldr, pr, n, P, c, tanh_out, out, ldo, stream);
+  MPGAN_CHECK_ARG(z && out && pz && n > 0 && P > 0 && c > 0 && ldz >= c && ldo >= c && (!r || ldr >= c) &&
+                      fz.rep > 0 && fz.cstride >= c && fz.cnt > 0 && fz.scale && fz.shift && fz.mean && fz.invstd,
+                  "norm_act_add_fold: bad argument");
+  MPGAN_UNSUPPORTED(c > 256, "norm_act_add_fold: C=%d too wide", c);
+  const bool vec = (c % 4 == 0) && (ldz % 4 == 0) && (ldo % 4 == 0) && aligned16(z) && aligned16(out) &&
+                   (!r || ((ldr % 4 == 0) && aligned16(r)));
+  const long rows = (long)n * P;
+  Pro a = make_pro(pz), b = make_pro(pr);
+  a.scale = fz.scale;            // "has a prologue": the values come from the fold
+  a.shift = fz.shift;
+  a.n_stride = 0;
+  const int CGa = vec ? c / 4 : c;
+  const int Ra = 256 / CGa;
+  long gxa = (P + Ra - 1) / Ra;
+  const long capa = 4096 / n > 1 ? 4096 / n : 1;
+  if (gxa > capa) gxa = capa;
+  dim3 grida((unsigned)gxa, (unsigned)n);
+  if (vec)
+    hipLaunchKernelGGL((norm_act_add_kernel<4, true>), grida, dim3(256), 0, (hipStream_t)stream, z, ldz, a, r, ldr, b,
+                       rows, (long)P, c, tanh_out, out, ldo, fz);
+  else
+    hipLaunchKernelGGL((norm_act_add_kernel<1, true>), grida, dim3(256), 0, (hipStream_t)stream, z, ldz, a, r, ldr, b,
+                       rows, (long)P, c, tanh_out, out, ldo, fz);
+  return check_launch("norm_act_add_fold");
 }
 
 extern "C" int mpgan_norm_bwd_reduce(const float* g, int32_t ldg, const float* z, int32_t ldz,

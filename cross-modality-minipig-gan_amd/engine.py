@@ -86,6 +86,7 @@ def fast_stream(device) -> "torch.cuda.Stream":
 
 _SINGLE_STREAM = bool(os.environ.get("MPGAN_SINGLE_STREAM"))
 _ALWAYS_PACK = bool(os.environ.get("MPGAN_DBG_ALWAYS_PACK"))
+_ACC_STATS = not os.environ.get("MPGAN_DBG_NO_ACC_STATS")     # BatchNorm statistics through accumulators + fold-on-load
 _FUSE_DOWN = not os.environ.get("MPGAN_DBG_NO_FUSE_DOWN")   # ResidualUnit: first conv + residual conv as one launch
 
 
@@ -470,6 +471,21 @@ class NormBuf:
         buf = torch.zeros(6, mm, device=dev)
         self.scale, self.shift, self.mean, self.invstd, self.c1, self.c2 = (buf[i, :m] for i in range(6))
         self.n, self.c, self.instance = n, c, instance
+        # accumulator statistics (csrc/norm_fold.h): set by the plan for layers whose producer and first consumer
+        # both support it; `folded` flips when the first consumer has been emitted
+        self.acc = None            # int64 view [replicas][4][cstride]
+        self.acc_cstride = 0
+        self.acc_count = 0
+        self.norm_mod = None
+        self.folded = False
+
+    def fold(self):
+        """The mpgan_norm_fold the FIRST consumer of these statistics passes; None once they are published."""
+        if self.acc is None or self.folded:
+            return None
+        self.folded = True
+        return ops.make_fold(self.acc, ops.ACC_REPLICAS, self.acc_cstride, self.acc_count, self.norm_mod, self.scale,
+                             self.shift, self.mean, self.invstd)
 
     def prologue(self, act, slope=1.0, slope_t=None) -> Prologue:
         return Prologue(self.scale, self.shift, self.c if self.instance else 0, act, slope, slope_t)
@@ -487,15 +503,26 @@ def _gdesc(g: ConvGeom) -> str:
             f"in{'x'.join(map(str, g.in_dhw))}")
 
 
-def emit_conv_fwd(prog, g: ConvGeom, x, wp, bias, y, pro=None, resid=None, tanh=False, stats=None, lane=0):
+def emit_conv_fwd(prog, g: ConvGeom, x, wp, bias, y, pro=None, resid=None, tanh=False, stats=None, lane=0, fold=None,
+                  stats_acc=None):
+    """fold: mpgan_norm_fold of the producer of x (its statistics are finalised by this launch);
+    stats_acc: int64 accumulators that receive this conv's own statistics instead of partial rows."""
     ops._check_in_out(g, x, y, "plan conv_forward")
     gc = g.c()
     pc = pro.c() if pro is not None else None
-    prog.add("conv_forward", lib().mpgan_conv_forward, C.byref(gc), x.data_ptr(), _ld(x), wp.data_ptr(), _p(bias),
-             C.byref(pc) if pc is not None else None, _p(resid), _ld(resid), int(tanh), _p(stats), y.data_ptr(), _ld(y),
-             keep=(gc, pc, x, wp, bias, y, resid, pro), desc=_gdesc(g),
-             tag=(gather_kernel_name(g, False, pro is not None, bool(pro is not None and pro.n_stride),
-                                     _fast_leaky(pro)), 2.0 * conv_macs(g)), lane=lane)
+    tag = (gather_kernel_name(g, False, pro is not None, bool(pro is not None and pro.n_stride), _fast_leaky(pro)),
+           2.0 * conv_macs(g))
+    if fold is None and stats_acc is None:
+        prog.add("conv_forward", lib().mpgan_conv_forward, C.byref(gc), x.data_ptr(), _ld(x), wp.data_ptr(), _p(bias),
+                 C.byref(pc) if pc is not None else None, _p(resid), _ld(resid), int(tanh), _p(stats), y.data_ptr(),
+                 _ld(y), keep=(gc, pc, x, wp, bias, y, resid, pro), desc=_gdesc(g), tag=tag, lane=lane)
+        return
+    assert stats is None or stats_acc is None
+    prog.add("conv_forward_fold", lib().mpgan_conv_forward_fold, C.byref(gc), x.data_ptr(), _ld(x), wp.data_ptr(),
+             _p(bias), C.byref(pc) if pc is not None else None, C.byref(fold) if fold is not None else None, _p(resid),
+             _ld(resid), int(tanh), _p(stats), _p(stats_acc), ops.ACC_REPLICAS if stats_acc is not None else 0,
+             y.data_ptr(), _ld(y), keep=(gc, pc, fold, x, wp, bias, y, resid, pro, stats_acc), desc=_gdesc(g), tag=tag,
+             lane=lane)
 
 
 def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):
@@ -556,7 +583,7 @@ def emit_norm_stats(prog, z, nb: NormBuf, norm_mod, partials, eps=1e-5, momentum
 
 
 def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod, partials, pro=None, training=True,
-                       eval_norms=None, c_norm=None):
+                       eval_norms=None, c_norm=None, fold=None):
     """Conv whose raw output feeds a norm layer: BatchNorm statistics come out of the
     conv's own epilogue (one finalize launch follows); so do InstanceNorm's when the partial rows
     fall into per-sample groups; otherwise a separate statistics pass runs.  In eval
@@ -565,6 +592,14 @@ def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod,
     ResidualUnit's residual conv: the trailing channels are the un-normalised residual branch)."""
     c = g.cout if c_norm is None else c_norm
     y_norm = y if c_norm is None else y[..., :c]
+    if training and nb.acc is not None:
+        # accumulator statistics: no finalize launch; the first consumer of `nb` folds them (NormBuf.fold)
+        nb.norm_mod = norm_mod
+        nb.acc_cstride = g.cout
+        n_, P_, _ = ops._cl(y, "conv+norm")
+        nb.acc_count = n_ * P_
+        emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro, fold=fold, stats_acc=nb.acc)
+        return
     if not training and not nb.instance:
         emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro)
         if eval_norms is not None:       # input-independent: the plan folds all of them into one launch up front
@@ -589,12 +624,12 @@ def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod,
         if not grouped or rows % n:
             rows = 0
     if rows == 0:
-        emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro)
+        emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro, fold=fold)
         emit_norm_stats(prog, y_norm, nb, norm_mod, partials)
         return
     W = g.cout                                  # partial rows are [2][W] wide
     assert partials.numel() >= (rows + 32) * 2 * W
-    emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro, stats=partials)
+    emit_conv_fwd(prog, g, x, wp, bias, y, pro=pro, stats=partials, fold=fold)
     if nb.instance:
         prog.add("norm_finalize", lib().mpgan_norm_finalize_strided, partials.data_ptr(), n, rows // n, c, W, P, 1,
                  _p(norm_mod.weight), _p(norm_mod.bias), float(norm_mod.eps), 0.0, None, None, None,
@@ -627,14 +662,20 @@ def emit_eval_norms(prog, eval_norms, dev):
              keep=(table, eval_norms))
 
 
-def emit_norm_act_add(prog, z, pz, r, pr, out, tanh=False):
+def emit_norm_act_add(prog, z, pz, r, pr, out, tanh=False, fold=None):
+    """fold: mpgan_norm_fold of z's producer (this launch finalises its statistics)."""
     n, P, ldz = ops._cl(z, "norm_act_add z")
     assert out.shape == z.shape and (r is None or r.shape == z.shape)
     pzc = pz.c() if pz is not None else None
     prc = pr.c() if pr is not None else None
-    prog.add("norm_act_add", lib().mpgan_norm_act_add, z.data_ptr(), ldz, C.byref(pzc) if pzc else None, _p(r), _ld(r),
-             C.byref(prc) if prc else None, n, P, z.shape[-1], int(tanh), out.data_ptr(), _ld(out),
-             keep=(z, pzc, pz, r, prc, pr, out))
+    if fold is None:
+        prog.add("norm_act_add", lib().mpgan_norm_act_add, z.data_ptr(), ldz, C.byref(pzc) if pzc else None, _p(r),
+                 _ld(r), C.byref(prc) if prc else None, n, P, z.shape[-1], int(tanh), out.data_ptr(), _ld(out),
+                 keep=(z, pzc, pz, r, prc, pr, out))
+        return
+    prog.add("norm_act_add_fold", lib().mpgan_norm_act_add_fold, z.data_ptr(), ldz, C.byref(pzc), C.byref(fold), _p(r),
+             _ld(r), C.byref(prc) if prc else None, n, P, z.shape[-1], int(tanh), out.data_ptr(), _ld(out),
+             keep=(z, pzc, pz, fold, r, prc, pr, out))
 
 
 def emit_norm_bwd(prog, g, z, nb: NormBuf, pro: Prologue, dz, partials, dgamma, dbeta, dslope, peer=None):
@@ -842,6 +883,26 @@ class UNetPlan:
                 st["ua"] = E(n, *sizes[l], co)
             up_state.append(st)
         self._late = (down_state, up_state)
+        # Accumulator statistics (csrc/norm_fold.h) for the norm layers whose producing kernel can leave them and
+        # whose first consumer can fold them: no finalize launch for those.  (nb, accumulator row width)
+        self.acc_wants = []
+        if training and not instance and _ACC_STATS:
+            def want(nb, g_prod, code, consumer_ok):
+                if consumer_ok and ops.conv_acc_supported(g_prod, code):
+                    self.acc_wants.append((nb, g_prod.cout))
+            for l in range(L - 1):
+                sdn = down_state[l]
+                want(sdn["nb0"], sdn["gf"] if sdn["gf"] is not None else sdn["g0"], 0, ops.conv_fold_supported(sdn["g1"]))
+                want(sdn["nb1"], sdn["g1"], 1, True)                     # consumer: the residual-sum pass
+            want(nbb0, gb0, 0, ops.conv_fold_supported(gb1))
+            want(nbb1, gb1, 1, True)
+            for l in range(L - 1):
+                u = up_state[l]
+                if "zu" in u:
+                    want(u["nbt"], u["gt"], 0, ops.conv_fold_supported(u["gu"]))
+                    want(u["nbu"], u["gu"], 1, True)
+                else:
+                    want(u["nbt"], u["gt"], 0, True)                     # top level: materialised by the residual-sum pass
         self.scratch = scratch
         self._marks = (own_mark, wait_mark)
         self.eval_norms = [] if not training else None   # eval mode: (norm module, NormBuf, C) of every layer
@@ -881,16 +942,19 @@ class UNetPlan:
                 #  than the ~20 us kernels they would overlap -- G forward 4.42 -> 4.56 ms)
                 emit_conv_fwd(f, s["gr"], s["xin"], wp(R(s["ru"].res)), s["ru"].res.bias, s["r"])
             emit_conv_fwd_norm(f, s["g1"], s["z0"], wp(R(cv1)), cv1.bias, s["z1"], s["nb1"], N1, part,
-                               pro=prelu_pro(s["nb0"], A0), training=tr, eval_norms=self.eval_norms)
-            emit_norm_act_add(f, s["z1"], prelu_pro(s["nb1"], A1), s["r"], None, cats[l][..., :s["c"]])
+                               pro=prelu_pro(s["nb0"], A0), training=tr, eval_norms=self.eval_norms,
+                               fold=s["nb0"].fold())
+            emit_norm_act_add(f, s["z1"], prelu_pro(s["nb1"], A1), s["r"], None, cats[l][..., :s["c"]],
+                              fold=s["nb1"].fold())
         d_last = cats[L - 2][..., :bt["cb_in"]]
         emit_conv_fwd_norm(f, bt["gb0"], d_last, wp(R(bt["bc0"])), bt["bc0"].bias, bt["zb0"], bt["nbb0"], bt["BN0"],
                            part, training=tr, eval_norms=self.eval_norms)
         emit_conv_fwd(f, bt["gbr"], d_last, wp(R(bt["res"])), bt["res"].bias, bt["rb"])
         emit_conv_fwd_norm(f, bt["gb1"], bt["zb0"], wp(R(bt["bc1"])), bt["bc1"].bias, bt["zb1"], bt["nbb1"],
-                           bt["BN1"], part, pro=prelu_pro(bt["nbb0"], bt["BA0"]), training=tr, eval_norms=self.eval_norms)
+                           bt["BN1"], part, pro=prelu_pro(bt["nbb0"], bt["BA0"]), training=tr, eval_norms=self.eval_norms,
+                           fold=bt["nbb0"].fold())
         emit_norm_act_add(f, bt["zb1"], prelu_pro(bt["nbb1"], bt["BA1"]), bt["rb"], None,
-                          cats[L - 2][..., bt["cb_in"]:])
+                          cats[L - 2][..., bt["cb_in"]:], fold=bt["nbb1"].fold())
         for l in range(L - 2, -1, -1):
             u = up_state[l]
             emit_conv_fwd_norm(f, u["gt"], cats[l], wp(R(u["ct"])), u["ct"].bias, u["zt"], u["nbt"], u["NT"], part,
@@ -898,13 +962,13 @@ class UNetPlan:
             pt = prelu_pro(u["nbt"], u["AT"])
             if "zu" in u:
                 emit_conv_fwd_norm(f, u["gu"], u["zt"], wp(R(u["cu"])), u["cu"].bias, u["zu"], u["nbu"], u["NU"], part,
-                                   pro=pt, training=tr, eval_norms=self.eval_norms)
+                                   pro=pt, training=tr, eval_norms=self.eval_norms, fold=u["nbt"].fold())
                 dst = cats[l - 1][..., chans[l - 1]:] if l > 0 else y_out
                 emit_norm_act_add(f, u["zu"], prelu_pro(u["nbu"], u["AU"]), u["zt"], pt, dst,
-                                  tanh=(a["tanh_out"] and l == 0))
+                                  tanh=(a["tanh_out"] and l == 0), fold=u["nbu"].fold())
             else:
                 # top level: conv-only residual unit on the materialised act(bn(zt))
-                emit_norm_act_add(f, u["zt"], pt, None, None, u["ua"])
+                emit_norm_act_add(f, u["zt"], pt, None, None, u["ua"], fold=u["nbt"].fold())
                 emit_conv_fwd(f, u["gu"], u["ua"], wp(R(u["cu"])), u["cu"].bias, y_out, resid=u["ua"],
                               tanh=a["tanh_out"])
         if not a["want_backward"]:
@@ -1044,10 +1108,23 @@ class GeneratorPlan:
                                             gbufs=g, scratch=self.scratch, training=training,
                                             own_mark=marks[u], wait_mark=marks[u + 2] if u + 2 < nU else None))
         self.scratch.alloc()
+        wants = [w for p in self.unet_plans for w in p.acc_wants]
+        self.acc_all = None
+        if wants:
+            total = sum(ops.ACC_REPLICAS * ops.ACC_WORDS * cw for _, cw in wants)
+            self.acc_all = torch.zeros(total, dtype=torch.int64, device=dev)
+            off = 0
+            for nb, cw in wants:
+                sz = ops.ACC_REPLICAS * ops.ACC_WORDS * cw
+                nb.acc = self.acc_all[off:off + sz]
+                off += sz
         for p in self.unet_plans:
             p.emit()
         self.fwd = Program()
         store.emit_pack(self.fwd)
+        if self.acc_all is not None:      # one memset for every norm layer of the forward
+            self.fwd.add("zero_bytes", lib().mpgan_zero_bytes, self.acc_all.data_ptr(), self.acc_all.numel() * 8,
+                         keep=(self.acc_all,))
         if not training:
             emit_eval_norms(self.fwd, [e for p in self.unet_plans for e in p.eval_norms], dev)
         for p in self.unet_plans:

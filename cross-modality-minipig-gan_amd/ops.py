@@ -13,7 +13,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from ._lib import ConvGeomC, PeerTapsC, PrologueC, check, lib
+from ._lib import ConvGeomC, NormFoldC, PeerTapsC, PrologueC, check, lib
 
 ACT_NONE = 0
 ACT_LEAKY = 1
@@ -137,6 +137,34 @@ class PeerTaps:
 
 def _peer(t: Optional[PeerTaps]):
     return None if t is None else C.byref(t.c())
+
+
+ACC_WORDS = 4
+ACC_REPLICAS = 8
+
+
+def conv_acc_supported(g: ConvGeom, has_prologue) -> bool:
+    gc = g.c()
+    return bool(lib().mpgan_conv_acc_supported(C.byref(gc), int(has_prologue)))
+
+
+def conv_fold_supported(g: ConvGeom) -> bool:
+    gc = g.c()
+    return bool(lib().mpgan_conv_fold_supported(C.byref(gc)))
+
+
+def make_fold(acc, replicas, cstride, count, norm_mod, scale, shift, mean, invstd) -> NormFoldC:
+    """mpgan_norm_fold for a torch BatchNorm module's parameters / buffers and a plan's output vectors."""
+    f = NormFoldC()
+    f.acc = acc.data_ptr()
+    f.replicas, f.cstride, f.count = int(replicas), int(cstride), int(count)
+    f.gamma, f.beta = _ptr(norm_mod.weight), _ptr(norm_mod.bias)
+    f.eps, f.momentum = float(norm_mod.eps), float(norm_mod.momentum if norm_mod.momentum is not None else 0.1)
+    f.running_mean = _ptr(getattr(norm_mod, "running_mean", None))
+    f.running_var = _ptr(getattr(norm_mod, "running_var", None))
+    f.num_batches_tracked = _ptr(getattr(norm_mod, "num_batches_tracked", None))
+    f.scale, f.shift, f.mean, f.invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+    return f
 
 
 def _check_in_out(g: ConvGeom, x: torch.Tensor, y: torch.Tensor, what: str):
@@ -625,3 +653,36 @@ def norm_bwd_apply_bf16(g, z, scale, shift, mean, invstd, c1, c2, slope: float, 
                                           c1.data_ptr(), c2.data_ptr(), float(slope), n * P, c, dz.data_ptr(), lddz,
                                           _ptr(bias_partials), _stream()), "norm_bwd_apply_bf16")
     return dz
+
+
+# --------------------------------------------------------------------------
+# BatchNorm statistics through accumulators + fold-on-load (csrc/norm_fold.h)
+# --------------------------------------------------------------------------
+def acc_buffer(c: int, device) -> torch.Tensor:
+    """Zeroed int64 accumulators [ACC_REPLICAS][ACC_WORDS][c] for one norm layer fed by a c-channel conv."""
+    return torch.zeros(ACC_REPLICAS * ACC_WORDS * c, dtype=torch.int64, device=device)
+
+
+def conv_forward_fold(g: ConvGeom, x, w_packed, bias, y, *, pro: Optional[Prologue] = None, fold: Optional[NormFoldC] = None,
+                      resid=None, tanh_out: bool = False, stats_acc=None):
+    _check_in_out(g, x, y, "conv_forward_fold")
+    _, _, ldx = _cl(x, "conv_forward_fold x")
+    _, _, ldy = _cl(y, "conv_forward_fold y")
+    ldr = _cl(resid, "conv_forward_fold resid")[2] if resid is not None else 0
+    gc = g.c()
+    if stats_acc is not None and (stats_acc.dtype != torch.int64 or stats_acc.numel() < ACC_REPLICAS * ACC_WORDS * g.cout):
+        raise ValueError("conv_forward_fold: stats_acc must be int64 [ACC_REPLICAS][4][Cout]")
+    check(lib().mpgan_conv_forward_fold(C.byref(gc), x.data_ptr(), ldx, w_packed.data_ptr(), _ptr(bias), _pro(pro),
+                                        C.byref(fold) if fold is not None else None, _ptr(resid), ldr, int(tanh_out),
+                                        None, _ptr(stats_acc), ACC_REPLICAS if stats_acc is not None else 0,
+                                        y.data_ptr(), ldy, _stream()), "conv_forward_fold")
+    return y
+
+
+def norm_act_add_fold(z, pz: Prologue, fold: NormFoldC, r, pr: Optional[Prologue], out, *, tanh_out=False):
+    n, P, ldz = _cl(z, "norm_act_add_fold z")
+    _, _, ldo = _cl(out, "norm_act_add_fold out")
+    ldr = _cl(r, "norm_act_add_fold r")[2] if r is not None else 0
+    check(lib().mpgan_norm_act_add_fold(z.data_ptr(), ldz, _pro(pz), C.byref(fold), _ptr(r), ldr, _pro(pr), n, P,
+                                        z.shape[-1], int(tanh_out), out.data_ptr(), ldo, _stream()), "norm_act_add_fold")
+    return out

@@ -347,6 +347,48 @@ int mpgan_patch_scatter_add(const float* dpatches, int32_t b, const int32_t dhw[
                             const int32_t* corners, int32_t samples, const int32_t roi[3],
                             float* dvol, void* stream);
 
+/* ---- BatchNorm statistics without a finalize launch (the generator's forward chain) ----------------------
+ * A conv leaves per-channel fixed-point sums (sum y, sum y^2) of its raw output in integer accumulators
+ * `acc` = int64 [replicas][MPGAN_ACC_WORDS][cstride] (zeroed by the caller before the producing launch;
+ * order-independent, hence reproducible); the FIRST consumer of those statistics folds them at block start
+ * (mpgan_norm_fold), publishes scale / shift / mean / invstd and advances the running statistics -- what
+ * mpgan_norm_finalize does, without its launch.  See csrc/norm_fold.h. */
+#define MPGAN_ACC_WORDS 4
+typedef struct {
+  const int64_t* acc;        /* null => no fold: the prologue's own scale / shift are used */
+  int32_t replicas;
+  int32_t cstride;           /* channels per accumulator row (>= the c channels the norm covers) */
+  int64_t count;             /* elements per channel (N*D*H*W) */
+  const float* gamma;
+  const float* beta;
+  float eps, momentum;
+  float* running_mean;       /* nullable */
+  float* running_var;
+  int64_t* num_batches_tracked;
+  float* scale;              /* outputs, written by one block of the consuming launch */
+  float* shift;
+  float* mean;
+  float* invstd;
+} mpgan_norm_fold;
+
+/* Zero `bytes` bytes at ptr on the stream (the accumulators of all norm layers of a plan: one call per forward). */
+int mpgan_zero_bytes(void* ptr, int64_t bytes, void* stream);
+/* 1 if the kernel serving this conv can leave accumulators (stats_acc) / can fold them on load (fold). */
+int32_t mpgan_conv_acc_supported(const mpgan_conv_geom* g, int32_t has_prologue);
+int32_t mpgan_conv_fold_supported(const mpgan_conv_geom* g);
+/* mpgan_conv_forward with either form of statistics on either side: `fold` (nullable) replaces pro->scale/shift
+ * (pro still carries act / slope / slope_ptr); stats_acc (nullable, exclusive with stats_partials) receives this
+ * conv's sums with `acc_replicas` replicas of Cout-wide rows. */
+int mpgan_conv_forward_fold(const mpgan_conv_geom* g, const float* x, int32_t ldx, const float* w_packed,
+                            const float* bias, const mpgan_prologue* pro, const mpgan_norm_fold* fold,
+                            const float* resid, int32_t ldr, int32_t tanh_out, float* stats_partials,
+                            int64_t* stats_acc, int32_t acc_replicas, float* y, int32_t ldy, void* stream);
+/* mpgan_norm_act_add whose z-side scale / shift come from accumulators (fold_z; pz carries act / slope). */
+int mpgan_norm_act_add_fold(const float* z, int32_t ldz, const mpgan_prologue* pz, const mpgan_norm_fold* fold_z,
+                            const float* r, int32_t ldr, const mpgan_prologue* pr, int32_t n,
+                            int64_t pixels_per_sample, int32_t c, int32_t tanh_out, float* out, int32_t ldo,
+                            void* stream);
+
 /* ---- bf16 storage path (BASELINE config C5: the reference's own 3-D graph, GAN_final.py:106-114,167-189) ----
  * Activations, activation gradients and packed weights are bf16 in HBM (void* below); products accumulate in fp32
  * on v_mfma_f32_32x32x16_bf16; BatchNorm statistics, parameters, weight gradients and Adam stay fp32.

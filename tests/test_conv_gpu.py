@@ -435,3 +435,86 @@ def test_residual_unit_first_conv_and_residual_conv_as_one_launch(cin, c, spatia
     assert_close(net["bn"].running_mean.cpu(), rm, what="running_mean")
     assert_close(net["bn"].running_var.cpu(), rv, rtol=1e-4, what="running_var")
     assert int(net["bn"].num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("cin,c,k,s,spatial,transposed", [
+    (16, 16, 3, 1, (40, 56), False), (32, 32, 3, 1, (24, 40), False), (1, 32, 3, 2, (48, 64), False),
+    (64, 128, 3, 1, (16, 16), False), (64, 16, 3, 2, (12, 20), True), (32, 1, 3, 2, (20, 28), True)])
+def test_batchnorm_statistics_through_accumulators_and_fold_on_load(cin, c, k, s, spatial, transposed):
+    """csrc/norm_fold.h: the producing conv adds its per-block (sum, sum^2) to int64 fixed-point accumulators;
+    the FIRST consumer folds them at block start -- here (a) the residual-sum pass, (b) a following 3x3 conv with
+    the load prologue where the persistent patch kernel serves it -- publishes scale / shift / mean / invstd and
+    advances the running statistics.  Same numbers as F.batch_norm (train) on the conv output; order-independent,
+    so two runs agree bit for bit."""
+    import torch.nn as nn
+    from mpgan_amd import ops
+    n = 4
+    gen = torch.Generator().manual_seed(31 + cin + c)
+    x = torch.rand(n, cin, *spatial, generator=gen) * 2 - 1
+    if transposed:
+        w = (torch.rand(cin, c, k, k, generator=gen) - 0.5) / (cin * k * k) ** 0.5
+        b = torch.rand(c, generator=gen) - 0.5
+        z_ref = F.conv_transpose2d(x, w, b, stride=s, padding=1, output_padding=s - 1)
+    else:
+        w = (torch.rand(c, cin, k, k, generator=gen) - 0.5) / (cin * k * k) ** 0.5
+        b = torch.rand(c, generator=gen) - 0.5
+        z_ref = F.conv2d(x, w, b, stride=s, padding=1)
+    g = _geom(2, n, cin, c, k, s, 1, spatial, transposed=transposed)
+    assert ops.conv_acc_supported(g, 0)
+    bn = nn.BatchNorm2d(c).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    gamma, beta = bn.weight.detach().cpu(), bn.bias.detach().cpu()
+    alpha = 0.25
+    y_ref = F.batch_norm(z_ref, torch.zeros(c), torch.ones(c), gamma, beta, True, 0.1, 1e-5)
+    a_ref = torch.where(y_ref > 0, y_ref, alpha * y_ref)
+    wp = ops.pack_weight(w.cuda(), transposed=transposed)
+    slope = torch.tensor([alpha], device="cuda")
+    outs = []
+    for rep in range(2):
+        z = torch.full((n, *g.out_dhw, c), float("nan"), device="cuda")
+        acc = ops.acc_buffer(c, "cuda")
+        ops.conv_forward_fold(g, to_cl(x), wp, b.cuda(), z, stats_acc=acc)
+        assert_close(from_cl(z, 2), z_ref, what="conv output")
+        vec = [torch.full((c,), float("nan"), device="cuda") for _ in range(4)]
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
+        P = n * g.out_dhw[1] * g.out_dhw[2]
+        fold = ops.make_fold(acc, ops.ACC_REPLICAS, c, P, bn, *vec)
+        pro = ops.Prologue(vec[0], vec[1], 0, ops.ACT_LEAKY, 1.0, slope)
+        out = torch.full_like(z, float("nan"))
+        r = torch.rand(z_ref.shape, generator=torch.Generator().manual_seed(5)) - 0.5
+        ops.norm_act_add_fold(z, pro, fold, to_cl(r), None, out)
+        assert_close(from_cl(out, 2), a_ref + r, rtol=1e-4, what="act(bn(z)) + r through the fold")
+        y = from_cl(z, 2) * vec[0].cpu()[None, :, None, None] + vec[1].cpu()[None, :, None, None]
+        assert_close(y, y_ref, rtol=1e-4, what="published scale/shift")
+        rm, rv = torch.zeros(c), torch.ones(c)
+        F.batch_norm(z_ref, rm, rv, gamma, beta, True, 0.1, 1e-5)
+        assert_close(bn.running_mean.cpu(), rm, what="running_mean")
+        assert_close(bn.running_var.cpu(), rv, rtol=1e-4, what="running_var")
+        assert int(bn.num_batches_tracked) == 1
+        outs.append((acc.clone(), vec[0].clone(), vec[1].clone(), out.clone()))
+    for t0, t1 in zip(outs[0], outs[1]):
+        assert torch.equal(t0, t1), "accumulator statistics must not depend on block arrival order"
+    # (b) the next conv folds on load
+    g2 = _geom(2, n, c, c, 3, 1, 1, g.out_dhw[1:])
+    if c >= 16 and ops.conv_fold_supported(g2):
+        w2 = (torch.rand(c, c, 3, 3, generator=gen) - 0.5) / (c * 9) ** 0.5
+        z2_ref = F.conv2d(a_ref, w2, None, padding=1)
+        acc = ops.acc_buffer(c, "cuda")
+        z = torch.empty(n, *g.out_dhw, c, device="cuda")
+        ops.conv_forward_fold(g, to_cl(x), wp, b.cuda(), z, stats_acc=acc)
+        vec = [torch.full((c,), float("nan"), device="cuda") for _ in range(4)]
+        fold = ops.make_fold(acc, ops.ACC_REPLICAS, c, n * g.out_dhw[1] * g.out_dhw[2], bn, *vec)
+        pro = ops.Prologue(vec[0], vec[1], 0, ops.ACT_LEAKY, 1.0, slope)
+        acc2 = ops.acc_buffer(c, "cuda")
+        z2 = torch.full((n, *g2.out_dhw, c), float("nan"), device="cuda")
+        ops.conv_forward_fold(g2, z, ops.pack_weight(w2.cuda()), None, z2, pro=pro, fold=fold, stats_acc=acc2)
+        assert_close(from_cl(z2, 2), z2_ref, rtol=5e-4, what="conv with fold-on-load prologue")
+        assert torch.isfinite(vec[2]).all() and torch.isfinite(vec[3]).all()
+        # ... and its own accumulators hold the sums of its output
+        A = acc2.view(ops.ACC_REPLICAS, 4, c).sum(0).double().cpu()
+        s1 = A[0] / 256.0 + A[1] / 2.0 ** 56
+        s2 = A[2] / 256.0 + A[3] / 2.0 ** 56
+        assert_close(s1.float(), z2_ref.double().sum((0, 2, 3)).float(), rtol=1e-4, what="accumulated sum")
+        assert_close(s2.float(), (z2_ref.double() ** 2).sum((0, 2, 3)).float(), rtol=1e-4, what="accumulated sum of squares")

@@ -86,7 +86,13 @@ def fast_stream(device) -> "torch.cuda.Stream":
 
 _SINGLE_STREAM = bool(os.environ.get("MPGAN_SINGLE_STREAM"))
 _ALWAYS_PACK = bool(os.environ.get("MPGAN_DBG_ALWAYS_PACK"))
-_ACC_STATS = not os.environ.get("MPGAN_DBG_NO_ACC_STATS")     # BatchNorm statistics through accumulators + fold-on-load
+# BatchNorm statistics through integer accumulators + fold-on-load in the first consumer (csrc/norm_fold.h) instead of
+# partial rows + a finalize launch.  Built, tested and MEASURED: the 66 finalize launches it
+# removes from a generator forward (4.7-6.3 us each + a ~1.5 us boundary) are paid back in full by what it adds to
+# every block of the neighbouring kernels -- the fold's load -> barrier -> double-precision finalize -> barrier sits on
+# each consumer block's critical path (+3.6-5 us per launch) and the atomics on the producer's tail (+1-4 us) -- and
+# same-address atomics make a 1-channel layer 8x slower (convt_quad: 28 -> 225 us).  Off unless MPGAN_ACC_STATS=1.
+_ACC_STATS = bool(os.environ.get("MPGAN_ACC_STATS"))
 _FUSE_DOWN = not os.environ.get("MPGAN_DBG_NO_FUSE_DOWN")   # ResidualUnit: first conv + residual conv as one launch
 
 

@@ -87,6 +87,8 @@ SIGNATURES = {
     "mpgan_percentile_workspace": (_L, []),
     "mpgan_percentiles": (_I, [_P, _L, C.POINTER(C.c_double), _I, _P, _L, _P, _P]),
     "mpgan_scale_intensity_range": (_I, [_P, _L, _P, _F, _F, _I, _P, _P]),
+    "mpgan_resample_to_identity_grid": (_I, [_P, _I3, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                             _I3, C.c_double, _P, _P]),
     "mpgan_ssim_workspace": (_L, [_I3]),
     "mpgan_ssim": (_I, [_P, _P, _I3, _F, _P, _L, _P, _P]),
     "mpgan_adam_step": (_I, [_P, _P, _P, _P, _L, C.c_double, C.c_double, C.c_double, C.c_double, _I, _F, _P]),

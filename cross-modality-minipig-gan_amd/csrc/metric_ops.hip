@@ -428,3 +428,95 @@ extern "C" int mpgan_scale_intensity_range(const float* x, int64_t numel, const 
                      a_minmax, b_min, b_max, clip, y);
   return check_launch("scale_intensity_range");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Resampling onto the 256 mm identity grid (next-row N3, code/GAN/transforms.py:79-213: ResampleT1T2d =
+// itk.resample_image_filter(identity transform, LinearInterpolateImageFunction, reference image with
+// origin = -size/2, spacing = 256/size, identity direction), default pixel 0).  ITK is not in this image; the
+// kernel restates ITK 5's published algorithm:
+//   p   = origin_out + i * spacing_out                         (output physical point, identity direction)
+//   c   = (Direction_in * diag(spacing_in))^-1 (p - origin_in)  (continuous index into the input)
+//   inside  <=>  -0.5 <= c_d < size_d - 0.5 for every d        (ImageFunction::IsInsideBuffer)
+//   value   = trilinear interpolation at c, the base index clamped to [0, size-1] and a neighbour beyond the last
+//             index dropped (LinearInterpolateImageFunction::EvaluateOptimized), else 0.
+// One thread per output voxel: an HBM/L2-bound gather (8 reads, 1 write).
+// ---------------------------------------------------------------------------------------------------
+struct ResampleGeom {
+  double m[9];        // inverse of Direction*diag(spacing), row-major, in ITK (x, y, z) order
+  double origin_in[3];
+  double origin_out[3], spacing_out[3];
+  int in_size[3];     // (x, y, z)
+  int out_size[3];
+};
+
+__global__ __launch_bounds__(256) void resample_linear_kernel(const float* __restrict__ in, ResampleGeom g,
+                                                              float* __restrict__ out) {
+  const long total = (long)g.out_size[0] * g.out_size[1] * g.out_size[2];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ox = (int)(i % g.out_size[0]);
+    const long q = i / g.out_size[0];
+    const int oy = (int)(q % g.out_size[1]), oz = (int)(q / g.out_size[1]);
+    const double d0 = g.origin_out[0] + ox * g.spacing_out[0] - g.origin_in[0];
+    const double d1 = g.origin_out[1] + oy * g.spacing_out[1] - g.origin_in[1];
+    const double d2 = g.origin_out[2] + oz * g.spacing_out[2] - g.origin_in[2];
+    double c[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) c[r] = g.m[3 * r] * d0 + g.m[3 * r + 1] * d1 + g.m[3 * r + 2] * d2;
+    bool inside = true;
+    int b[3];
+    double f[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      inside = inside && c[d] >= -0.5 && c[d] < (double)g.in_size[d] - 0.5;
+      int bi = (int)floor(c[d]);
+      if (bi < 0) bi = 0;
+      b[d] = bi;
+      double fr = c[d] - (double)bi;
+      if (fr < 0.0) fr = 0.0;                       // c in [-0.5, 0): the base sample alone
+      if (bi + 1 > g.in_size[d] - 1) fr = 0.0;      // no neighbour beyond the last index
+      f[d] = fr;
+    }
+    float v = 0.f;
+    if (inside) {
+      const long sx = 1, sy = g.in_size[0], sz = (long)g.in_size[0] * g.in_size[1];
+      const long base = b[0] * sx + b[1] * sy + b[2] * sz;
+      const long ax = f[0] > 0.0 ? sx : 0, ay = f[1] > 0.0 ? sy : 0, az = f[2] > 0.0 ? sz : 0;
+      const double v000 = in[base], v100 = in[base + ax], v010 = in[base + ay], v110 = in[base + ax + ay];
+      const double v001 = in[base + az], v101 = in[base + ax + az], v011 = in[base + ay + az],
+                   v111 = in[base + ax + ay + az];
+      const double x00 = v000 + f[0] * (v100 - v000), x10 = v010 + f[0] * (v110 - v010);
+      const double x01 = v001 + f[0] * (v101 - v001), x11 = v011 + f[0] * (v111 - v011);
+      const double y0 = x00 + f[1] * (x10 - x00), y1 = x01 + f[1] * (x11 - x01);
+      v = (float)(y0 + f[2] * (y1 - y0));
+    }
+    out[i] = v;
+  }
+}
+
+extern "C" int mpgan_resample_to_identity_grid(const float* vol, const int32_t* in_dhw, const double* origin_xyz,
+                                               const double* spacing_xyz, const double* direction_3x3,
+                                               const int32_t* out_dhw, double extent_mm, float* out, void* stream) {
+  MPGAN_CHECK_ARG(vol && in_dhw && origin_xyz && spacing_xyz && direction_3x3 && out_dhw && out && extent_mm > 0,
+                  "resample: null argument");
+  ResampleGeom g;
+  double a[9];   // A = Direction * diag(spacing)
+  for (int d = 0; d < 3; ++d) {
+    MPGAN_CHECK_ARG(in_dhw[d] > 0 && out_dhw[d] > 0 && spacing_xyz[d] > 0, "resample: bad size / spacing in dim %d", d);
+    g.in_size[d] = in_dhw[2 - d];               // arrays are (z, y, x); ITK indexes (x, y, z)
+    g.out_size[d] = out_dhw[2 - d];
+    g.origin_in[d] = origin_xyz[d];
+    g.origin_out[d] = -0.5 * g.out_size[d];      // transforms.py:144: SetOrigin(-output_size / 2)
+    g.spacing_out[d] = extent_mm / g.out_size[d];
+    for (int r = 0; r < 3; ++r) a[3 * r + d] = direction_3x3[3 * r + d] * spacing_xyz[d];
+  }
+  const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+  MPGAN_CHECK_ARG(det != 0.0, "resample: singular direction matrix");
+  g.m[0] = (a[4] * a[8] - a[5] * a[7]) / det; g.m[1] = (a[2] * a[7] - a[1] * a[8]) / det; g.m[2] = (a[1] * a[5] - a[2] * a[4]) / det;
+  g.m[3] = (a[5] * a[6] - a[3] * a[8]) / det; g.m[4] = (a[0] * a[8] - a[2] * a[6]) / det; g.m[5] = (a[2] * a[3] - a[0] * a[5]) / det;
+  g.m[6] = (a[3] * a[7] - a[4] * a[6]) / det; g.m[7] = (a[1] * a[6] - a[0] * a[7]) / det; g.m[8] = (a[0] * a[4] - a[1] * a[3]) / det;
+  const long total = (long)out_dhw[0] * out_dhw[1] * out_dhw[2];
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(resample_linear_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, vol, g, out);
+  return check_launch("resample_to_identity_grid");
+}

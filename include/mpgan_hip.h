@@ -317,6 +317,15 @@ int mpgan_percentiles(const float* x, int64_t numel, const double* q_host, int32
 int mpgan_scale_intensity_range(const float* x, int64_t numel, const float* a_minmax, float b_min,
                                 float b_max, int32_t clip, float* y, void* stream);
 
+/* ResampleT1T2d (code/GAN/transforms.py:79-213) on arrays: linear-interpolation resampling of `vol` (contiguous
+ * (D,H,W) fp32 with ITK geometry origin / spacing in (x,y,z) order and a row-major 3x3 direction matrix) onto
+ * the identity-direction reference grid the transform builds: out_dhw voxels, origin = -size/2, spacing =
+ * extent_mm / size (extent_mm = 256 in the reference), identity transform, default pixel 0.  Restates ITK 5's
+ * ResampleImageFilter + LinearInterpolateImageFunction (ITK is not installable here: parity unpinned). */
+int mpgan_resample_to_identity_grid(const float* vol, const int32_t* in_dhw, const double* origin_xyz,
+                                    const double* spacing_xyz, const double* direction_3x3, const int32_t* out_dhw,
+                                    double extent_mm, float* out, void* stream);
+
 /* Mean structural similarity of two slices (dhw[0] == 1: 7x7 window) or volumes (dhw[0] >= 7: 7x7x7),
  * the algorithm skimage.metrics.structural_similarity runs with the arguments psnr_ssim_metric.py:91-92
  * passes (data_range only): uniform window, K1 = 0.01, K2 = 0.03, sample covariance, mean over the

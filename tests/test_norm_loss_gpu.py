@@ -289,3 +289,31 @@ def test_scale_intensity_range_percentiles_matches_monai_restatement():
     want2 = scale_intensity_range_percentiles(vol.astype(np.float64), 5, 95, 0.0, 255.0, clip=False)
     got2 = preprocess.scale_intensity_range_percentiles(torch.from_numpy(vol).cuda(), 5, 95, 0.0, 255.0, False)
     np.testing.assert_allclose(got2.cpu().numpy(), want2, rtol=1e-5, atol=1e-3)
+
+
+def test_resample_to_identity_grid_matches_restatement():
+    """Next-row N3, second half: `ResampleT1T2d` (code/GAN/transforms.py:79-213) on arrays.  ITK is absent, so the
+    kernel is held to an independent numpy restatement of ITK's published algorithm (oracle/resample_ref.py;
+    PARITY UNPINNED against ITK itself) on an anisotropic, rotated, off-centre geometry, plus two properties that
+    need no reference: an input that already lives on the reference grid comes back unchanged, and everything
+    outside the input's half-voxel border is the default pixel 0."""
+    from mpgan_amd import preprocess
+    from oracle import resample_ref
+    gen = torch.Generator().manual_seed(21)
+    vol = torch.rand(36, 48, 40, generator=gen) * 100
+    th = 0.2
+    direction = [[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]]
+    origin, spacing = (-70.0, -95.0, -60.0), (3.4, 4.1, 3.2)
+    for out_size in ((32, 32, 32), (48, 40, 24)):
+        ref = resample_ref.resample_to_identity_grid(vol.numpy(), origin, spacing, direction, out_size)
+        got = preprocess.resample_to_identity_grid(vol.cuda(), origin, spacing, direction, out_size).cpu().numpy()
+        assert got.shape == tuple(reversed(out_size))
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-4)
+        assert (ref == 0).any() and (ref != 0).any()                 # the geometry exercises both sides of the border
+    size = (24, 20, 16)                                              # (x, y, z) on the reference grid itself
+    v2 = torch.rand(size[2], size[1], size[0], generator=gen)
+    sp = [256.0 / s for s in size]
+    same = preprocess.resample_to_identity_grid(v2.cuda(), [-s / 2 for s in size], sp, np.eye(3).tolist(), size).cpu()
+    np.testing.assert_allclose(same.numpy(), v2.numpy(), rtol=0, atol=1e-6)
+    far = preprocess.resample_to_identity_grid(v2.cuda(), (1000.0, 1000.0, 1000.0), sp, np.eye(3).tolist(), size)
+    assert float(far.abs().max()) == 0.0

@@ -1282,6 +1282,7 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
 // Rows: wave w owns tile rows 2w, 2w+1; lane operand maps as in the kernels above.
 // ---------------------------------------------------------------------------
 constexpr int PT_H = 8, PT_W = 16;
+__device__ float g_patch_zero_page[64];   // what the persistent patch kernel's padding chunks load
 
 struct PatchLaunch {
   int tiles_x, tiles_y;
@@ -1293,6 +1294,8 @@ struct PatchLaunch {
   int merged, ylo, yhi, xlo, xhi, stats_off;
   FastDiv fPWm, fKx;
   int w_floats;          // persistent form: LDS floats of the staged weights (the patch follows them)
+  int pca, pcw;          // persistent form: LDS pitch (floats) of a patch pixel / of a weight row
+  const void* zero_page; // persistent form: >= 16 bytes of zeros in global memory (padding reads it)
 };
 
 //   MERGE : one block walks ALL phases of its tile (strided backward-data / transposed convs): the
@@ -1612,10 +1615,13 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
                                                                    const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  constexpr int PC = CIN + 4;
   constexpr int CQ = CIN / 4;
   constexpr int LU = CIN == 16 ? 9 : 12;      // patch chunks per thread: the WHOLE patch of a tile in one round (host checks)
   constexpr int WU = 4;
+  // LDS pitches (floats per pixel / per weight row), chosen by the host so that the fragments' ds_read_b128 are
+  // conflict-free: CIN + 8 for the 16x16x4 form (CIN + 4 cost 61 % of the LDS cycles in bank conflicts there,
+  // rocprofv3 SQ_LDS_BANK_CONFLICT), CIN + 4 for the 32x32x2 form.
+  const int PCA = pl.pca, PCW = pl.pcw;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int Cout = p.Cout;
@@ -1678,11 +1684,10 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
 #pragma unroll
       for (int u = 0; u < WU; ++u) {
         const int idx = base + u * 256 + tid;
-        if (idx < wtotal) *reinterpret_cast<float4*>(wl + (idx / CQ) * PC + 4 * cq) = wv[u];
+        if (idx < wtotal) *reinterpret_cast<float4*>(wl + (idx / CQ) * PCW + 4 * cq) = wv[u];
       }
     }
   }
-
   if (folding) {   // BatchNorm of the producer, finalised here instead of by a launch of its own (norm_fold.h)
     fold_stats_block(p.fold, CIN, reinterpret_cast<long long*>(fold_sh + CIN), fold_sc, fold_sh, tid, 256, blockIdx.x == 0);
     if constexpr (PRO != 0) {
@@ -1690,6 +1695,20 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
       sh = *reinterpret_cast<const float4*>(fold_sh + 4 * cq);
     }
   }
+
+  // ---- this thread's patch chunks: position inside the patch, decoded ONCE (the same for every tile) ----
+  // pyx: (py << 16) | px, or -1 for a slot past the patch; per tile a chunk then costs a range test, two
+  // multiply-adds and a select instead of a software division (the staging was the bulk of the 9.5 vector
+  // instructions per MFMA this kernel family showed in SQ_INSTS_VALU / SQ_INSTS_MFMA).
+  int pyx[LU];
+#pragma unroll
+  for (int u = 0; u < LU; ++u) {
+    const int idx = u * 256 + tid;
+    unsigned py, px;
+    fdivmod((unsigned)idx / (unsigned)CQ, fPW, py, px);
+    pyx[u] = idx < total ? (int)((py << 16) | px) : -1;
+  }
+  const float* zero4 = reinterpret_cast<const float*>(pl.zero_page);   // 16 bytes of zeros in global memory
   float4 pv[LU];
   unsigned pok = 0;
   int ln = 0;                                         // sample of the tile held in pv (per-sample prologue vectors)
@@ -1705,20 +1724,15 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
     decode(t, n, my0, mx0);
     ln = n;
     const int y0 = my0 * isy + ylo, x0 = mx0 * isx + xlo;
-    const float* __restrict__ gin = p.in + (long)n * Hi * Wi * ldi;
+    const float* __restrict__ gin = p.in + (long)n * Hi * Wi * ldi + 4 * cq;
     pok = 0;
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
-      const int idx = u * 256 + tid;
-      const unsigned pix = (unsigned)idx / (unsigned)CQ;
-      unsigned py, px;
-      fdivmod(pix, fPW, py, px);
-      const int iy = y0 + (int)py, ix = x0 + (int)px;
-      const unsigned ok = (idx < total ? 1u : 0u) & ((unsigned)iy < (unsigned)Hi ? 1u : 0u) &
-                          ((unsigned)ix < (unsigned)Wi ? 1u : 0u);
-      const long off = ok ? ((long)iy * Wi + ix) * ldi + 4 * cq : 0;
-      pv[u] = *reinterpret_cast<const float4*>(gin + off);
-      pok |= ok << u;
+      const int iy = y0 + (pyx[u] >> 16), ix = x0 + (pyx[u] & 0xffff);
+      const bool ok = pyx[u] >= 0 && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+      const float* src = ok ? gin + (iy * Wi + ix) * ldi : zero4;      // padding reads the zero page
+      pv[u] = *reinterpret_cast<const float4*>(src);
+      if constexpr (PRO != 0) pok |= (ok ? 1u : 0u) << u;              // act(0*scale + shift) != 0: masked after the prologue
     }
   };
   auto store_patch = [&]() {
@@ -1730,17 +1744,17 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
     }
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
-      const int idx = u * 256 + tid;
       float4 x = pv[u];
       if constexpr (PRO != 0) {
         x.x = act_apply(x.x * sc.x + sh.x, act, slope);
         x.y = act_apply(x.y * sc.y + sh.y, act, slope);
         x.z = act_apply(x.z * sc.z + sh.z, act, slope);
         x.w = act_apply(x.w * sc.w + sh.w, act, slope);
+        const bool ok = (pok >> u) & 1u;
+        x.x = ok ? x.x : 0.f; x.y = ok ? x.y : 0.f; x.z = ok ? x.z : 0.f; x.w = ok ? x.w : 0.f;
       }
-      const bool ok = (pok >> u) & 1u;
-      x.x = ok ? x.x : 0.f; x.y = ok ? x.y : 0.f; x.z = ok ? x.z : 0.f; x.w = ok ? x.w : 0.f;
-      if (idx < total) *reinterpret_cast<float4*>(patch + (idx / CQ) * PC + 4 * cq) = x;
+      if (pyx[u] >= 0)
+        *reinterpret_cast<float4*>(patch + ((pyx[u] >> 16) * PW + (pyx[u] & 0xffff)) * PCA + 4 * cq) = x;
     }
   };
 
@@ -1771,6 +1785,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
       int scol = 0;
       bool swrite = false;
       if (live) {
+        // (32-bit element offsets in the epilogues below: the host admits only outputs below 2^31 elements)
         if constexpr (!NARROW) {
           const int li = lane & 31, lh = lane >> 5;
           f32x16 acc;
@@ -1778,14 +1793,14 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
           {
             const int tyl = 2 * wid + (li >> 4), txl = li & 15;
-            const float* Arow = patch + ((tyl * isy - ylo) * PW + (txl * isx - xlo)) * PC + 4 * lh;
-            const float* Brow = wl + (li < Cout ? li : 0) * PC + 4 * lh;
+            const float* Arow = patch + ((tyl * isy - ylo) * PW + (txl * isx - xlo)) * PCA + 4 * lh;
+            const float* Brow = wl + (li < Cout ? li : 0) * PCW + 4 * lh;
             for (int jy = 0; jy < ny; ++jy) {
               const int dy = ph.dy0 + dsy * jy;
               for (int jx = 0; jx < nx; ++jx) {
                 const int dx = ph.dx0 + dsx * jx;
-                const float* A = Arow + (dy * PW + dx) * PC;
-                const float* B = Brow + (MERGE ? (ph.ky0 + p.kstep[1] * jy) * p.Kx + ph.kx0 + p.kstep[2] * jx : jy * nx + jx) * Cout * PC;
+                const float* A = Arow + (dy * PW + dx) * PCA;
+                const float* B = Brow + (MERGE ? (ph.ky0 + p.kstep[1] * jy) * p.Kx + ph.kx0 + p.kstep[2] * jx : jy * nx + jx) * Cout * PCW;
 #pragma unroll
                 for (int g = 0; g < CIN / 8; ++g) {
                   const float4 a = *reinterpret_cast<const float4*>(A + 8 * g);
@@ -1800,20 +1815,26 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
           }
           const int co = li;
           const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+          // register r of lane (li, lh) is m-row 2*wid + (r >> 3), m-column 4*lh + (r & 3) + 8*((r >> 2) & 1)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int my = my0 + 2 * wid + (rl >> 4), mx = mx0 + (rl & 15);
-            const int oy = my * osy + ph.oy, ox = mx * osx + ph.ox;
-            const bool ok = my < My && mx < Mx && oy < p.Ho && ox < p.Wo && co < Cout;
-            if (ok) {
-              const long pix = ((long)n * p.Ho + oy) * p.Wo + ox;
-              float v = acc[r] + bv;
-              sm += v;
-              sq += v * v;
-              if (gres) v += gres[pix * ldr + co];
-              if (tanh_out) v = tanhf(v);
-              gout[pix * ldo + co] = v;
+          for (int rh = 0; rh < 2; ++rh) {
+            const int my = my0 + 2 * wid + rh, oy = my * osy + ph.oy;
+            const bool rowok = my < My && oy < p.Ho && co < Cout;
+            const int rowbase = ((n * p.Ho + oy) * p.Wo + ph.ox) ;
+#pragma unroll
+            for (int rq = 0; rq < 8; ++rq) {
+              const int r = rh * 8 + rq;
+              const int mx = mx0 + 4 * lh + (rq & 3) + 8 * (rq >> 2);
+              const int ox = mx * osx;
+              if (rowok && mx < Mx && ox + ph.ox < p.Wo) {
+                const int pix = rowbase + ox;
+                float v = acc[r] + bv;
+                sm += v;
+                sq += v * v;
+                if (gres) v += gres[pix * ldr + co];
+                if (tanh_out) v = tanhf(v);
+                gout[pix * ldo + co] = v;
+              }
             }
           }
           sm += __shfl_xor(sm, 32, 64);
@@ -1824,15 +1845,15 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
           const int l16 = lane & 15, kq = lane >> 4;
           f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
           {
-            const float* A0row = patch + (((2 * wid) * isy - ylo) * PW + (l16 * isx - xlo)) * PC + 4 * kq;
-            const float* A1row = A0row + isy * PW * PC;
-            const float* Brow = wl + (l16 < Cout ? l16 : 0) * PC + 4 * kq;
+            const float* A0row = patch + (((2 * wid) * isy - ylo) * PW + (l16 * isx - xlo)) * PCA + 4 * kq;
+            const float* A1row = A0row + isy * PW * PCA;
+            const float* Brow = wl + (l16 < Cout ? l16 : 0) * PCW + 4 * kq;
             for (int jy = 0; jy < ny; ++jy) {
               const int dy = ph.dy0 + dsy * jy;
               for (int jx = 0; jx < nx; ++jx) {
                 const int dx = ph.dx0 + dsx * jx;
-                const int aoff = (dy * PW + dx) * PC;
-                const float* B = Brow + (MERGE ? (ph.ky0 + p.kstep[1] * jy) * p.Kx + ph.kx0 + p.kstep[2] * jx : jy * nx + jx) * Cout * PC;
+                const int aoff = (dy * PW + dx) * PCA;
+                const float* B = Brow + (MERGE ? (ph.ky0 + p.kstep[1] * jy) * p.Kx + ph.kx0 + p.kstep[2] * jx : jy * nx + jx) * Cout * PCW;
 #pragma unroll
                 for (int g = 0; g < CIN / 16; ++g) {
                   const float4 a0 = *reinterpret_cast<const float4*>(A0row + aoff + 16 * g);
@@ -1853,14 +1874,16 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
           const int co = l16;
           const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+          for (int mt = 0; mt < 2; ++mt) {
+            const int my = my0 + 2 * wid + mt, oy = my * osy + ph.oy;
+            const bool rowok = my < My && oy < p.Ho && co < Cout;
+            const int rowbase = (n * p.Ho + oy) * p.Wo + ph.ox;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int my = my0 + 2 * wid + mt, mx = mx0 + 4 * kq + r;
-              const int oy = my * osy + ph.oy, ox = mx * osx + ph.ox;
-              const bool ok = my < My && mx < Mx && oy < p.Ho && ox < p.Wo && co < Cout;
-              if (ok) {
-                const long pix = ((long)n * p.Ho + oy) * p.Wo + ox;
+              const int mx = mx0 + 4 * kq + r;
+              const int ox = mx * osx;
+              if (rowok && mx < Mx && ox + ph.ox < p.Wo) {
+                const int pix = rowbase + ox;
                 float v = (mt == 0 ? acc0[r] : acc1[r]) + bv;
                 sm += v;
                 sq += v * v;
@@ -1869,6 +1892,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
                 gout[pix * ldo + co] = v;
               }
             }
+          }
           sm += __shfl_xor(sm, 16, 64);
           sq += __shfl_xor(sq, 16, 64);
           sm += __shfl_xor(sm, 32, 64);
@@ -2074,10 +2098,21 @@ static bool patch_persist_plan(const GatherConv& p, const PatchLaunch& pl, Patch
   }
   const int LU = p.Cin == 16 ? 9 : 12;
   if (PH * PW * CQ > LU * 256) return false;
+  if (PH > 0xffff || PW > 0xffff) return false;
+  // 32-bit element offsets in the kernel
+  if ((long)p.N * p.Ho * p.Wo * (p.ldo > p.ldr ? p.ldo : p.ldr) >= (1L << 31) || (long)p.Hi * p.Wi * p.ldi >= (1L << 31)) return false;
   *out = pl;
-  out->w_floats = (wtaps * p.Cout * PC + 3) & ~3;
-  int pf = PH * PW * PC;
+  const bool narrow = p.Cout <= 16;
+  out->pcw = narrow ? p.Cin + 8 : PC;                                   // see the kernel: conflict-free ds_read_b128
+  out->pca = narrow ? (p.istride[2] == 1 ? p.Cin + 8 : p.Cin + 4) : PC;
+  out->w_floats = (wtaps * p.Cout * out->pcw + 3) & ~3;
+  int pf = PH * PW * out->pca;
   out->patch_floats = (pf + 3) & ~3;
+  {
+    static void* zp = nullptr;          // address of the device-side zero page, looked up once
+    if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_patch_zero_page)) != hipSuccess) { zp = nullptr; return false; }
+    out->zero_page = zp;
+  }
   const int nph = pl.merged ? p.nphase : 1;
   const long bytes = ((long)out->w_floats + out->patch_floats + nph * 256 + 2 * p.Cin + 8 * p.Cin + 4) * 4;   // + fold scratch
   if (bytes > 150 * 1024) return false;

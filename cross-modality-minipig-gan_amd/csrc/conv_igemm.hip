@@ -1296,6 +1296,9 @@ struct PatchLaunch {
   int w_floats;          // persistent form: LDS floats of the staged weights (the patch follows them)
   int pca, pcw;          // persistent form: LDS pitch (floats) of a patch pixel / of a weight row
   const void* zero_page; // persistent form: >= 16 bytes of zeros in global memory (padding reads it)
+  FastDiv fTx, fTy;      // persistent form: tile index -> (sample, tile row, tile column)
+  int stagger;           // persistent form: sleep (x 64 clocks) per dispatch round before a block starts (see the kernel)
+  int dbg;               // MPGAN_DBG_PATCH_SKIP bits (what-if timing builds): 1 no output stores, 2 no MFMAs, 4 no patch loads, 8 no LDS patch stores
 };
 
 //   MERGE : one block walks ALL phases of its tile (strided backward-data / transposed convs): the
@@ -1701,23 +1704,28 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   // multiply-adds and a select instead of a software division (the staging was the bulk of the 9.5 vector
   // instructions per MFMA this kernel family showed in SQ_INSTS_VALU / SQ_INSTS_MFMA).
   int pyx[LU];
+  const int nu = (total + 255) / 256;       // register slots in use: the rest of the unrolled loops is skipped (block-uniform)
 #pragma unroll
   for (int u = 0; u < LU; ++u) {
-    const int idx = u * 256 + tid;
-    unsigned py, px;
-    fdivmod((unsigned)idx / (unsigned)CQ, fPW, py, px);
-    pyx[u] = idx < total ? (int)((py << 16) | px) : -1;
+    pyx[u] = -1;
+    if (u < nu) {
+      const int idx = u * 256 + tid;
+      unsigned py, px;
+      fdivmod((unsigned)idx / (unsigned)CQ, fPW, py, px);
+      pyx[u] = idx < total ? (int)((py << 16) | px) : -1;
+    }
   }
   const float* zero4 = reinterpret_cast<const float*>(pl.zero_page);   // 16 bytes of zeros in global memory
   float4 pv[LU];
   unsigned pok = 0;
   int ln = 0;                                         // sample of the tile held in pv (per-sample prologue vectors)
   auto decode = [&](int t, int& n, int& my0, int& mx0) {
-    const int tx = t % pl.tiles_x;
-    const int q = t / pl.tiles_x;
-    my0 = (q % pl.tiles_y) * PT_H;
-    mx0 = tx * PT_W;
-    n = q / pl.tiles_y;
+    unsigned q, tx, ty, nn;
+    fdivmod((unsigned)t, pl.fTx, q, tx);
+    fdivmod(q, pl.fTy, nn, ty);
+    my0 = (int)ty * PT_H;
+    mx0 = (int)tx * PT_W;
+    n = (int)nn;
   };
   auto load_patch = [&](int t) {
     int n, my0, mx0;
@@ -1728,9 +1736,11 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
     pok = 0;
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
+      if (u >= nu) break;
       const int iy = y0 + (pyx[u] >> 16), ix = x0 + (pyx[u] & 0xffff);
       const bool ok = pyx[u] >= 0 && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
       const float* src = ok ? gin + (iy * Wi + ix) * ldi : zero4;      // padding reads the zero page
+      if (pl.dbg & 4) src = zero4;
       pv[u] = *reinterpret_cast<const float4*>(src);
       if constexpr (PRO != 0) pok |= (ok ? 1u : 0u) << u;              // act(0*scale + shift) != 0: masked after the prologue
     }
@@ -1744,6 +1754,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
     }
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
+      if (u >= nu) break;
       float4 x = pv[u];
       if constexpr (PRO != 0) {
         x.x = act_apply(x.x * sc.x + sh.x, act, slope);
@@ -1753,7 +1764,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
         const bool ok = (pok >> u) & 1u;
         x.x = ok ? x.x : 0.f; x.y = ok ? x.y : 0.f; x.z = ok ? x.z : 0.f; x.w = ok ? x.w : 0.f;
       }
-      if (pyx[u] >= 0)
+      if (pyx[u] >= 0 && !(pl.dbg & 8))
         *reinterpret_cast<float4*>(patch + ((pyx[u] >> 16) * PW + (pyx[u] & 0xffff)) * PCA + 4 * cq) = x;
     }
   };
@@ -1763,6 +1774,13 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   const int ldo = p.ldo, ldr = p.ldr, tanh_out = p.tanh_out;
   const int osy = p.ostride[1], osx = p.ostride[2];
 
+  // De-phase the blocks that share a CU (dispatch deals the first 256 blocks one per CU, then the next 256, ...):
+  // identical blocks started together stay in lockstep -- all staging, then all contracting -- and leave the matrix
+  // pipe idle while they stage.  pl.stagger x 64 clocks of sleep per dispatch round (0: off).
+  if (pl.stagger > 0) {
+    const int rounds = (int)(blockIdx.x >> 8);
+    for (int i = 0; i < rounds * pl.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   int t = (int)blockIdx.x;
   if (t < ntiles) {
     load_patch(t);
@@ -1778,7 +1796,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
     for (int phase = 0; phase < nph; ++phase) {
       const Phase& ph = p.ph[phase];
       const int My = ph.Mz > 0 ? ph.My : 0, Mx = ph.Mx;
-      const int ny = ph.nz > 0 ? ph.ny : 0, nx = ph.nx;
+      const int ny = (ph.nz > 0 && !(pl.dbg & 2)) ? ph.ny : 0, nx = ph.nx;
       float* st = stslots + phase * 256;
       const bool live = my0 < My && mx0 < Mx;          // block-uniform
       float sm = 0.f, sq = 0.f;
@@ -1833,7 +1851,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
                 sq += v * v;
                 if (gres) v += gres[pix * ldr + co];
                 if (tanh_out) v = tanhf(v);
-                gout[pix * ldo + co] = v;
+                if (!(pl.dbg & 1)) gout[pix * ldo + co] = v;
               }
             }
           }
@@ -1889,7 +1907,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
                 sq += v * v;
                 if (gres) v += gres[pix * ldr + co];
                 if (tanh_out) v = tanhf(v);
-                gout[pix * ldo + co] = v;
+                if (!(pl.dbg & 1)) gout[pix * ldo + co] = v;
               }
             }
           }
@@ -2109,6 +2127,12 @@ static bool patch_persist_plan(const GatherConv& p, const PatchLaunch& pl, Patch
   int pf = PH * PW * out->pca;
   out->patch_floats = (pf + 3) & ~3;
   {
+    out->fTx = make_fastdiv((unsigned)pl.tiles_x);
+    out->fTy = make_fastdiv((unsigned)pl.tiles_y);
+    static const int dbg_skip = getenv("MPGAN_DBG_PATCH_SKIP") ? atoi(getenv("MPGAN_DBG_PATCH_SKIP")) : 0;
+    out->dbg = dbg_skip;
+    static const int stag = getenv("MPGAN_DBG_PATCH_STAGGER") ? atoi(getenv("MPGAN_DBG_PATCH_STAGGER")) : 0;
+    out->stagger = stag;
     static void* zp = nullptr;          // address of the device-side zero page, looked up once
     if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_patch_zero_page)) != hipSuccess) { zp = nullptr; return false; }
     out->zero_page = zp;

@@ -1538,3 +1538,94 @@ class PatchDiscPlan:
             self.tap_g_logit.zero_()
             self.tap_g_prob.zero_()
         self.peer = None
+        if getattr(self, "ext_used", False):
+            self.clear_ext()
+
+    # ---- external gradients on materialised taps (the reference's own perceptual_loss body on TapDict values) ----
+    def _ext_buffers(self):
+        if not hasattr(self, "gext"):
+            # per conv layer: gradients arriving on (z, y, a) = (conv out, norm out, activation) as channels-last tensors
+            self.gext = [[torch.zeros_like(z) for _ in range(3)] for z in self.zs]
+            self.ext_used = False
+        return self.gext
+
+    def deposit_tap_grad(self, key: int, g: torch.Tensor):
+        """Gradient of one of the 16 taps (NC(D)HW, as TapSet.materialize returned it)."""
+        if not hasattr(self, "gas"):
+            raise RuntimeError("this discriminator pass was run without a backward (no gradient can flow into its taps)")
+        ge = self._ext_buffers()
+        n = self.n
+        if key < 12 or key == 12:
+            i, kind = (3, 2) if key == 12 else divmod(key, 3)
+            z = self.zs[i]
+            gg = g.reshape(n, z.shape[-1], *z.shape[1:4])                     # NCDHW (2-D taps: D = 1)
+            ge[i][kind].add_(gg.permute(0, 2, 3, 4, 1))
+        elif key == 13:
+            self.tap_g_h.view(n, -1).add_(g.reshape(n, -1))
+        elif key == 14:
+            self.tap_g_logit.add_(g.reshape(-1))
+        else:
+            self.tap_g_prob.add_(g.reshape(-1))
+        self.ext_used = True
+
+    def clear_ext(self):
+        if hasattr(self, "gext"):
+            for trio in self.gext:
+                for t in trio:
+                    t.zero_()
+        self.ext_used = False
+
+    def backward_program_ext(self, peer: Optional["PatchDiscPlan"]) -> Program:
+        """backward_program with the external tap gradients folded in, layer by layer:
+            g_a += G_a;  dz = BNbwd_act(g_a) + BNbwd_identity(G_y) + G_z
+        (BatchNorm's backward is linear in the gradient of its output, so the y-tap's gradient goes through a
+        second norm-backward with an identity activation; both add into dgamma / dbeta).  A compatibility path
+        built from the existing kernels: three extra element-wise passes per layer."""
+        key = ("ext", id(peer) if peer is not None else 0)
+        if key in self._bwd_cache:
+            return self._bwd_cache[key]
+        ge = self._ext_buffers()
+        store, L = self.store, lib()
+        part, ws = self.scratch.partials, self.scratch.ws
+        gv = store.grad_view if self.want_param_grads else (lambda p: None)
+        b = Program()
+        n = self.n
+        add = lambda dst, src: b.add("axpby", L.mpgan_axpby, dst.data_ptr(), 1.0, src.data_ptr(), 1.0, dst.numel(),
+                                     dst.data_ptr(), keep=(dst, src))
+        b.add("axpby", L.mpgan_axpby, self.g_prob.data_ptr(), 1.0, self.tap_g_prob.data_ptr(), 1.0, n,
+              self.g_prob.data_ptr())
+        b.add("sigmoid_backward", L.mpgan_sigmoid_backward, self.g_prob.data_ptr(), self.prob.data_ptr(), n,
+              self.dlogit.data_ptr())
+        b.add("axpby", L.mpgan_axpby, self.dlogit.data_ptr(), 1.0, self.tap_g_logit.data_ptr(), 1.0, n,
+              self.dlogit.data_ptr())
+        if self.want_param_grads:
+            emit_conv_wgrad(b, self.g_l2, self.h, self.dlogit, gv(self.lin2.weight), ws, dbias=gv(self.lin2.bias))
+        emit_conv_dgrad(b, self.g_l2, self.dlogit, store.wp_bwd(self.r_l2), self.dh, resid=self.tap_g_h)
+        pro4 = self.lrelu(self.nbs[-1])
+        if self.want_param_grads:
+            emit_conv_wgrad(b, self.g_l1, self.zs[-1], self.dh, gv(self.lin1.weight), ws, pro=pro4,
+                            dbias=gv(self.lin1.bias))
+        emit_conv_fwd(b, self.g_l1_bwd, self.dh, store.wp_tco(self.r_l1), None, self.gas[-1].view(n, 1, 1, 1, -1))
+        for i in range(len(self.convs) - 1, -1, -1):
+            pr = None
+            if peer is not None:
+                pr = ops.PeerTaps(peer.zs[i], peer.nbs[i].scale, peer.nbs[i].shift, self.coef[i])
+            gz, gy, ga = ge[i]
+            add(self.gas[i], ga)
+            emit_norm_bwd(b, self.gas[i], self.zs[i], self.nbs[i], self.lrelu(self.nbs[i]), self.gas[i], part,
+                          gv(self.bns[i].weight), gv(self.bns[i].bias), None, peer=pr)
+            emit_norm_bwd(b, gy, self.zs[i], self.nbs[i], self.nbs[i].prologue(ACT_NONE), gy, part,
+                          gv(self.bns[i].weight), gv(self.bns[i].bias), None)
+            add(self.gas[i], gy)
+            add(self.gas[i], gz)
+            src = self.zs[i - 1] if i > 0 else self.x_in
+            pro_in = self.lrelu(self.nbs[i - 1]) if i > 0 else None
+            if self.want_param_grads:
+                emit_conv_wgrad(b, self.geoms[i], src, self.gas[i], gv(self.convs[i].weight), ws, pro=pro_in,
+                                dbias=gv(self.convs[i].bias))
+            if i > 0:
+                emit_conv_dgrad(b, self.geoms[i], self.gas[i], store.wp_bwd(self.recs[i]), self.gas[i - 1])
+            elif self.want_input_grad:
+                emit_conv_dgrad(b, self.geoms[0], self.gas[0], store.wp_bwd(self.recs[0]), self.g_x)
+        self._bwd_cache[key] = b
+        return b

@@ -125,10 +125,14 @@ class _PerceptualFn(torch.autograd.Function):
 def perceptual_loss(y_hat_activations, y_activations):
     """test_runs/GAN.py:288-298 (y_hat = fake taps, y = real taps)."""
     assert set(y_activations.keys()) == set(y_hat_activations.keys())
-    if not isinstance(y_hat_activations, TapDict) or not isinstance(y_activations, TapDict):
-        raise TypeError("perceptual_loss expects the tap dicts returned by mpgan_amd's PatchDiscriminator")
-    tf, tr = y_hat_activations.tapset, y_activations.tapset
-    return _PerceptualFn.apply(tf.handle, tr.handle, tf, tr)
+    if isinstance(y_hat_activations, TapDict) and isinstance(y_activations, TapDict):
+        tf, tr = y_hat_activations.tapset, y_activations.tapset      # fused: the 16 taps are never materialised
+        return _PerceptualFn.apply(tf.handle, tr.handle, tf, tr)
+    # any other mapping of tensors (e.g. taps a caller materialised or detached): the reference's own body
+    running_sum = torch.zeros(1, device=y_hat_activations[0].device, dtype=y_hat_activations[0].dtype)
+    for key in y_activations.keys():
+        running_sum = running_sum + torch.nn.functional.l1_loss(y_activations[key], y_hat_activations[key]) / y_activations[key].numel()
+    return running_sum
 
 
 class GAN(nn.Module):

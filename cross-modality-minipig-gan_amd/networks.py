@@ -372,12 +372,50 @@ class TapSet:
         return plan.prob.reshape(n, 1).clone()
 
 
+class _TapFn(torch.autograd.Function):
+    """One perceptual tap as a real tensor (what the reference's Discriminator.forward returns with
+    `.clone()`, test_runs/GAN.py:183-198), connected to the discriminator pass through the TapSet's handle:
+    its gradient is deposited into the plan's external-tap buffers, which the pass's backward then feeds
+    through the BatchNorm / conv chain (PatchDiscPlan.backward_program_ext)."""
+
+    @staticmethod
+    def forward(ctx, handle, tapset, key):
+        ctx.tapset, ctx.key = tapset, key
+        return tapset.materialize(key)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.tapset.plan.deposit_tap_grad(ctx.key, g)
+        return torch.zeros(1, device=g.device), None, None
+
+
 class TapDict(dict):
-    """dict[int -> TapSet] with the reference's 16 keys (all values are the same TapSet)."""
+    """The reference's `perceptual_dict` (16 int keys).  Values are produced on demand: indexing a key
+    materialises that tap as a differentiable tensor (`_TapFn`), so the reference's own `perceptual_loss` body
+    (test_runs/GAN.py:288-298: `F.l1_loss(y_activations[key], y_hat_activations[key])`) runs unchanged on it.
+    `mpgan_amd.gan_patch.perceptual_loss`, given two TapDicts, never materialises anything (fused path)."""
 
     def __init__(self, tapset: TapSet):
-        super().__init__({k: tapset for k in TapSet.KEYS})
+        super().__init__({k: None for k in TapSet.KEYS})
         self.tapset = tapset
+
+    def __getitem__(self, key):
+        if key not in TapSet.KEYS:
+            raise KeyError(key)
+        v = super().__getitem__(key)
+        if v is None:
+            v = _TapFn.apply(self.tapset.handle, self.tapset, key)
+            super().__setitem__(key, v)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in TapSet.KEYS else default
+
+    def values(self):
+        return [self[k] for k in TapSet.KEYS]
+
+    def items(self):
+        return [(k, self[k]) for k in TapSet.KEYS]
 
 
 class _PatchDiscFn(torch.autograd.Function):
@@ -413,7 +451,11 @@ class _PatchDiscFn(torch.autograd.Function):
             plan.g_prob.zero_()
         else:
             plan.g_prob.copy_(gprob.reshape(-1))
-        plan.backward_program(getattr(plan, "peer", None)).run()
+        if getattr(plan, "ext_used", False):
+            plan.backward_program_ext(getattr(plan, "peer", None)).run()
+            plan.clear_ext()
+        else:
+            plan.backward_program(getattr(plan, "peer", None)).run()
         gx = plan.g_x.view(ctx.shape).clone() if ctx.needs_input_grad[0] else None
         plan.peer = None
         plan.peer_lease = None

@@ -184,3 +184,61 @@ def test_variant_b_steps_match_oracle():
         if name in ("model_conv.0.bias", "model_conv.3.bias", "model_conv.6.bias", "model_conv.9.bias"):
             continue
         assert _l2rel(p.grad, rdp[name].grad) < 5e-2, ("D grad " + name, _l2rel(p.grad, rdp[name].grad))
+
+
+def _reference_perceptual_loss(y_hat_activations, y_activations):
+    """The reference's own loss body, test_runs/GAN.py:288-298, verbatim in behaviour (torch.Tensor([0]).type_as,
+    F.l1_loss / numel per key, summed)."""
+    import torch.nn.functional as F
+    assert set(y_activations.keys()) == set(y_hat_activations.keys())
+    running_sum = torch.Tensor([0]).type_as(y_hat_activations[0])
+    for key in y_activations.keys():
+        layer_contribution = F.l1_loss(y_activations[key], y_hat_activations[key]) / y_activations[key].numel()
+        running_sum = running_sum + layer_contribution
+    return running_sum
+
+
+def test_reference_perceptual_loss_body_runs_on_the_returned_dict():
+    """Boundary: `Discriminator.forward` returns `(validity, {idx: Tensor})` in the reference
+    (test_runs/GAN.py:183-198) and its own `perceptual_loss` (:288-298) indexes that dict.  Here the dict's values
+    are materialised on demand as differentiable tensors, so the reference's loss body runs UNCHANGED on it: same
+    value as the fused path and as the oracle, and the same gradient w.r.t. the fake patches (the gradients of all
+    16 taps travel back through the BatchNorm / conv chain of the pass that produced them)."""
+    from mpgan_amd.gan import adversarial_loss
+    from mpgan_amd.gan_patch import perceptual_loss
+    ours, ref, R = _pair()
+    for p in list(ours.parameters()) + list(ref.parameters()):
+        p.requires_grad_(False)
+    gen = torch.Generator().manual_seed(22)
+    xf = torch.rand(2, 1, 16, 16, 16, generator=gen) * 2 - 1
+    xr = torch.rand(2, 1, 16, 16, 16, generator=gen) * 2 - 1
+    # oracle
+    xfr = xf.clone().requires_grad_(True)
+    vf, af = ref(xfr)
+    _, ar = ref(xr)
+    loss_ref = 1e6 * R.perceptual_loss(af, ar).sum() + R.adversarial_loss(vf, torch.ones_like(vf))
+    loss_ref.backward()
+    # fused path
+    x1 = xf.cuda().requires_grad_(True)
+    v1, t1 = ours(x1)
+    _, t1r = ours(xr.cuda())
+    fused = perceptual_loss(t1, t1r)
+    (1e6 * fused.sum() + adversarial_loss(v1, torch.ones_like(v1))).backward()
+    # the reference's body on the returned dicts
+    x2 = xf.cuda().requires_grad_(True)
+    v2, t2 = ours(x2)
+    _, t2r = ours(xr.cuda())
+    assert isinstance(t2[0], torch.Tensor) and tuple(t2[0].shape) == (2, 64, 14, 14, 14) and t2[15].shape == (2, 1)
+    body = _reference_perceptual_loss(t2, t2r)
+    assert body.shape == (1,)
+    assert_close(body, fused.detach(), rtol=1e-5, what="reference body vs fused perceptual loss")
+    assert_close(body.detach().cpu(), R.perceptual_loss(af, ar).detach().reshape(1), rtol=2e-4, what="vs oracle")
+    (1e6 * body.sum() + adversarial_loss(v2, torch.ones_like(v2))).backward()
+    assert _l2rel(x2.grad, x1.grad) < 2e-4, _l2rel(x2.grad, x1.grad)          # same kernels, same stored tensors
+    flips = _kink_flips(t2.tapset, ref, xf)
+    assert flips <= 3 and _l2rel(x2.grad, xfr.grad) < (2e-3 if flips == 0 else 5e-2), (flips, _l2rel(x2.grad, xfr.grad))
+    # a second, plain backward through the same discriminator still works (external buffers were cleared)
+    x3 = xf.cuda().requires_grad_(True)
+    v3, _ = ours(x3)
+    adversarial_loss(v3, torch.ones_like(v3)).backward()
+    assert torch.isfinite(x3.grad).all()

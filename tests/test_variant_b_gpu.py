@@ -232,10 +232,10 @@ def test_reference_perceptual_loss_body_runs_on_the_returned_dict():
     body = _reference_perceptual_loss(t2, t2r)
     assert body.shape == (1,)
     assert_close(body, fused.detach(), rtol=1e-5, what="reference body vs fused perceptual loss")
-    assert_close(body.detach().cpu(), R.perceptual_loss(af, ar).detach().reshape(1), rtol=2e-4, what="vs oracle")
+    assert_close(body.detach().cpu(), R.perceptual_loss(af, ar).detach().reshape(1), rtol=1e-3, what="vs oracle")   # head taps: ~3e-4 of rounding (see above)
+    flips = _kink_flips(t2.tapset, ref, xf)                                    # (before backward releases the pass)
     (1e6 * body.sum() + adversarial_loss(v2, torch.ones_like(v2))).backward()
     assert _l2rel(x2.grad, x1.grad) < 2e-4, _l2rel(x2.grad, x1.grad)          # same kernels, same stored tensors
-    flips = _kink_flips(t2.tapset, ref, xf)
     assert flips <= 3 and _l2rel(x2.grad, xfr.grad) < (2e-3 if flips == 0 else 5e-2), (flips, _l2rel(x2.grad, xfr.grad))
     # a second, plain backward through the same discriminator still works (external buffers were cleared)
     x3 = xf.cuda().requires_grad_(True)

@@ -78,7 +78,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the N>1 code path where ranks must share one GPU)")
     ap.add_argument("--no-gfwd", action="store_true", help="skip the side measurement of the G forward (clean profiles)")
-    ap.add_argument("--norm", default="batch", choices=("batch", "instance"),
+    ap.add_argument("--norm", default="batch", choices=("batch", "instance", "instance_affine"),
                     help="generator norm layers: the reference's BatchNorm (default, the headline) or north_star's InstanceNorm")
     ap.add_argument("--lr", type=float, default=1e-6,
                     help="Adam lr for both nets.  The reference's 5e-4 drives the 952,576-input Linear head into "

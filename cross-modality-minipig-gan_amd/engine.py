@@ -352,7 +352,9 @@ class ParamStore:
     def offset(self, p) -> int:
         return self._off[id(p)]
 
-    def grad_view(self, p) -> torch.Tensor:
+    def grad_view(self, p) -> Optional[torch.Tensor]:
+        if p is None:                            # e.g. the gamma / beta of a non-affine instance norm
+            return None
         o = self._off[id(p)]
         return self.flat_grad[o:o + p.numel()].view(p.shape)
 

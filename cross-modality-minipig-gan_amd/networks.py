@@ -6,7 +6,7 @@ signatures, attribute names (`.model`, `.model_conv`, `.model_linear`) and
 state_dict keys of code/GAN/GAN_final.py:92-122,159-209 (and the MONAI 0.4.0
 U-Net tree beneath the generator), so a reference
 checkpoint's `generator.*` / `discriminator.*` entries load unchanged.
-Keyword-only additions: `dimensions` (2|3), `norm` ("batch"|"instance"),
+Keyword-only additions: `dimensions` (2|3), `norm` ("batch"|"instance"|"instance_affine"),
 `channels`, `strides`, `device`.
 
 The torch.nn leaf modules below are parameter CONTAINERS only: their own
@@ -41,9 +41,11 @@ class _Container(nn.Module):
 def _norm(norm: str, dims: int, ch: int) -> nn.Module:
     if norm == "batch":
         return _BN[dims](ch)
-    if norm == "instance":
+    if norm == "instance":                       # MONAI Norm.INSTANCE: torch's default, no gamma / beta
+        return _IN[dims](ch)
+    if norm == "instance_affine":                # same parameter set (and state_dict keys) as the batch variant
         return _IN[dims](ch, affine=True)
-    raise ValueError(f"norm must be 'batch' or 'instance', got {norm!r}")
+    raise ValueError(f"norm must be 'batch', 'instance' or 'instance_affine', got {norm!r}")
 
 
 def _convolution(dims, cin, cout, stride, *, conv_only=False, transposed=False, norm="batch", k=3) -> nn.Sequential:
@@ -198,7 +200,7 @@ class _GenFn(torch.autograd.Function):
         store = gen.store
         plan = gen._acquire(key, lambda: GeneratorPlan(gen, store, n, spatial, want_backward=need_bwd,
                                                       want_input_grad=bool(ctx.needs_input_grad[0]),
-                                                      instance=(gen.norm == "instance"), training=gen.training))
+                                                      instance=gen.norm.startswith("instance"), training=gen.training))
         lease = _Lease(plan)
         plan.x_in.view(-1).copy_(x.reshape(-1))     # C == 1: NC(D)HW and channels-last coincide
         plan.fwd.run()

@@ -30,8 +30,10 @@ def _norm_layer(norm: str, dims: int, ch: int) -> nn.Module:
     if norm == "batch":
         return _BN[dims](ch)  # eps 1e-5, momentum .1, affine, track stats
     if norm == "instance":
-        # north_star asks for InstanceNorm; affine so it has the same
-        # parameters as the batch variant, no running stats (torch default).
+        # north_star asks for InstanceNorm; MONAI's Norm.INSTANCE is torch's
+        # default (affine=False, no running stats).
+        return _IN[dims](ch)
+    if norm == "instance_affine":
         return _IN[dims](ch, affine=True)
     raise ValueError(norm)
 

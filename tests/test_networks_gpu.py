@@ -26,7 +26,8 @@ def _pre_norm_bias(name, keys):
     if name.startswith("model_conv."):
         return name in ("model_conv.0.bias", "model_conv.3.bias", "model_conv.6.bias", "model_conv.9.bias")
     stem = name[:-len("conv.bias")]
-    return name.endswith("conv.bias") and (stem + "adn.N.weight") in keys
+    # followed by a norm layer: its PReLU is always there, gamma only when the norm is affine
+    return name.endswith("conv.bias") and ((stem + "adn.N.weight") in keys or (stem + "adn.A.weight") in keys)
 
 
 def _check_param_grads(ours, ref, rtol=2e-3):
@@ -57,7 +58,8 @@ def _check_param_grads(ours, ref, rtol=2e-3):
 @pytest.mark.parametrize("dims,spatial,n,norm,nblocks", [
     (2, (32, 48), 2, "batch", 2),
     (2, (64, 64), 3, "batch", 6),       # the reference's 6-U-Net cascade
-    (2, (32, 32), 2, "instance", 2),    # north_star's InstanceNorm variant
+    (2, (32, 32), 2, "instance", 2),    # north_star's InstanceNorm variant (MONAI Norm.INSTANCE: no gamma / beta)
+    (2, (32, 32), 2, "instance_affine", 2),
     (3, (16, 16, 24), 2, "batch", 2),   # the reference's real (3-D) graph
 ])
 def test_generator_forward_backward_matches_oracle(dims, spatial, n, norm, nblocks):

@@ -860,12 +860,16 @@ class UNetPlan:
         sb = sizes[L - 1]
         gb0 = conv_geom_of(bc0, n, sb, dims)
         gb1 = conv_geom_of(bc1, n, sb, dims)
-        gbr = conv_geom_of(bottom.res, n, sb, dims)
-        zb0, zb1, rb = E(n, *sb, cb), E(n, *sb, cb), E(n, *sb, cb)
+        # MONAI's ResidualUnit has a residual conv only when the stride or the channel count changes: a bottom
+        # layer with chans[-2] == chans[-1] (generator_test.py's (…, 512, 512)) adds its input unchanged.
+        gbr = conv_geom_of(bottom.res, n, sb, dims) if bottom.res is not None else None
+        zb0, zb1 = E(n, *sb, cb), E(n, *sb, cb)
+        rb = E(n, *sb, cb) if gbr is not None else None
         nbb0, nbb1 = NormBuf(n, cb, instance, dev), NormBuf(n, cb, instance, dev)
         scratch.want_partials(n, sb[0] * sb[1] * sb[2], cb)
         for g in (gb0, gb1, gbr):
-            scratch.want_ws(g)
+            if g is not None:
+                scratch.want_ws(g)
         # up
         up_state = []
         out_ch = in_ch                        # output channels of up level l == input channels of down level l
@@ -957,12 +961,13 @@ class UNetPlan:
         d_last = cats[L - 2][..., :bt["cb_in"]]
         emit_conv_fwd_norm(f, bt["gb0"], d_last, wp(R(bt["bc0"])), bt["bc0"].bias, bt["zb0"], bt["nbb0"], bt["BN0"],
                            part, training=tr, eval_norms=self.eval_norms)
-        emit_conv_fwd(f, bt["gbr"], d_last, wp(R(bt["res"])), bt["res"].bias, bt["rb"])
+        if bt["res"] is not None:
+            emit_conv_fwd(f, bt["gbr"], d_last, wp(R(bt["res"])), bt["res"].bias, bt["rb"])
         emit_conv_fwd_norm(f, bt["gb1"], bt["zb0"], wp(R(bt["bc1"])), bt["bc1"].bias, bt["zb1"], bt["nbb1"],
                            bt["BN1"], part, pro=prelu_pro(bt["nbb0"], bt["BA0"]), training=tr, eval_norms=self.eval_norms,
                            fold=bt["nbb0"].fold())
-        emit_norm_act_add(f, bt["zb1"], prelu_pro(bt["nbb1"], bt["BA1"]), bt["rb"], None,
-                          cats[L - 2][..., bt["cb_in"]:], fold=bt["nbb1"].fold())
+        emit_norm_act_add(f, bt["zb1"], prelu_pro(bt["nbb1"], bt["BA1"]), bt["rb"] if bt["res"] is not None else d_last,
+                          None, cats[L - 2][..., bt["cb_in"]:], fold=bt["nbb1"].fold())
         for l in range(L - 2, -1, -1):
             u = up_state[l]
             emit_conv_fwd_norm(f, u["gt"], cats[l], wp(R(u["ct"])), u["ct"].bias, u["zt"], u["nbt"], u["NT"], part,
@@ -1031,9 +1036,12 @@ class UNetPlan:
         emit_norm_bwd(b, gab0, bt["zb0"], bt["nbb0"], prelu_pro(bt["nbb0"], bt["BA0"]), gab0, part,
                       gv(bt["BN0"].weight), gv(bt["BN0"].bias), gv(bt["BA0"].weight))
         emit_conv_wgrad(bw, bt["gb0"], d_last, gab0, gv(bt["bc0"].weight), ws, dbias=gv(bt["bc0"].bias), lane=1)
-        emit_conv_wgrad(bw, bt["gbr"], d_last, g_b, gv(bt["res"].weight), ws, dbias=gv(bt["res"].bias), lane=1)
         emit_conv_dgrad(b, bt["gb0"], gab0, wpb(R(bt["bc0"])), gd_last, resid=gd_last)
-        emit_conv_dgrad(b, bt["gbr"], g_b, wpb(R(bt["res"])), gd_last, resid=gd_last)
+        if bt["res"] is not None:
+            emit_conv_wgrad(bw, bt["gbr"], d_last, g_b, gv(bt["res"].weight), ws, dbias=gv(bt["res"].bias), lane=1)
+            emit_conv_dgrad(b, bt["gbr"], g_b, wpb(R(bt["res"])), gd_last, resid=gd_last)
+        else:
+            emit_norm_act_add(b, g_b, None, gd_last, None, gd_last)           # identity residual: gd_last += g_b
         # ---- down path, bottom to top ----
         for l in range(L - 2, -1, -1):
             s = down_state[l]

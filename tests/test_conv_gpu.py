@@ -33,6 +33,9 @@ CONV_CASES = [
     (3, 64, 128, 3, 1, 0, (6, 6, 6), 1),
     (3, 128, 256, 4, 2, 0, (8, 8, 10), 1),
     (3, 256, 512, 3, 1, 0, (5, 5, 5), 2),  # variant-B D conv4
+    (3, 512, 512, 3, 2, 1, (4, 4, 4), 1),  # generator_test.py's 7-level U-Net: levels 5-6 on 2^3 voxels ...
+    (3, 512, 512, 3, 1, 1, (2, 2, 2), 1),  # ... its bottom layer
+    (3, 256, 512, 3, 2, 1, (8, 8, 8), 1),
 ]
 
 CONVT_CASES = [
@@ -43,6 +46,8 @@ CONVT_CASES = [
     (2, 64, 1, (5, 6), 2),                 # 16 lanes per pixel
     (3, 192, 32, (3, 4, 5), 1),
     (3, 32, 1, (5, 4, 6), 2),
+    (3, 1024, 512, (2, 2, 2), 1),          # 7-level U-Net: deepest up-convolution (cat of 512 + 512)
+    (3, 512, 128, (4, 4, 4), 1),
 ]
 
 

@@ -247,3 +247,104 @@ def test_full_gd_step_at_c3_matches_oracle():
             elif k.endswith("running_mean") or k.endswith("running_var"):
                 err = (sd[k].cpu() - v).abs().max().item()
                 assert err <= 1e-4 * v.abs().max().item() + 1e-6, (k, err)
+
+
+SEVEN_LEVELS = (64, 128, 256, 512, 512, 512, 512)
+
+
+def test_seven_level_generator_of_generator_test_matches_oracle():
+    """The wide generator of test_runs/generator_test.py:47-88: U-Nets with channels (64, 128, 256, 512, 512, 512,
+    512) and seven strides (MONAI uses the first six; its bottom ResidualUnit 512 -> 512 has an IDENTITY residual),
+    built 3-D and fed `ones(1, 1, 128^3)` in train mode -- the reference's own smoke input.  One U-Net of the
+    cascade (the six are identical in shape; 129 M parameters each) against the CPU oracle:
+      * forward on the reference's input and on a random volume, elementwise;
+      * backward of the random volume through an L1 + L2 loss.  At this shape the fp32 backward is not a stable
+        function of its inputs: BatchNorm over 8 and 64 values per channel on levels 5-7 cancels the gradient to
+        ~1e-8 of its terms, and the oracle's OWN fp32 gradient differs from its fp64 gradient by O(1) in every
+        tensor below level 3 (tools/debug_seven.py prints the table).  So the yardstick is the fp64 oracle, and
+        each tensor of ours must be as close to it as the fp32 oracle is: err(ours, f64) <= 3 err(f32, f64) + 2e-3
+        in relative L2.  The well-conditioned tensors (up path, levels 1-3: 1e-5 .. 1e-2) are held tightly by
+        that; for the chaotic ones it only says "no worse than torch".  The wide layers' kernels are checked
+        exactly in test_conv_gpu.py (512-channel cases)."""
+    import copy
+    from mpgan_amd.gan import reconstruction_loss
+    from mpgan_amd.networks import CasNetGenerator
+    from oracle import refmodel as R
+    strides = (2,) * 7
+    ref = R.CasNetGenerator((1, 128, 128, 128), 1, dimensions=3, channels=SEVEN_LEVELS, strides=strides)
+    R.closed_form_fill_(ref)
+    ref.train()
+    ours = CasNetGenerator((1, 128, 128, 128), 1, dimensions=3, channels=SEVEN_LEVELS, strides=strides)
+    ours.load_state_dict(ref.state_dict())
+    ours.cuda().train()
+    n_params = sum(p.numel() for p in ours.parameters())
+    assert n_params == sum(p.numel() for p in ref.parameters()) == 129_425_400
+
+    ref64 = copy.deepcopy(ref).double()
+    ones = torch.ones(1, 1, 128, 128, 128)
+    with torch.no_grad():
+        y_ref1 = ref(ones)
+        y1 = ours(ones.cuda())
+        ref64(ones.double())
+    assert y1.shape == (1, 1, 128, 128, 128)
+    assert (y1.cpu() - y_ref1).abs().max().item() < 2e-3, (y1.cpu() - y_ref1).abs().max().item()
+    assert (y1.cpu() - y_ref1).abs().mean().item() < 1e-4
+
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(1, 1, 128, 128, 128, generator=gen) * 2 - 1).requires_grad_(True)
+    t = torch.rand(1, 1, 128, 128, 128, generator=gen) * 2 - 1
+
+    def run_ref(m, x, t):
+        y = m(x)
+        loss = R.reconstruction_loss(y, t) + 0.1 * (y * y).mean()
+        loss.backward()
+        return y.detach(), loss.item()
+
+    y_ref, loss_ref = run_ref(ref, x, t)
+    x64 = x.detach().double().requires_grad_(True)
+    y64, _ = run_ref(ref64, x64, t.double())
+    xc = x.detach().cuda().requires_grad_(True)
+    y = ours(xc)
+    assert (y.cpu() - y_ref).abs().mean().item() < 1e-4
+    assert (y.cpu() - y_ref).abs().max().item() < 2e-3
+    assert _rel_l2(y.cpu(), y64) <= 3 * _rel_l2(y_ref, y64) + 1e-6
+    loss = reconstruction_loss(y, t.cuda()) + 0.1 * (y * y).mean()
+    assert abs(loss.item() - loss_ref) <= 1e-4 * abs(loss_ref)
+    loss.backward()
+
+    def held(name, got, g32, g64):
+        e_ours, e_32 = _rel_l2(got, g64), _rel_l2(g32, g64)
+        assert e_ours <= 3 * e_32 + 2e-3, (name, e_ours, e_32)
+        return e_ours, e_32
+
+    held("dL/dx", xc.grad.cpu(), x.grad, x64.grad)
+    p32, p64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in p64.values())
+    tight = 0
+    for name, p in ours.named_parameters():
+        if name.endswith("conv.bias") and (name[:-len("conv.bias")] + "adn.A.weight") in p32:
+            assert p.grad.abs().max().item() <= 1e-4 * gmax + 1e-6, name      # true gradient: zero
+            continue
+        if p.numel() == 1:
+            assert abs(p.grad.item() - p64[name].grad.item()) <= 3 * abs(p32[name].grad.item() - p64[name].grad.item()) \
+                + 2e-3 * gmax, name
+            continue
+        e_ours, e_32 = held(name, p.grad.cpu(), p32[name].grad, p64[name].grad)
+        tight += e_ours < 2e-2
+    assert tight >= 12, tight            # the up path and the top levels ARE well-conditioned, and match
+    # Running statistics (two train-mode forwards).  The reference's all-ones volume leaves near-constant fields
+    # on the deep levels (batch variance ~ eps or below), where each BatchNorm amplifies fp32 rounding up to 300x
+    # into the next layer: levels 1-3 are held tightly against the fp32 oracle, the deeper ones by the same
+    # fp64 yardstick as the gradients.
+    sd, sr, s64 = ours.state_dict(), ref.state_dict(), ref64.state_dict()
+    for k in sr:
+        if "running_" not in k:
+            continue
+        if k.count("submodule") <= 2:
+            if k.endswith("running_mean"):
+                assert (sd[k].cpu() - sr[k]).abs().max().item() < 2e-5, k
+            else:
+                assert _rel_l2(sd[k].cpu(), sr[k]) < 1e-4, k
+        else:
+            # (one draw of rounding noise each: within an order of magnitude of the fp32 oracle's own error)
+            assert _rel_l2(sd[k].cpu(), s64[k]) <= 10 * _rel_l2(sr[k], s64[k]) + 1e-3, k

@@ -158,6 +158,18 @@ class Program:
         self.descs += other.descs
         self.lanes += other.lanes
 
+    def rebind(self, ptr: int, slot: "C.c_void_p") -> int:
+        """Replace every pointer argument equal to `ptr` by the mutable `slot` (a ctypes pointer object whose
+        .value the caller sets before `run`): the caller's own tensor is then read / written in place instead
+        of a plan-owned staging buffer.  Returns the number of calls touched."""
+        hits = 0
+        for i, (fn, args) in enumerate(self.calls):
+            if fn is None or not any(type(a) is int and a == ptr for a in args):
+                continue
+            self.calls[i] = (fn, tuple(slot if (type(a) is int and a == ptr) else a for a in args))
+            hits += 1
+        return hits
+
     def _event(self, i):
         ev = self.events.get(i)
         if ev is None:
@@ -1156,6 +1168,45 @@ class GeneratorPlan:
             self.bwd.join()                   # parameter gradients are complete when the program returns
             self.g_x = self.g_acts[0] if want_input_grad else None
         self.busy = False
+
+
+class IoSlots:
+    """The plan's boundary tensors (network input, output, upstream gradient, input gradient) as rebindable pointer
+    slots: `bind` points the programs at the caller's tensors for one pass, `reset` returns them to the plan's own
+    buffers (which tools and tests that drive `plan.fwd.run()` directly keep using)."""
+
+    def __init__(self, programs, **tensors):
+        self.home, self.slot = {}, {}
+        for name, t in tensors.items():
+            if t is None:
+                continue
+            sl = C.c_void_p(t.data_ptr())
+            if sum(pr.rebind(t.data_ptr(), sl) for pr in programs) == 0:
+                continue
+            self.home[name], self.slot[name] = t, sl
+
+    @staticmethod
+    def usable(t: torch.Tensor) -> bool:
+        return t.is_contiguous() and t.dtype == torch.float32 and t.data_ptr() % 256 == 0
+
+    def bind(self, name, t: torch.Tensor) -> bool:
+        sl = self.slot.get(name)
+        if sl is None or not self.usable(t) or t.numel() != self.home[name].numel():
+            return False
+        sl.value = t.data_ptr()
+        return True
+
+    def reset(self):
+        for name, sl in self.slot.items():
+            sl.value = self.home[name].data_ptr()
+
+
+def plan_io(plan) -> IoSlots:
+    io = getattr(plan, "io", None)
+    if io is None:
+        io = plan.io = IoSlots((plan.fwd, plan.bwd), x=plan.x_in, y=getattr(plan, "y", None),
+                               g_y=getattr(plan, "g_y", None), g_x=getattr(plan, "g_x", None))
+    return io
 
 
 # --------------------------------------------------------------------------

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .engine import DiscPlan, DiscPlanBF16, GeneratorPlan, ParamStore
+from .engine import DiscPlan, DiscPlanBF16, GeneratorPlan, ParamStore, plan_io
 
 _CONV = {2: nn.Conv2d, 3: nn.Conv3d}
 _CONVT = {2: nn.ConvTranspose2d, 3: nn.ConvTranspose3d}
@@ -202,13 +202,25 @@ class _GenFn(torch.autograd.Function):
                                                       want_input_grad=bool(ctx.needs_input_grad[0]),
                                                       instance=gen.norm.startswith("instance"), training=gen.training))
         lease = _Lease(plan)
-        plan.x_in.view(-1).copy_(x.reshape(-1))     # C == 1: NC(D)HW and channels-last coincide
-        plan.fwd.run()
-        y = plan.y.view(x.shape).clone()
+        # C == 1: NC(D)HW and channels-last coincide, so the kernels read the caller's tensor and write the returned
+        # one in place (engine.IoSlots); a misaligned or strided tensor goes through the plan's staging buffer.
+        io = plan_io(plan)
+        if not io.bind("x", x):
+            plan.x_in.view(-1).copy_(x.reshape(-1))
+        y = torch.empty_like(x)
+        direct_y = io.bind("y", y)
+        try:
+            plan.fwd.run()
+        finally:
+            if not need_bwd:
+                io.reset()
+        if not direct_y:
+            y.view(-1).copy_(plan.y.view(-1))
         if need_bwd:
             ctx.lease = lease
             ctx.shape = x.shape
-            store.attach_grads()
+            ctx.save_for_backward(x, y)          # read again by the backward (first conv's wgrad, tanh'): autograd's
+            store.attach_grads()                 # version check guards them against in-place edits
         else:
             lease.release()
         return y
@@ -216,9 +228,21 @@ class _GenFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         plan = ctx.lease.plan
-        plan.g_y.view(-1).copy_(gy.reshape(-1))
-        plan.bwd.run()
-        gx = plan.g_x.view(ctx.shape).clone() if ctx.needs_input_grad[0] else None
+        _ = ctx.saved_tensors                    # raises if x or y were modified in place since the forward
+        io = plan_io(plan)
+        gy = gy.contiguous()
+        if not io.bind("g_y", gy):
+            plan.g_y.view(-1).copy_(gy.reshape(-1))
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(ctx.shape, device=gy.device, dtype=torch.float32)
+            direct = io.bind("g_x", gx)
+        try:
+            plan.bwd.run()
+        finally:
+            io.reset()
+        if gx is not None and not direct:
+            gx.view(-1).copy_(plan.g_x.view(-1))
         ctx.lease.release()
         return gx, None, None
 
@@ -263,12 +287,19 @@ class _DiscFn(torch.autograd.Function):
         plan = disc._acquire(key, lambda: plan_cls(disc, store, n, spatial, want_backward=need_bwd,
                                                    want_input_grad=want_in, want_param_grads=want_par))
         lease = _Lease(plan)
-        plan.x_in.view(-1).copy_(x.reshape(-1))
-        plan.fwd.run()
+        io = plan_io(plan)
+        if not io.bind("x", x):                  # (see _GenFn: the first conv reads the caller's tensor in place)
+            plan.x_in.view(-1).copy_(x.reshape(-1))
+        try:
+            plan.fwd.run()
+        finally:
+            if not need_bwd:
+                io.reset()
         prob = plan.prob.view(n, 1).clone()
         if need_bwd:
             ctx.lease = lease
             ctx.shape = x.shape
+            ctx.save_for_backward(x)
             if want_par:
                 store.attach_grads()
         else:
@@ -278,9 +309,19 @@ class _DiscFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gprob):
         plan = ctx.lease.plan
+        _ = ctx.saved_tensors
+        io = plan_io(plan)
         plan.g_prob.copy_(gprob.reshape(-1))
-        plan.bwd.run()
-        gx = plan.g_x.view(ctx.shape).clone() if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(ctx.shape, device=gprob.device, dtype=torch.float32)
+            direct = io.bind("g_x", gx)
+        try:
+            plan.bwd.run()
+        finally:
+            io.reset()
+        if gx is not None and not direct:
+            gx.view(-1).copy_(plan.g_x.view(-1))
         ctx.lease.release()
         return gx, None, None
 

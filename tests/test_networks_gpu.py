@@ -348,3 +348,48 @@ def test_fused_adam_state_round_trips_in_torch_adam_format():
     assert opt.step_count == 3
     assert torch.equal(d.store.flat, d2.store.flat), (d.store.flat - d2.store.flat).abs().max().item()
     assert torch.equal(opt.exp_avg, opt2.exp_avg) and torch.equal(opt.exp_avg_sq, opt2.exp_avg_sq)
+
+
+def test_boundary_tensors_are_used_in_place_and_guarded():
+    """The generator / discriminator read the caller's input and write the returned tensor directly (1-channel
+    NC(D)HW == channels-last; engine.IoSlots) -- no staging copies.  Same numbers through the staging path that a
+    misaligned view takes; autograd's version counter rejects an in-place edit of the input between forward and
+    backward (the first conv's weight gradient reads it again)."""
+    from mpgan_amd.networks import CasNetGenerator, Discriminator
+    from mpgan_amd.engine import plan_io
+    R = _oracle()
+    torch.manual_seed(3)
+    g = CasNetGenerator((1, 32, 32), 2, dimensions=2).cuda().train()
+    d = Discriminator((1, 32, 32), dimensions=2).cuda().train()
+    base = torch.rand(2 * 32 * 32 + 1, device="cuda") * 2 - 1
+    x_al = base[:-1].clone().view(2, 1, 32, 32).requires_grad_(True)
+    x_mis = base[1:].view(2, 1, 32, 32)                       # 4-byte offset: not usable in place
+    x_mis = x_mis.detach().requires_grad_(True)
+    with torch.no_grad():
+        x_mis.copy_(x_al)
+    outs = []
+    for x in (x_al, x_mis):
+        for m in (g, d):
+            m.zero_grad()
+        # same BatchNorm running statistics for both passes
+        y = g(x)
+        p = d(y)
+        (p.sum() + y.abs().mean()).backward()
+        outs.append((y.detach().clone(), p.detach().clone(), x.grad.clone(), g.store.flat_grad.clone(),
+                     d.store.flat_grad.clone()))
+    plan = next(iter(g._plans.values()))[0]
+    io = plan_io(plan)
+    assert set(io.slot) == {"x", "y", "g_y", "g_x"}, set(io.slot)
+    assert io.slot["x"].value == plan.x_in.data_ptr()          # slots are back on the plan's buffers after a pass
+    assert not io.usable(x_mis) and io.usable(x_al)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    x = x_al.detach().clone().requires_grad_(True)
+    y = g(x)
+    with torch.no_grad():
+        x.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        y.sum().backward()
+    # the plan is returned to the pool and usable again
+    y = g(x_al)
+    y.sum().backward()

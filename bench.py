@@ -51,11 +51,12 @@ def note(msg):
 
 
 def kernel_source_hash():
-    """sha256 over the HIP sources: profiles/traffic.json is only quoted when it was measured on these."""
+    """sha256 over the sources of the dominant (fp32 implicit-GEMM) kernel -- conv_igemm.hip and every header
+    in csrc/: profiles/traffic.json is only quoted when it was measured on exactly these."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "cross-modality-minipig-gan_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if name == "conv_igemm.hip" or name.endswith(".h"):
             h.update(name.encode())
             h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
@@ -383,7 +384,12 @@ def main():
             "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
                      "backend": dist.get_backend() if world > 1 else None},
             "roofline": roofline,
-            "step_mfma_frac": (step_flops_sample * args.batch) / (dt / args.steps) / 1e12 / PEAK_FP32_TFLOPS,
+            # the step's matrix work priced at the peak of the pipe it runs on, over the step time (bf16 storage:
+            # D's share -- everything but G's forward x2 + backward = 4 x g_flops -- on the bf16 pipe, G on the fp32 pipe)
+            "step_mfma_frac": ((step_flops_sample * args.batch) / PEAK_FP32_TFLOPS if args.dtype == "f32" else
+                               (4 * g_flops_sample * args.batch) / PEAK_FP32_TFLOPS +
+                               ((step_flops_sample - 4 * g_flops_sample) * args.batch) / PEAK_BF16_TFLOPS)
+                              / (dt / args.steps) / 1e12,
             "g_forward": None if g_fwd_ms is None else {
                 "ms": g_fwd_ms, "slices_per_s": args.batch / (g_fwd_ms * 1e-3),
                 "mfma_frac": g_fwd_flops / (g_fwd_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},

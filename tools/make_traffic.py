@@ -8,8 +8,10 @@ FETCH_SIZE / WRITE_SIZE are in KiB; the factor 2 is the gfx950 half-count correc
 import collections
 import csv
 import json
+import os
 import re
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(path, counter):
@@ -27,13 +29,15 @@ def per_kernel(path, counter):
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {}
+    import bench
+    # stamped with the kernel sources the passes ran on: bench.py quotes these bytes only for the same sources
+    out = {"_source_sha256_16": bench.kernel_source_hash()}
     for k, (f, n) in sorted(fetch.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
         w = write.get(k, (0.0, 0))[0]
         out[k] = {"launches": n, "fetch_bytes_per_launch_corrected": 2 * f * 1024,
                   "write_bytes_per_launch": w * 1024, "hbm_bytes_per_launch": (2 * f + w) * 1024}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
-    for k in list(out)[:8]:
+    for k in [k for k in out if not k.startswith('_')][:8]:
         print(f"{k:70s} {out[k]['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch x{out[k]['launches']}")
 
 

@@ -25,6 +25,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ uint4 g_zero_page[16];   // 256 B of zeros: what a masked LDS-DMA gather reads
+__device__ int g_hb_dbg;            // MPGAN_DBG_HB what-if bits (development): 1 = gathers confined to a 64 KiB window,
+                                    // 2 = no MFMAs, 4 = no fragment reads either, 8 = weights confined to 16 KiB,
+                                    // 16 = no LDS-DMA (the contraction runs on whatever the LDS holds)
 
 #define GLDS16(gptr, lptr)                                                                            \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),             \
@@ -55,6 +58,11 @@ __device__ __forceinline__ void lds_wait(V (&a)[NA], V (&b)[NB]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
   else if constexpr (NA == 2 && NB == 2)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+  else if constexpr (NA == 4 && NB == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+  else if constexpr (NA == 2 && NB == 1)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]));
   else if constexpr (NA == 4 && NB == 8)
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
@@ -67,26 +75,30 @@ constexpr int HB_BM = 256;          // pixels per tile
 constexpr int HB_BK = 64;           // K elements per step (one 128-byte LDS row)
 constexpr int HB_ROWB = 128;
 
-template <int BN>
+//   NW: waves per block.  4 = one wave per SIMD (128 x 64 or 64 x 64 per wave); 8 = two waves per SIMD (64 x 64 or
+//   64 x 32 per wave): one wave's vmcnt / barrier / fragment waits sit under the other's MFMAs.
+template <int BN, int NW = 4>
 struct HbTile {
-  static constexpr int WM = BN == 128 ? 2 : 4, WN = BN == 128 ? 2 : 1;
+  static constexpr int NT = NW * 64;
+  static constexpr int WM = NW == 8 ? 4 : (BN == 128 ? 2 : 4), WN = NW == 8 ? 2 : (BN == 128 ? 2 : 1);
   static constexpr int TM = HB_BM / WM / 32, TN = BN / WN / 32;
-  static constexpr int APIECES = HB_BM * 8 / 256, BPIECES = BN * 8 / 256;
+  static constexpr int PASS_ROWS = NT / 8;                            // rows one LDS-DMA instruction of every wave fills
+  static constexpr int APIECES = HB_BM / PASS_ROWS, BPIECES = BN / PASS_ROWS;
   static constexpr int STAGE = (HB_BM + BN) * HB_ROWB;
   static constexpr int NSTAGE = 3;
   static constexpr int IMG_PITCH = BN + 4;                            // floats
   static constexpr int ROWPIX = HB_BM * IMG_PITCH * 4;                // int[256] behind the fp32 epilogue image
   static constexpr int SMEM_LOOP = NSTAGE * STAGE;
-  static constexpr int SMEM_EPI = ROWPIX + HB_BM * 4 + 2048;                  // + the column-sum partials
+  static constexpr int SMEM_EPI = ROWPIX + HB_BM * 4 + 4096;                  // + the column-sum partials
   static constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
 };
 
 //   MASK : taps can fall outside the gathered tensor (backward-data gathers, padded convs): per-row tap bitmasks,
 //          invalid pieces read the zero page.  !MASK: every tap of every pixel is in range (valid convs).
-template <int BN, bool MASK>
-__global__ __launch_bounds__(256, 1) void gather_conv_bf16_kernel(const GatherConv p) {
-  using T = HbTile<BN>;
-  constexpr int TM = T::TM, TN = T::TN, WN = T::WN;
+template <int BN, bool MASK, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void gather_conv_bf16_kernel(const GatherConv p) {
+  using T = HbTile<BN, NW>;
+  constexpr int TM = T::TM, TN = T::TN, WN = T::WN, NT = T::NT, PR = T::PASS_ROWS;
   constexpr int NLOADS = T::APIECES + T::BPIECES;     // LDS-DMA instructions per thread and K-step
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void gather_conv_bf16_kernel(const GatherCo
   unsigned tmask[MASK ? T::APIECES : 1];
 #pragma unroll
   for (int i = 0; i < T::APIECES; ++i) {
-    unsigned m = (unsigned)m0 + r0 + 32 * i;
+    unsigned m = (unsigned)m0 + r0 + PR * i;
     const bool live = m < (unsigned)Mtot;
     m = live ? m : (unsigned)Mtot - 1u;               // clamped rows gather a real pixel; never stored
     unsigned q, umx, umy, umz;
@@ -133,6 +145,7 @@ __global__ __launch_bounds__(256, 1) void gather_conv_bf16_kernel(const GatherCo
     fdivmod(q, ph.fMz, q, umz);
     const int bz = (int)umz * p.istride[0], by = (int)umy * p.istride[1], bx = (int)umx * p.istride[2];
     rbB[i] = (unsigned)((((int)q * Di + bz) * Hi + by) * Wi + bx) * (unsigned)ldi * 2u;
+    if (g_hb_dbg & 1) rbB[i] &= 0xFF80u;
     if constexpr (MASK) {
       unsigned mk = 0;
       int j = 0;
@@ -153,10 +166,12 @@ __global__ __launch_bounds__(256, 1) void gather_conv_bf16_kernel(const GatherCo
   unsigned wrowB[T::BPIECES];
 #pragma unroll
   for (int i = 0; i < T::BPIECES; ++i) {
-    int co = n0 + r0 + 32 * i;
+    int co = n0 + r0 + PR * i;
     co = co < Cout ? co : Cout - 1;                   // clamped columns are computed and dropped
     wrowB[i] = (unsigned)co * Ktot2;
+    if (g_hb_dbg & 8) wrowB[i] &= 0x3F80u;
   }
+  const int dbg = g_hb_dbg;
 
   // K order: channel-chunk major, taps inner (the taps that re-read an input element are then adjacent K-steps).
   // The tap walk is wave-uniform and lives in scalar registers: the K loop makes NO LDS access besides the
@@ -168,19 +183,23 @@ __global__ __launch_bounds__(256, 1) void gather_conv_bf16_kernel(const GatherCo
   auto issue = [&]() {
     const int dz = ph.dz0 + dsz * jz, dy = ph.dy0 + dsy * jy, dx = ph.dx0 + dsx * jx;
     const int kz = ph.kz0 + ksz * jz, ky = ph.ky0 + ksy * jy, kx = ph.kx0 + ksx * jx;
-    const unsigned deltaB = (unsigned)(((dz * Hi + dy) * Wi + dx) * ldi * 2);
-    const unsigned woffB = (unsigned)(((kz * p.Ky + ky) * p.Kx + kx) * Cin * 2);
+    unsigned deltaB = (unsigned)(((dz * Hi + dy) * Wi + dx) * ldi * 2);
+    unsigned woffB = (unsigned)(((kz * p.Ky + ky) * p.Kx + kx) * Cin * 2);
+    if (dbg & 1) deltaB = 0;
+    if (dbg & 8) woffB = 0;
     const unsigned ciB = (unsigned)(ichunk * HB_BK + ck * 8) * 2u;
     char* As = lds + istage * T::STAGE + (8 * wid) * HB_ROWB;
     char* Bs = As + HB_BM * HB_ROWB;
+    if (!(dbg & 16)) {
 #pragma unroll
     for (int i = 0; i < T::APIECES; ++i) {
       const char* src = ginb + (rbB[i] + deltaB + ciB);
       if constexpr (MASK) src = ((tmask[i] >> itap) & 1u) ? src : zero;
-      GLDS16(src, As + 32 * i * HB_ROWB);
+      GLDS16(src, As + PR * i * HB_ROWB);
     }
 #pragma unroll
-    for (int i = 0; i < T::BPIECES; ++i) GLDS16(gwb + (wrowB[i] + woffB + ciB), Bs + 32 * i * HB_ROWB);
+    for (int i = 0; i < T::BPIECES; ++i) GLDS16(gwb + (wrowB[i] + woffB + ciB), Bs + PR * i * HB_ROWB);
+    }
     itap += 1;
     jx += 1;
     if (jx == ph.nx) { jx = 0; jy += 1; }
@@ -206,32 +225,45 @@ __global__ __launch_bounds__(256, 1) void gather_conv_bf16_kernel(const GatherCo
   const int brow = HB_BM * HB_ROWB + (wn * (BN / WN) + li) * HB_ROWB;
 
   const unsigned lds_base = lds_addr(lds);
+  // Pipeline: tile kt is consumed from stage kt % 3 while tiles kt+1 and kt+2 are in flight.  The K-step's ONE
+  // barrier sits in front of its LAST k-sub's MFMAs: by then this wave has read all of stage kt into registers,
+  // so behind the barrier (tile kt+1 landed for every wave, stage kt free for every wave) the first fragments of
+  // tile kt+1 are read and tile kt+3's DMAs are issued UNDER those MFMAs -- no bubble at the K-step boundary.
+  i32x4 fa[2][TM], fb[2][TN];
+  auto read_frags = [&](int stage, int s, int set) {
+    const unsigned As = lds_base + stage * T::STAGE + arow;
+    const unsigned Bs = lds_base + stage * T::STAGE + brow;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) fa[set][tm] = lds_read_b128(As + tm * 32 * HB_ROWB + foff[s]);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) fb[set][tn] = lds_read_b128(Bs + tn * 32 * HB_ROWB + foff[s]);
+  };
   if (nk > 0) issue();
   if (nk > 1) issue();
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");             // tile 0 landed
+  if (nk > 0 && !(dbg & 4)) read_frags(0, 0, 0);
+  if (nk > 2) issue();
   int cstage = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once all but the newest NLOADS DMAs of this wave are done (tile kt+1's)
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");           // every wave's part of tile kt landed; stage of tile kt-1 is free
-    if (kt + 2 < nk) issue();
-    const unsigned As = lds_base + cstage * T::STAGE + arow;
-    const unsigned Bs = lds_base + cstage * T::STAGE + brow;
-    // fragments of k-sub s+1 are read while the MFMAs of k-sub s run (two register sets)
-    i32x4 fa[2][TM], fb[2][TN];
-    auto read_frags = [&](int s, int set) {
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) fa[set][tm] = lds_read_b128(As + tm * 32 * HB_ROWB + foff[s]);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) fb[set][tn] = lds_read_b128(Bs + tn * 32 * HB_ROWB + foff[s]);
-    };
-    read_frags(0, 0);
+    const int nstage = cstage == T::NSTAGE - 1 ? 0 : cstage + 1;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int set = s & 1;
       lds_wait<TM, TN>(fa[set], fb[set]);
-      if (s < 3) read_frags(s + 1, set ^ 1);
+      if (s < 3) {
+        if (!(dbg & 4)) read_frags(cstage, s + 1, set ^ 1);
+      } else if (kt + 1 < nk) {
+        // tile kt+1 has landed once all but the newest NLOADS DMAs of this wave are done (tile kt+2's)
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) ; tail: the last tile" ::: "memory");      // (tools/check_isa.py)
+        asm volatile("s_barrier" ::: "memory");
+        if (!(dbg & 4)) read_frags(nstage, 0, 0);
+        if (kt + 3 < nk) issue();
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 2))
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -239,15 +271,15 @@ __global__ __launch_bounds__(256, 1) void gather_conv_bf16_kernel(const GatherCo
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][tm]),
                                                                 __builtin_bit_cast(bf16x8, fb[set][tn]), acc[tm][tn], 0, 0, 0);
     }
-    cstage = cstage == T::NSTAGE - 1 ? 0 : cstage + 1;
+    cstage = nstage;
   }
   asm volatile("s_barrier" ::: "memory");             // all fragment reads done: LDS becomes the epilogue image
 
   // ---- epilogue: fp32 image [pixel][channel] in LDS -> statistics, bf16 rows stored 16 bytes per lane ----
   float* img = reinterpret_cast<float*>(lds);
   int* rowpix = reinterpret_cast<int*>(lds + T::ROWPIX);
-  {
-    const unsigned m = (unsigned)m0 + tid;            // 256 threads, 256 rows
+  if (tid < HB_BM) {
+    const unsigned m = (unsigned)m0 + tid;            // one thread per row
     int pix = -1;
     if (m < (unsigned)Mtot) {
       unsigned q, umx, umy, umz;
@@ -276,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void gather_conv_bf16_kernel(const GatherCo
   if (p.stats) {
     // column sums of z = acc + bias over the rows that own an output pixel: thread (column, row half)
     float* part = reinterpret_cast<float*>(lds + T::ROWPIX + HB_BM * 4);   // [2 halves][2][BN]
-    constexpr int HALVES = 256 / BN;                  // 2 (BN 128) or 4 (BN 64)
+    constexpr int HALVES = NT / BN;                   // row groups: 2 or 4 (four waves), 4 or 8 (eight)
     const int c = tid % BN, hf = tid / BN;
     float sm = 0.f, sq = 0.f;
     for (int row = hf * (HB_BM / HALVES); row < (hf + 1) * (HB_BM / HALVES); ++row) {
@@ -302,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void gather_conv_bf16_kernel(const GatherCo
   }
   char* goutb = reinterpret_cast<char*>(p.out);
   constexpr int CHUNKS = BN / 8;                      // 16-byte chunks per row
-  for (int q = tid; q < HB_BM * CHUNKS; q += 256) {
+  for (int q = tid; q < HB_BM * CHUNKS; q += NT) {
     const int row = q / CHUNKS, ch = q % CHUNKS;
     const int pix = rowpix[row];
     if (pix < 0 || n0 + ch * 8 >= Cout) continue;
@@ -315,10 +347,10 @@ __global__ __launch_bounds__(256, 1) void gather_conv_bf16_kernel(const GatherCo
   }
 }
 
-template <int BN, bool MASK>
+template <int BN, bool MASK, int NW>
 static int hb_launch(const GatherConv& p, long maxM, hipStream_t st) {
-  auto kern = gather_conv_bf16_kernel<BN, MASK>;
-  constexpr int smem = HbTile<BN>::SMEM;
+  auto kern = gather_conv_bf16_kernel<BN, MASK, NW>;
+  constexpr int smem = HbTile<BN, NW>::SMEM;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -328,13 +360,19 @@ static int hb_launch(const GatherConv& p, long maxM, hipStream_t st) {
     }
     attr_set = true;
   }
+  static int dbg_set = -1;
+  if (dbg_set < 0) {
+    const char* e = getenv("MPGAN_DBG_HB");
+    dbg_set = e ? atoi(e) : 0;
+    if (dbg_set) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hb_dbg), &dbg_set, sizeof(int));
+  }
   GatherConv q = p;
   q.mtiles = (int)((maxM + HB_BM - 1) / HB_BM);
   q.ntiles = (p.Cout + BN - 1) / BN;
   q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 2 > (3L << 20) ? 1 : 0;
   q.ksplit = 1;
   dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, q);
   return check_launch("gather_conv_bf16");
 }
 
@@ -375,8 +413,17 @@ static int hb_dispatch(const GatherConv& p, hipStream_t st, const char* what) {
   const long maxM = max_phase_pixels(p);
   if (maxM == 0) return MPGAN_OK;
   const bool mask = !hb_all_in_range(p);
-  if (p.Cout > 64) return mask ? hb_launch<128, true>(p, maxM, st) : hb_launch<128, false>(p, maxM, st);
-  return mask ? hb_launch<64, true>(p, maxM, st) : hb_launch<64, false>(p, maxM, st);
+  static int nw = 0;
+  if (!nw) {
+    const char* e = getenv("MPGAN_DBG_HB_NW");      // development: force four or eight waves per block
+    nw = e ? atoi(e) : 8;
+  }
+  if (nw == 4) {
+    if (p.Cout > 64) return mask ? hb_launch<128, true, 4>(p, maxM, st) : hb_launch<128, false, 4>(p, maxM, st);
+    return mask ? hb_launch<64, true, 4>(p, maxM, st) : hb_launch<64, false, 4>(p, maxM, st);
+  }
+  if (p.Cout > 64) return mask ? hb_launch<128, true, 8>(p, maxM, st) : hb_launch<128, false, 8>(p, maxM, st);
+  return mask ? hb_launch<64, true, 8>(p, maxM, st) : hb_launch<64, false, 8>(p, maxM, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -404,14 +451,19 @@ constexpr int WH_BD = 128, WH_BG = 256, WH_BK = 64;
 constexpr int WH_STAGE = WH_BK * (WH_BD + WH_BG) * 2;      // 48 KiB
 constexpr int WH_SMEM = 3 * WH_STAGE;
 
-__global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradHb p) {
+//   NW = 4: 2 x 2 waves of 64 x 128;  NW = 8: 2 x 4 waves of 64 x 64, two per SIMD (see gather_conv_bf16_kernel).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void wgrad_bf16_kernel(const WgradHb p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int TM = 2, TN = 4;
-  constexpr int NLOADS = 4 + 8;
+  constexpr int WN = NW / 2;                             // waves along the 256 columns
+  constexpr int TM = 2, TN = WH_BG / WN / 32;
+  constexpr int PR = NW * 4;                             // rows one LDS-DMA instruction of every wave fills
+  constexpr int NP = WH_BK / PR;                         // row groups per thread
+  constexpr int NLOADS = 3 * NP;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WN, wn = wid % WN;
   const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
   const int tc = (int)(w % (unsigned)p.tiles_c);
   const unsigned wq = w / (unsigned)p.tiles_c;
@@ -445,14 +497,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradHb p) {
     gtapB[j] = (unsigned)(((kz * p.Gy + ky) * p.Gx + kx) * p.ldg + ci) * 2u;
   }
 
-  // Pixel cursors of this thread's four rows (16 i + prow of every 64-pixel K-step): decoded with divisions
+  // Pixel cursors of this thread's rows (PR i + prow of every 64-pixel K-step): decoded with divisions
   // once, then advanced by 64 pixels per K-step with carries.  (No row table in LDS: hipcc drains every
   // LDS-DMA in flight in front of an LDS access it cannot tell apart from the staging area.)
-  int cn[4], cz[4], cy[4], cx[4];
+  int cn[NP], cz[NP], cy[NP], cx[NP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NP; ++i) {
     unsigned q, ux, uy, uz;
-    fdivmod((unsigned)(mbeg + 16 * i + prow), p.fMx, q, ux);
+    fdivmod((unsigned)(mbeg + PR * i + prow), p.fMx, q, ux);
     fdivmod(q, p.fMy, q, uy);
     fdivmod(q, p.fMz, q, uz);
     cn[i] = (int)q; cz[i] = (int)uz; cy[i] = (int)uy; cx[i] = (int)ux;
@@ -460,21 +512,21 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradHb p) {
   int istage = 0;
   long mtile = mbeg;                                      // first pixel of the next tile to issue
   auto issue = [&]() {
-    char* Ds = lds + istage * WH_STAGE + (4 * wid) * 256;           // wave base: rows 16 i + 4 wid .. + 3
+    char* Ds = lds + istage * WH_STAGE + (4 * wid) * 256;           // wave base: rows PR i + 4 wid .. + 3
     char* Gs = lds + istage * WH_STAGE + WH_BK * 256 + (4 * wid) * 256;
     const unsigned mrowB = (unsigned)(mtile * p.ldd) * 2u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = 16 * i + prow;
+    for (int i = 0; i < NP; ++i) {
+      const int row = PR * i + prow;
       const bool valid = mtile + row < mend;
       const unsigned gpixB =
           (unsigned)(((cn[i] * p.Gz + cz[i] * p.sz) * p.Gy + cy[i] * p.sy) * p.Gx + cx[i] * p.sx) * (unsigned)p.ldg * 2u;
       const char* src = p.dense + (mrowB + (unsigned)(row * p.ldd) * 2u + dcolB);
-      GLDS16((valid && dok) ? src : zero, Ds + 16 * i * 256);
+      GLDS16((valid && dok) ? src : zero, Ds + PR * i * 256);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const char* gs = p.gath + (gpixB + gtapB[j]);
-        GLDS16((valid && gok[j]) ? gs : zero, Gs + j * (WH_BK * 256) + 16 * i * 256);
+        GLDS16((valid && gok[j]) ? gs : zero, Gs + j * (WH_BK * 256) + PR * i * 256);
       }
       cx[i] += WH_BK;
       while (cx[i] >= p.Mx) {
@@ -513,41 +565,51 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradHb p) {
     }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-      const int colb = wn * 128 + tn * 32 + 16 * (tg & 1);         // 0..255: sub-tile colb >> 7
+      const int colb = wn * (WH_BG / WN) + tn * 32 + 16 * (tg & 1);   // 0..255: sub-tile colb >> 7
       const int chunk = (colb & 127) / 8 + (tpp >> 1);
       boff[tn][half] = WH_BK * 256 * (1 + (colb >> 7)) + 256 * r + 16 * (chunk ^ fr) + 8 * (tpp & 1);
     }
   }
 
   const unsigned lds_base = lds_addr(lds);
+  // (pipeline as in gather_conv_bf16_kernel: the K-step's barrier sits in front of its last k-sub's MFMAs)
+  i32x2 fa[2][2 * TM], fb[2][2 * TN];                     // [set][2*tile + half]
+  auto read_frags = [&](int stage, int s, int set) {
+    const unsigned S = lds_base + stage * WH_STAGE;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      fa[set][2 * tm] = lds_read_tr16_b64(S + s * 16 * 256 + aoff[tm][0]);
+      fa[set][2 * tm + 1] = lds_read_tr16_b64(S + s * 16 * 256 + aoff[tm][1]);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      fb[set][2 * tn] = lds_read_tr16_b64(S + s * 16 * 256 + boff[tn][0]);
+      fb[set][2 * tn + 1] = lds_read_tr16_b64(S + s * 16 * 256 + boff[tn][1]);
+    }
+  };
   if (nk > 0) issue();
   if (nk > 1) issue();
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  if (nk > 0) read_frags(0, 0, 0);
+  if (nk > 2) issue();
   int cstage = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    if (kt + 2 < nk) issue();
-    const unsigned S = lds_base + cstage * WH_STAGE;
-    i32x2 fa[2][2 * TM], fb[2][2 * TN];                   // [set][2*tile + half]
-    auto read_frags = [&](int s, int set) {
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        fa[set][2 * tm] = lds_read_tr16_b64(S + s * 16 * 256 + aoff[tm][0]);
-        fa[set][2 * tm + 1] = lds_read_tr16_b64(S + s * 16 * 256 + aoff[tm][1]);
-      }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        fb[set][2 * tn] = lds_read_tr16_b64(S + s * 16 * 256 + boff[tn][0]);
-        fb[set][2 * tn + 1] = lds_read_tr16_b64(S + s * 16 * 256 + boff[tn][1]);
-      }
-    };
-    read_frags(0, 0);
+    const int nstage = cstage == 2 ? 0 : cstage + 1;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int set = s & 1;
       lds_wait<2 * TM, 2 * TN>(fa[set], fb[set]);
-      if (s < 3) read_frags(s + 1, set ^ 1);
+      if (s < 3) {
+        read_frags(cstage, s + 1, set ^ 1);
+      } else if (kt + 1 < nk) {
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) ; tail: the last tile" ::: "memory");      // (tools/check_isa.py)
+        asm volatile("s_barrier" ::: "memory");
+        read_frags(nstage, 0, 0);
+        if (kt + 3 < nk) issue();
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
@@ -559,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradHb p) {
                                                                 acc[tm][tn], 0, 0, 0);
         }
     }
-    cstage = cstage == 2 ? 0 : cstage + 1;
+    cstage = nstage;
   }
 
   float* out = p.partial + (long)split * p.Cd * NC;
@@ -567,7 +629,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradHb p) {
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-      const int col = c0 + wn * 128 + tn * 32 + li;
+      const int col = c0 + wn * (WH_BG / WN) + tn * 32 + li;
       if (col >= NC) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -583,7 +645,7 @@ static WgradHbPlan plan_wgrad_hb(int Cd, int NC, long M) {
   pl.tiles_c = (NC + WH_BG - 1) / WH_BG;
   pl.tiles_d = (Cd + WH_BD - 1) / WH_BD;
   const long tiles = (long)pl.tiles_c * pl.tiles_d;
-  long ns = (256 + tiles - 1) / tiles;                    // one block per CU per round
+  long ns = tiles <= 256 ? 256 / tiles : 1;               // one block per CU, ONE round: never a few blocks more than CUs
   const long maxsplit = M / (8 * WH_BK) > 1 ? M / (8 * WH_BK) : 1;
   if (ns > maxsplit) ns = maxsplit;
   if (ns > 64) ns = 64;
@@ -862,18 +924,24 @@ extern "C" int mpgan_conv_backward_weight_bf16(const mpgan_conv_geom* g, const v
   p.sz = g->stride[0]; p.sy = g->stride[1]; p.sx = g->stride[2];
   p.nsplit = pl.nsplit; p.chunk = pl.chunk; p.tiles_c = pl.tiles_c; p.tiles_d = pl.tiles_d;
   p.fMx = make_fastdiv(p.Mx); p.fMy = make_fastdiv(p.My); p.fMz = make_fastdiv(p.Mz);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, WH_SMEM);
-    if (e != hipSuccess) {
-      set_error("wgrad_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  static int nw = 0;
+  if (!nw) {
+    const char* e = getenv("MPGAN_DBG_HB_NW");      // development: force four or eight waves per block
+    nw = (e && atoi(e) == 4) ? 4 : 8;
+    hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, WH_SMEM);
+    hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<8>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, WH_SMEM);
+    if (e4 != hipSuccess || e8 != hipSuccess) {
+      nw = 0;
+      set_error("wgrad_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e4 != hipSuccess ? e4 : e8));
       return MPGAN_ERR_HIP;
     }
-    attr_set = true;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)pl.tiles_c * pl.tiles_d * pl.nsplit), dim3(256), WH_SMEM, st, p);
+  const dim3 grid((unsigned)pl.tiles_c * pl.tiles_d * pl.nsplit);
+  if (nw == 4) hipLaunchKernelGGL(wgrad_bf16_kernel<4>, grid, dim3(256), WH_SMEM, st, p);
+  else hipLaunchKernelGGL(wgrad_bf16_kernel<8>, grid, dim3(512), WH_SMEM, st, p);
   int rc = check_launch("wgrad_bf16");
   if (rc) return rc;
   const long total = (long)Cd * Cg * T;

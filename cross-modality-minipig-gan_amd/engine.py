@@ -1385,7 +1385,7 @@ class DiscPlanBF16:
                 f.add("conv_forward_bf16", L.mpgan_conv_forward_bf16, C.byref(gc), src.data_ptr(), g.cin,
                       w16(i).data_ptr(), cv.bias.data_ptr(), part.data_ptr(), z.data_ptr(), g.cout,
                       keep=(gc, src, z, part), desc=_gdesc(g),
-                      tag=(f"gather_conv_bf16_kernel<{128 if g.cout > 64 else 64}, false>", 2.0 * conv_macs(g)))
+                      tag=(f"gather_conv_bf16_kernel<{128 if g.cout > 64 else 64}, false, 8>", 2.0 * conv_macs(g)))
             f.add("norm_finalize", L.mpgan_norm_finalize, part.data_ptr(), 1, rows, g.cout, rows_total, 0,
                   _p(bn.weight), _p(bn.bias), float(bn.eps), float(bn.momentum), _p(bn.running_mean),
                   _p(bn.running_var), _p(bn.num_batches_tracked), nb.scale.data_ptr(), nb.shift.data_ptr(),
@@ -1445,7 +1445,7 @@ class DiscPlanBF16:
                     b.add("conv_backward_weight_bf16", L.mpgan_conv_backward_weight_bf16, C.byref(gc),
                           acts[i - 1].data_ptr(), g.cin, dz.data_ptr(), c, gv(cv.weight).data_ptr(), 1.0,
                           ws.data_ptr(), ws.numel() * 4, keep=(gc, ws), desc=_gdesc(g),
-                          tag=("wgrad_bf16_kernel", 2.0 * conv_macs(g)))
+                          tag=("wgrad_bf16_kernel<8>", 2.0 * conv_macs(g)))
                 else:
                     b.add("conv_backward_weight_bf16dy", L.mpgan_conv_backward_weight_bf16dy, C.byref(gc),
                           self.x_in.data_ptr(), 1, dz.data_ptr(), c, gv(cv.weight).data_ptr(), gv(cv.bias).data_ptr(),
@@ -1454,7 +1454,7 @@ class DiscPlanBF16:
             if i > 0:
                 b.add("conv_backward_data_bf16", L.mpgan_conv_backward_data_bf16, C.byref(gc), dz.data_ptr(), c,
                       w16b(i).data_ptr(), gas[i - 1].data_ptr(), g.cin, keep=(gc,), desc=_gdesc(g),
-                      tag=(f"dgrad:gather_conv_bf16_kernel<{128 if g.cin > 64 else 64}, true>", 2.0 * conv_macs(g)))
+                      tag=(f"dgrad:gather_conv_bf16_kernel<{128 if g.cin > 64 else 64}, true, 8>", 2.0 * conv_macs(g)))
             elif want_input_grad:
                 self.g_x = E(n, *dhw, 1)
                 b.add("conv_backward_data_bf16_to_f32", L.mpgan_conv_backward_data_bf16_to_f32, C.byref(gc), dz.data_ptr(),

@@ -716,6 +716,85 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Thin weight gradient, row-walking form, for the 1 -> 64 pad-free stride-1 3x3 / 3x3x3 conv (D.conv1; its dense
+// operand dy is the largest tensor of the discriminator: 1 GB in bf16 at 128^3).  lane = output channel, one wave
+// walks whole output rows four pixels at a time; the gathered samples of those four pixels (a 6-wide window per
+// (kz, ky)) are WAVE-UNIFORM, so they come through the scalar cache into SGPRs and every FMA takes one as its
+// scalar operand: no per-lane address arithmetic or bounds tests at all (the lane-strided kernel above spends
+// ~4 vector instructions on addresses per FMA at 27 taps).  The last group of a row is re-anchored at Mx - 4 and
+// its already-counted pixels masked, so nothing is read past the row.
+// ---------------------------------------------------------------------------
+template <int T, bool DENSE_BF16>
+__global__ __launch_bounds__(256) void thin_wgrad_rows_kernel(const WgradParams p) {
+  __shared__ float red[4][64 * T + 64];
+  constexpr int KZ = T == 27 ? 3 : 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int rows = p.N * p.Mz * p.My;
+  const int nwaves = (int)gridDim.x * 4;
+  const int Mx = p.Mx, ngroups = (Mx + 3) >> 2;
+  float acc[T], bsum = 0.f;
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+  for (int r = (int)blockIdx.x * 4 + wave; r < rows; r += nwaves) {
+    const int my = r % p.My, q = r / p.My;
+    const int mz = q % p.Mz, n = q / p.Mz;
+    const long drow = (long)r * Mx;                                        // first pixel of the dense row
+    const float* __restrict__ g0 = p.gath + (((long)n * p.Gz + mz) * p.Gy + my) * p.Gx;
+    for (int gi = 0; gi < ngroups; ++gi) {
+      const int x0 = gi + 1 < ngroups ? 4 * gi : Mx - 4;
+      const int first = 4 * gi - x0;                                       // pixels j < first were counted by the previous group
+      float d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long e = (drow + x0 + j) * p.ldd + lane;
+        float v;
+        if constexpr (DENSE_BF16) v = (float)reinterpret_cast<const __bf16*>(p.dense)[e];
+        else v = p.dense[e];
+        d[j] = j >= first ? v : 0.f;
+        bsum += d[j];
+      }
+#pragma unroll
+      for (int kz = 0; kz < KZ; ++kz)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* __restrict__ w = g0 + ((long)kz * p.Gy + ky) * p.Gx + x0;   // wave-uniform: scalar loads
+          float win[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) win[i] = w[i];
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[(kz * 3 + ky) * 3 + kx] = fmaf(d[j], win[j + kx], acc[(kz * 3 + ky) * 3 + kx]);
+        }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) red[wave][lane * T + t] = acc[t];
+  red[wave][64 * T + lane] = bsum;
+  __syncthreads();
+  float* out = p.partial + (long)blockIdx.x * 64 * T;
+  for (int i = threadIdx.x; i < 64 * T + 64; i += 256) {
+    const float s = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    if (i < 64 * T) out[i] = s;
+    else if (p.bias_partial) p.bias_partial[(long)blockIdx.x * 64 + (i - 64 * T)] = s;
+  }
+}
+
+static bool thin_rows_ok(const WgradParams& p, int T) {
+  static const bool off = getenv("MPGAN_DBG_NO_THIN_ROWS") != nullptr;
+  return !off && p.Cd == 64 && p.Cg == 1 && p.ldg == 1 && !p.pro.scale && (T == 9 || T == 27) && p.Kx == 3 && p.Ky == 3 &&
+         p.Kz == (T == 27 ? 3 : 1) && p.sz == 1 && p.sy == 1 && p.sx == 1 && p.pz == 0 && p.py == 0 && p.px == 0 && p.Mx >= 4 &&
+         p.Gx == p.Mx + 2 && p.Gy == p.My + 2 && p.Gz == p.Mz + (T == 27 ? 2 : 0);
+}
+
+template <bool DENSE_BF16>
+static void launch_thin_rows(const WgradParams& p, int T, int blocks, hipStream_t st) {
+  if (T == 9) hipLaunchKernelGGL((thin_wgrad_rows_kernel<9, DENSE_BF16>), dim3(blocks), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((thin_wgrad_rows_kernel<27, DENSE_BF16>), dim3(blocks), dim3(256), 0, st, p);
+}
+
 struct ThinWgradPlan { int blocks; long chunk; bool ok; };
 static ThinWgradPlan plan_thin_wgrad(int Cd, int Cg, int T, long M, bool has_pro, long lds_cap = 64 * 1024) {
   ThinWgradPlan t;
@@ -934,7 +1013,8 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
       const size_t smem = (size_t)PL * (Cd * T + Cd) * sizeof(float);
       dim3 grid(tp.blocks);
 #define THIN_LAUNCH(VV, TT) hipLaunchKernelGGL((thin_wgrad_kernel<VV, TT>), grid, dim3(256), smem, st0, p)
-      if (v4) { if (T == 1) THIN_LAUNCH(4, 1); else if (T == 9) THIN_LAUNCH(4, 9); else THIN_LAUNCH(4, 27); }
+      if (thin_rows_ok(p, T)) launch_thin_rows<false>(p, T, tp.blocks, st0);
+      else if (v4) { if (T == 1) THIN_LAUNCH(4, 1); else if (T == 9) THIN_LAUNCH(4, 9); else THIN_LAUNCH(4, 27); }
       else    { if (T == 1) THIN_LAUNCH(1, 1); else if (T == 9) THIN_LAUNCH(1, 9); else THIN_LAUNCH(1, 27); }
 #undef THIN_LAUNCH
       int rc0 = check_launch("thin_wgrad");
@@ -1016,6 +1096,9 @@ extern "C" int mpgan_conv_backward_weight_bf16dy(const mpgan_conv_geom* g, const
   const int CQ = Cd / 4, PL = 256 / CQ;
   const size_t smem = (size_t)PL * (Cd * T + Cd) * sizeof(float);
   dim3 grid(tp.blocks);
+  if (thin_rows_ok(p, T)) {
+    launch_thin_rows<true>(p, T, tp.blocks, st);
+  } else {
   if (smem > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1029,6 +1112,7 @@ extern "C" int mpgan_conv_backward_weight_bf16dy(const mpgan_conv_geom* g, const
   if (T == 1) hipLaunchKernelGGL((thin_wgrad_kernel<4, 1, true>), grid, dim3(256), smem, st, p);
   else if (T == 9) hipLaunchKernelGGL((thin_wgrad_kernel<4, 9, true>), grid, dim3(256), smem, st, p);
   else hipLaunchKernelGGL((thin_wgrad_kernel<4, 27, true>), grid, dim3(256), smem, st, p);
+  }
   int rc = check_launch("thin_wgrad_bf16dy");
   if (rc) return rc;
   const long total = (long)Cd * T;

@@ -1180,6 +1180,84 @@ static bool thin_cout1_ok(const GatherConv& p) {
          (long)T * p.Cin * 4 <= 48 * 1024;
 }
 
+// Cin == 1 -> 64 channels, stride 1, no padding, 3x3 / 3x3x3 (D.conv1), row-walking form: lane = output channel,
+// one wave walks whole output rows four pixels at a time.  The tap weights of the lane's channel sit in registers;
+// the input samples of the four pixels (a 6-wide window per (kz, ky)) are wave-uniform and arrive through the
+// scalar cache, so an FMA takes them as its scalar operand -- no per-lane addresses, bounds tests or LDS reads --
+// and a pixel's 64 channels leave as ONE contiguous 128 / 256-byte store.  The last group of a row is re-anchored
+// at Mx - 4 (re-stores the same values; statistics count each pixel once).  Grid and statistics rows as
+// thin_cin1_full_kernel's: one [sum | sum^2] row per block over whatever pixels its four waves walked.
+template <int T, bool OUT_BF16>
+__global__ __launch_bounds__(256) void thin_cin1_rows_kernel(const GatherConv p) {
+  __shared__ float red[4][128];
+  constexpr int KZ = T == 27 ? 3 : 1;
+  const Phase& ph = p.ph[0];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int rows = p.N * ph.Mz * ph.My, Mx = ph.Mx;
+  const int nwaves = (int)gridDim.x * 4, ngroups = (Mx + 3) >> 2;
+  float w[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) w[t] = p.wp[(long)lane * T + t];               // packed [Cout][tap][Cin = 1]
+  const float bv = p.bias ? p.bias[lane] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = (int)blockIdx.x * 4 + wave; r < rows; r += nwaves) {
+    const int my = r % ph.My, q = r / ph.My;
+    const int mz = q % ph.Mz, n = q / ph.Mz;
+    const float* __restrict__ g0 = p.in + (((long)n * p.Di + mz) * p.Hi + my) * p.Wi;
+    const long orow = (long)r * Mx;
+    for (int gi = 0; gi < ngroups; ++gi) {
+      const int x0 = gi + 1 < ngroups ? 4 * gi : Mx - 4;
+      const int first = 4 * gi - x0;
+      float o[4] = {bv, bv, bv, bv};
+#pragma unroll
+      for (int kz = 0; kz < KZ; ++kz)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* __restrict__ src = g0 + ((long)kz * p.Hi + ky) * p.Wi + x0;  // wave-uniform: scalar loads
+          float win[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) win[i] = src[i];
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaf(w[(kz * 3 + ky) * 3 + kx], win[j + kx], o[j]);
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long e = (orow + x0 + j) * p.ldo + lane;
+        if constexpr (OUT_BF16) reinterpret_cast<__bf16*>(p.out)[e] = (__bf16)o[j];
+        else p.out[e] = o[j];
+        const float v = j >= first ? o[j] : 0.f;
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+      }
+    }
+  }
+  if (p.stats) {
+    red[wave][lane] = s1;
+    red[wave][64 + lane] = s2;
+    __syncthreads();
+    if (threadIdx.x < 128)
+      p.stats[(long)blockIdx.x * 128 + threadIdx.x] =
+          (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
+static bool thin_cin1_rows_ok(const GatherConv& p) {
+  static const bool off = getenv("MPGAN_DBG_NO_THIN_ROWS") != nullptr;
+  const int T = p.Kz * p.Ky * p.Kx;
+  const Phase& ph = p.ph[0];
+  return !off && p.Cin == 1 && p.Cout == 64 && p.ldi == 1 && p.nphase == 1 && !p.pro.scale && !p.resid && !p.tanh_out &&
+         !p.stats_acc && !p.in_bf16 && (T == 9 || T == 27) && p.Kx == 3 && p.Ky == 3 && p.Kz == (T == 27 ? 3 : 1) &&
+         ph.nx == 3 && ph.ny == 3 && ph.nz == p.Kz && ph.dx0 == 0 && ph.dy0 == 0 && ph.dz0 == 0 && ph.kx0 == 0 &&
+         ph.ky0 == 0 && ph.kz0 == 0 && p.dstep[0] == 1 && p.dstep[1] == 1 && p.dstep[2] == 1 && p.kstep[0] == 1 &&
+         p.kstep[1] == 1 && p.kstep[2] == 1 && p.istride[0] == 1 && p.istride[1] == 1 && p.istride[2] == 1 &&
+         p.ostride[0] == 1 && p.ostride[1] == 1 && p.ostride[2] == 1 && ph.oz == 0 && ph.oy == 0 && ph.ox == 0 &&
+         ph.Mx >= 4 && p.Wi == ph.Mx + 2 && p.Hi == ph.My + 2 && p.Di == ph.Mz + (T == 27 ? 2 : 0) && p.Wo == ph.Mx &&
+         p.Ho == ph.My && p.Do == ph.Mz;
+}
+
 static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
   const int T = p.Kz * p.Ky * p.Kx;
   if (p.out_bf16) {     // 1 -> C conv writing bf16 (D.conv1 of the bf16 path): all-channel kernel only
@@ -1189,6 +1267,11 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
                       "thin conv (bf16 out): needs Cin == 1, Cout in {16, 32, 64}, no resid/tanh, aligned output");
     MPGAN_UNSUPPORTED(p.stats && p.Cout > 64, "thin conv (bf16 out): fused statistics up to 64 channels");
     dim3 grid((unsigned)((maxM + 255) / 256), 1, (unsigned)p.nphase);
+    if (thin_cin1_rows_ok(p)) {
+      if (T == 9) hipLaunchKernelGGL((thin_cin1_rows_kernel<9, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((thin_cin1_rows_kernel<27, true>), grid, dim3(256), 0, st, p);
+      return check_launch("thin_cin1_rows_bf16");
+    }
     const size_t smem = ((size_t)((T * p.Cout + 3) & ~3) + (p.stats ? 256 * (size_t)(p.Cout + 1) : 0)) * sizeof(float);
     if (p.Cout == 16) hipLaunchKernelGGL((thin_cin1_full_kernel<4, true>), grid, dim3(256), smem, st, p);
     else if (p.Cout == 32) hipLaunchKernelGGL((thin_cin1_full_kernel<8, true>), grid, dim3(256), smem, st, p);
@@ -1227,6 +1310,11 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
                       "thin conv: fused statistics need the all-channel kernel (Cout 16 or 32, 16-byte aligned output/bias)");
     if (full) {
       dim3 grid((unsigned)((maxM + 255) / 256), 1, (unsigned)p.nphase);
+      if (!p.stats && thin_cin1_rows_ok(p)) {
+        if (T == 9) hipLaunchKernelGGL((thin_cin1_rows_kernel<9, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((thin_cin1_rows_kernel<27, false>), grid, dim3(256), 0, st, p);
+        return check_launch("thin_cin1_rows");
+      }
       const size_t smem = ((size_t)((T * p.Cout + 3) & ~3) + ((p.stats || p.stats_acc) ? 256 * (size_t)(p.Cout + 1) : 0)) * sizeof(float);
       if (p.Cout == 16) hipLaunchKernelGGL(thin_cin1_full_kernel<4>, grid, dim3(256), smem, st, p);
       else if (p.Cout == 32) hipLaunchKernelGGL(thin_cin1_full_kernel<8>, grid, dim3(256), smem, st, p);

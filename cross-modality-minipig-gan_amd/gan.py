@@ -203,7 +203,10 @@ class GAN(nn.Module):
                                            storage_dtype=storage_dtype)
         self.logged: Dict[str, torch.Tensor] = {}
         self.ddp = None  # set by parallel.DataParallelGAN
-        self.overlap_streams = not os.environ.get("MPGAN_SINGLE_STREAM")
+        # D step: run G(t1w) on a second stream underneath D(real)?  Measured in round 2 (20-step benches, same box):
+        # 59.1 vs 58.6 ms at C3 and 174.3 vs 175.8 ms at C5 with / without -- nothing beyond run-to-run spread, while
+        # D's forward kernels stretch up to 3x under the contention.  Off by default; MPGAN_GFWD_OVERLAP=1 turns it on.
+        self.overlap_streams = bool(os.environ.get("MPGAN_GFWD_OVERLAP")) and not os.environ.get("MPGAN_SINGLE_STREAM")
 
     def forward(self, x):
         return self.generator(x)
@@ -234,9 +237,9 @@ class GAN(nn.Module):
         if optimizer_idx == 1:                      # GAN_final.py:276-296
             valid = torch.full((t1w_images.shape[0], 1), float(self.hparams.one_sided_label_value),
                                device=t1w_images.device, dtype=t1w_images.dtype)
-            # D(real) and G(t1w) are independent: the generator's forward (a chain of ~300 small,
-            # latency-bound launches) runs on the second stream underneath the discriminator's
-            # matrix-bound forward.  Same values, same BatchNorm running-stat order (D sees real, then fake).
+            # D(real) and G(t1w) are independent: with `overlap_streams` the generator's forward (a chain of ~230
+            # small, latency-bound launches) runs on the second stream underneath the discriminator's matrix-bound
+            # forward.  Same values, same BatchNorm running-stat order (D sees real, then fake).  Off by default.
             main = torch.cuda.current_stream()
             side = engine.fast_stream(t1w_images.device) if self.overlap_streams else None
             if side is not None:

@@ -17,6 +17,21 @@ struct Phase {
   int dz0, dy0, dx0;  // input offset of tap j:  d0 + dstep*j
 };
 
+// Backward-data launches of the K-stepped kernels: norm-backward partial sums of the gradient they produce.
+// The epilogue holds g (the gradient w.r.t. the activation a = act(bn(z))) in registers; with z and the layer's
+// norm vectors it leaves, per tile, sum(gy), sum(gy * zhat), sum(g * min(y, 0)) -- what norm_bwd_reduce would
+// re-read g and z for (one [3][C] row per (phase, m-tile), any row order: the finalize adds them all).
+struct BwdStats {
+  const float* z;
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  float* part;
+  int ldz, leaky;
+  float slope;
+};
+
 struct GatherConv {
   const float* in;
   const float* wp;
@@ -37,6 +52,7 @@ struct GatherConv {
   long long* stats_acc;  // fixed-point statistics accumulators [acc_rep][4][Cout] instead of `stats` rows (norm_fold.h)
   int acc_rep;
   NormFold fold;         // consumer side: fold the producer's accumulators into the prologue's scale / shift
+  BwdStats bwd;          // see above (part == null: off)
   int in_bf16, out_bf16; // thin (VALU) kernels of the bf16 path: `in` / `out` point at bf16 data (weights stay fp32)
   Phase ph[8];
 };

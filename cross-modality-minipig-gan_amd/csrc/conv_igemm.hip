@@ -89,10 +89,38 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
     cov[tn] = n0 + (wn * TN + tn) * 32 + li;
     bv[tn] = (p.bias && cov[tn] < Cout) ? p.bias[cov[tn]] : 0.f;
   }
+  // fused norm-backward sums of the produced gradient (BwdStats): per-column vectors and running sums
+  const bool bw = p.bwd.part != nullptr;
+  float bsc[TN], bsh[TN], bmu[TN], bis[TN], b1[TN], b2[TN], b3[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const bool okc = bw && cov[tn] < Cout;
+    bsc[tn] = okc ? p.bwd.scale[cov[tn]] : 0.f;
+    bsh[tn] = okc ? p.bwd.shift[cov[tn]] : 0.f;
+    bmu[tn] = okc ? p.bwd.mean[cov[tn]] : 0.f;
+    bis[tn] = okc ? p.bwd.invstd[cov[tn]] : 0.f;
+    b1[tn] = b2[tn] = b3[tn] = 0.f;
+  }
+  const bool bleaky = p.bwd.leaky != 0;
+  const float bslope = p.bwd.slope;
   // row-major walk: the 64-bit pixel offset is formed once per row, not once per element
   if (active)
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+  for (int tm = 0; tm < TM; ++tm) {
+    // BwdStats: the tile's z values are fetched in ONE batch in front of the stores (loads between the stores could
+    // not be hoisted over them -- the compiler cannot rule out aliasing -- and would each wait out a full round trip)
+    float zv[16][TN];
+    if (bw) {
+      const float* __restrict__ zb = p.bwd.z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int pix = rowpix[row];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          zv[r][tn] = (pix >= 0 && cov[tn] < Cout) ? zb[(long)pix * p.bwd.ldz + cov[tn]] : 0.f;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -107,8 +135,50 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
         if (rrow) v += rrow[cov[tn]];
         if (tanh_out) v = tanhf(v);
         orow[cov[tn]] = v;
+        if (bw) {                            // as norm_bwd_reduce_kernel (norm_ops.hip), element by element
+          const float zz = zv[r][tn];
+          const float y = zz * bsc[tn] + bsh[tn];
+          const float zh = (zz - bmu[tn]) * bis[tn];
+          const bool neg = bleaky && y < 0.f;
+          const float gy = neg ? v * bslope : v;
+          b1[tn] += gy;
+          b2[tn] += gy * zh;
+          b3[tn] += neg ? v * y : 0.f;
+        }
       }
     }
+  }
+  if (bw) {
+    // the two half-waves (shuffle), then the WM waves sharing a column range (LDS, fixed order): no atomics
+    constexpr int WMB = 4 / WN;
+    float* stb = lds + 1024;                // [WMB][3][BN], clear of rowpix
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = (wn * TN + tn) * 32 + li;
+      b1[tn] += __shfl_xor(b1[tn], 32, 64);
+      b2[tn] += __shfl_xor(b2[tn], 32, 64);
+      b3[tn] += __shfl_xor(b3[tn], 32, 64);
+      if (active && lh == 0) {
+        stb[(wm * 3 + 0) * BN + col] = b1[tn];
+        stb[(wm * 3 + 1) * BN + col] = b2[tn];
+        stb[(wm * 3 + 2) * BN + col] = b3[tn];
+      }
+    }
+    __syncthreads();
+    if (active && tid < BN && n0 + tid < Cout) {
+      float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WMB; ++w) {
+        t1 += stb[(w * 3 + 0) * BN + tid];
+        t2 += stb[(w * 3 + 1) * BN + tid];
+        t3 += stb[(w * 3 + 2) * BN + tid];
+      }
+      float* row = p.bwd.part + (long)stats_row * 3 * Cout;
+      row[n0 + tid] = t1;
+      row[Cout + n0 + tid] = t2;
+      row[2 * Cout + n0 + tid] = t3;
+    }
+  }
   if (p.stats || p.stats_acc) {
     // Fused BatchNorm statistics of z = acc + bias over this tile's valid rows.  Rows without
     // an output pixel carry acc == 0 exactly (their A rows are zero-filled), so the raw column
@@ -208,6 +278,12 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
       float* row = p.stats + (long)stats_row * 2 * p.Cout;
       row[n0 + tid] = 0.f;
       row[p.Cout + n0 + tid] = 0.f;
+    }
+    if (p.bwd.part && tid < BN && n0 + tid < p.Cout) {
+      float* row = p.bwd.part + (long)stats_row * 3 * p.Cout;
+      row[n0 + tid] = 0.f;
+      row[p.Cout + n0 + tid] = 0.f;
+      row[2 * p.Cout + n0 + tid] = 0.f;
     }
     return;
   }
@@ -494,6 +570,12 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
       float* row = p.stats + (long)stats_row * 2 * p.Cout;
       row[n0 + tid] = 0.f;
       row[p.Cout + n0 + tid] = 0.f;
+    }
+    if (p.bwd.part && kg == 0 && tid < BN && n0 + tid < p.Cout) {
+      float* row = p.bwd.part + (long)stats_row * 3 * p.Cout;
+      row[n0 + tid] = 0.f;
+      row[p.Cout + n0 + tid] = 0.f;
+      row[2 * p.Cout + n0 + tid] = 0.f;
     }
     return;
   }
@@ -2405,12 +2487,14 @@ static int launch_gather(const GatherConv& p, hipStream_t st) {
                     "gather_conv: fold-on-load is per channel (BatchNorm) over >= Cin accumulator columns");
   if (variant <= 2) {
     MPGAN_UNSUPPORTED(p.fold.acc != nullptr, "thin conv: no fold-on-load");
+    MPGAN_UNSUPPORTED(p.bwd.part != nullptr, "thin conv: no fused norm-backward sums (mpgan_conv_bwd_stats_rows() == 0)");
     return launch_thin(p, maxM, st);
   }
   {
     PatchLaunch pl;
     int smem = 0;
     if (patch_plan(p, &pl, &smem)) {
+      MPGAN_UNSUPPORTED(p.bwd.part != nullptr, "patch kernel: no fused norm-backward sums (mpgan_conv_bwd_stats_rows() == 0)");
       const bool aligned = (p.ldi % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0) &&
                            ((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0) &&
                            (!p.pro.scale || ((reinterpret_cast<uintptr_t>(p.pro.scale) |
@@ -2654,6 +2738,46 @@ extern "C" int mpgan_conv_backward_data(const mpgan_conv_geom* g, const float* d
   p.in = dy; p.wp = w_packed_bwd; p.out = dx; p.bias = nullptr; p.resid = resid;
   p.pro = make_pro(nullptr);
   p.ldi = lddy; p.ldo = lddx; p.ldr = ldr; p.tanh_out = 0;
+  if (!g->transposed)
+    build_transposed(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
+  else
+    build_forward(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
+  return launch_gather(p, (hipStream_t)stream);
+}
+
+// Partial rows mpgan_conv_backward_data_stats leaves for this geometry; 0 = that launch is served by a thin or
+// patch kernel, which has no fused sums (run mpgan_norm_bwd_reduce instead).
+extern "C" int32_t mpgan_conv_bwd_stats_rows(const mpgan_conv_geom* g) {
+  const int v = mpgan_conv_variant(g, 1, 0);
+  if (v < 32 || v == 1128) return 0;
+  GatherConv p{};
+  if (!g->transposed) build_transposed(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
+  else build_forward(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
+  return (int32_t)((max_phase_pixels(p) + BM - 1) / BM) * p.nphase;
+}
+
+// mpgan_conv_backward_data + the reduce pass of the norm layer in front of this conv's input, in one launch:
+// dx is the gradient w.r.t. a = act(scale * z + shift); partials[rows][3][Cin] receive the sums mpgan_norm_bwd_reduce
+// would form from dx and z (BatchNorm: scale / shift / mean / invstd hold Cin values; any number of rows feeds
+// mpgan_norm_bwd_finalize with n = 1, chunks = rows).
+extern "C" int mpgan_conv_backward_data_stats(const mpgan_conv_geom* g, const float* dy, int32_t lddy,
+                                              const float* w_packed_bwd, float* dx, int32_t lddx, const float* z,
+                                              int32_t ldz, const float* scale, const float* shift, const float* mean,
+                                              const float* invstd, int32_t act, float slope, float* partials,
+                                              void* stream) {
+  int rc = check_geom(g);
+  if (rc) return rc;
+  MPGAN_CHECK_ARG(dy && w_packed_bwd && dx && z && scale && shift && mean && invstd && partials,
+                  "conv_backward_data_stats: null pointer");
+  MPGAN_CHECK_ARG(lddy >= g->cout && lddx >= g->cin && ldz >= g->cin, "conv_backward_data_stats: bad pitch");
+  MPGAN_UNSUPPORTED(mpgan_conv_bwd_stats_rows(g) == 0, "conv_backward_data_stats: this geometry is served by a kernel "
+                                                      "without fused sums (mpgan_conv_bwd_stats_rows() == 0)");
+  GatherConv p{};
+  p.in = dy; p.wp = w_packed_bwd; p.out = dx; p.bias = nullptr; p.resid = nullptr;
+  p.pro = make_pro(nullptr);
+  p.ldi = lddy; p.ldo = lddx; p.ldr = 0; p.tanh_out = 0;
+  p.bwd.z = z; p.bwd.ldz = ldz; p.bwd.scale = scale; p.bwd.shift = shift; p.bwd.mean = mean; p.bwd.invstd = invstd;
+  p.bwd.leaky = act == MPGAN_ACT_LEAKY; p.bwd.slope = slope; p.bwd.part = partials;
   if (!g->transposed)
     build_transposed(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
   else

@@ -553,6 +553,27 @@ def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):
              desc=_gdesc(g), tag=("dgrad:" + gather_kernel_name(g, True, False), 2.0 * conv_macs(g)))
 
 
+_FUSE_BWD_STATS = not os.environ.get("MPGAN_DBG_NO_FUSE_BWD_STATS")
+
+
+def emit_conv_dgrad_stats(prog, g: ConvGeom, dy, wp_bwd, dx, z, nb: "NormBuf", slope: float, partials) -> int:
+    """Backward-data whose epilogue also leaves the norm-backward partial sums of dx against z (the raw output of
+    the layer in front, BatchNorm + LeakyReLU(slope)): returns the number of rows, 0 when this geometry has no
+    fused sums (then the plain launch is emitted and the caller runs the reduce pass)."""
+    rows = ops.conv_bwd_stats_rows(g) if _FUSE_BWD_STATS and not nb.instance else 0
+    if not rows or partials.numel() < rows * 3 * g.cin:
+        emit_conv_dgrad(prog, g, dy, wp_bwd, dx)
+        return 0
+    ops._check_in_out(g, dx, dy, "plan conv_backward_data_stats")
+    gc = g.c()
+    prog.add("conv_backward_data", lib().mpgan_conv_backward_data_stats, C.byref(gc), dy.data_ptr(), _ld(dy),
+             wp_bwd.data_ptr(), dx.data_ptr(), _ld(dx), z.data_ptr(), _ld(z), nb.scale.data_ptr(), nb.shift.data_ptr(),
+             nb.mean.data_ptr(), nb.invstd.data_ptr(), ACT_LEAKY, float(slope), partials.data_ptr(),
+             keep=(gc, dy, wp_bwd, dx, z, nb, partials), desc=_gdesc(g),
+             tag=("dgrad:" + gather_kernel_name(g, True, False), 2.0 * conv_macs(g)))
+    return rows
+
+
 def emit_conv_wgrad(prog, g: ConvGeom, x, dy, dw, ws, pro=None, dbias=None, lane=0):
     """dW += wgrad; for a ConvNd, dbias += colsum(dy) rides along in the same kernel."""
     ops._check_in_out(g, x, dy, "plan conv_backward_weight")
@@ -698,9 +719,11 @@ def emit_norm_act_add(prog, z, pz, r, pr, out, tanh=False, fold=None):
              keep=(z, pzc, pz, fold, r, prc, pr, out))
 
 
-def emit_norm_bwd(prog, g, z, nb: NormBuf, pro: Prologue, dz, partials, dgamma, dbeta, dslope, peer=None):
+def emit_norm_bwd(prog, g, z, nb: NormBuf, pro: Prologue, dz, partials, dgamma, dbeta, dslope, peer=None, reduced_rows=0):
     """reduce -> finalize -> apply.  dgamma/dbeta/dslope are gradient views
-    (accumulated into) or None when the owner's parameters are frozen."""
+    (accumulated into) or None when the owner's parameters are frozen.
+    reduced_rows > 0: `partials` already holds that many [3][C] rows, left by the backward-data launch that
+    produced g (emit_conv_dgrad_stats) -- no reduce pass."""
     n, P, ldz = ops._cl(z, "norm_bwd z")
     assert g.shape == z.shape and dz.shape == z.shape
     c = z.shape[-1]
@@ -710,6 +733,14 @@ def emit_norm_bwd(prog, g, z, nb: NormBuf, pro: Prologue, dz, partials, dgamma, 
     pc = pro.c()
     pe = peer.c() if peer is not None else None
     pe_ref = C.byref(pe) if pe is not None else None
+    if reduced_rows:
+        assert peer is None and not nb.instance and partials.numel() >= reduced_rows * 3 * c
+        prog.add("norm_bwd_finalize", L.mpgan_norm_bwd_finalize, partials.data_ptr(), 1, reduced_rows, c, n * P, 0,
+                 _p(dgamma), _p(dbeta), _p(dslope), nb.c1.data_ptr(), nb.c2.data_ptr(), keep=(dgamma, dbeta, dslope))
+        prog.add("norm_bwd_apply", L.mpgan_norm_bwd_apply, g.data_ptr(), _ld(g), z.data_ptr(), ldz, C.byref(pc),
+                 nb.mean.data_ptr(), nb.invstd.data_ptr(), nb.c1.data_ptr(), nb.c2.data_ptr(), pe_ref, n, P, c,
+                 dz.data_ptr(), _ld(dz), keep=(dz, g, z, pc, pro, nb, partials))
+        return
     prog.add("norm_bwd_reduce", L.mpgan_norm_bwd_reduce, g.data_ptr(), _ld(g), z.data_ptr(), ldz, C.byref(pc),
              nb.mean.data_ptr(), nb.invstd.data_ptr(), pe_ref, n, P, c, partials.data_ptr(),
              keep=(g, z, pc, pro, nb, partials, pe, peer))
@@ -1244,6 +1275,8 @@ class DiscPlan:
             recs.append(store.register_conv(cv, cout=cv.out_channels, cin=cv.in_channels, taps=taps))
             scratch.want_partials(n, size[0] * size[1] * size[2], cv.out_channels)
             scratch.want_ws(g)
+            if g.cin > 1:          # rows of the backward-data launch that also reduces the previous layer's norm backward
+                scratch.partials_need = max(scratch.partials_need, ops.conv_bwd_stats_rows(g) * 3 * g.cin)
         P_last = size[0] * size[1] * size[2]
         c_last = convs[-1].out_channels
         if lin.in_features != P_last * c_last:
@@ -1281,16 +1314,21 @@ class DiscPlan:
         b.add("linear1_backward", L.mpgan_linear1_backward, zs[-1].data_ptr(), C.byref(pc), n, P_last, c_last,
               store.wp(rlin).data_ptr(), dlogit.data_ptr(), gas[-1].data_ptr(), _p(gv(lin.weight)), _p(gv(lin.bias)),
               1.0, keep=(gas,))
+        reduced = 0                                  # rows the previous backward-data launch left in `part`
         for i in range(3, -1, -1):
             pro_i = lrelu(nbs[i])
-            emit_norm_bwd(b, gas[i], zs[i], nbs[i], pro_i, gas[i], part, gv(bns[i].weight), gv(bns[i].bias), None)
+            emit_norm_bwd(b, gas[i], zs[i], nbs[i], pro_i, gas[i], part, gv(bns[i].weight), gv(bns[i].bias), None,
+                          reduced_rows=reduced)
             src = zs[i - 1] if i > 0 else self.x_in
             pro_in = lrelu(nbs[i - 1]) if i > 0 else None
             if want_param_grads:
                 emit_conv_wgrad(b, geoms[i], src, gas[i], gv(convs[i].weight), ws, pro=pro_in,
                                 dbias=gv(convs[i].bias), lane=1)
             if i > 0:
-                emit_conv_dgrad(b, geoms[i], gas[i], store.wp_bwd(recs[i]), gas[i - 1])
+                # the gradient w.r.t. a_{i-1} = LeakyReLU(BN(z_{i-1})): the epilogue of this launch also forms the
+                # norm-backward sums of layer i-1, so that layer needs no reduce pass over g and z
+                reduced = emit_conv_dgrad_stats(b, geoms[i], gas[i], store.wp_bwd(recs[i]), gas[i - 1], zs[i - 1],
+                                                nbs[i - 1], 0.2, part)
             elif want_input_grad:
                 self.g_x = E(n, *dhw, 1)
                 emit_conv_dgrad(b, geoms[0], gas[0], store.wp_bwd(recs[0]), self.g_x)

@@ -223,6 +223,31 @@ def conv_backward_data(g: ConvGeom, dy, w_packed_bwd, dx, *, resid=None):
     return dx
 
 
+def conv_bwd_stats_rows(g: ConvGeom) -> int:
+    """Partial rows conv_backward_data_stats leaves for this geometry (0: no fused sums for it)."""
+    gc = g.c()
+    return int(lib().mpgan_conv_bwd_stats_rows(C.byref(gc)))
+
+
+def conv_backward_data_stats(g: ConvGeom, dy, w_packed_bwd, dx, z, scale, shift, mean, invstd, act: int, slope: float,
+                             partials):
+    """dx = conv_backward_data(dy) and, from the same launch, the norm-backward partial sums of dx against z
+    (partials[rows][3][Cin]; see include/mpgan_hip.h)."""
+    _check_in_out(g, dx, dy, "conv_backward_data_stats")
+    _, _, lddy = _cl(dy, "conv_backward_data_stats dy")
+    _, _, lddx = _cl(dx, "conv_backward_data_stats dx")
+    _, _, ldz = _cl(z, "conv_backward_data_stats z")
+    rows = conv_bwd_stats_rows(g)
+    if z.shape != dx.shape or partials.numel() < rows * 3 * g.cin:
+        raise ValueError("conv_backward_data_stats: z must match dx and partials hold rows*3*Cin floats")
+    gc = g.c()
+    check(lib().mpgan_conv_backward_data_stats(C.byref(gc), dy.data_ptr(), lddy, w_packed_bwd.data_ptr(), dx.data_ptr(),
+                                               lddx, z.data_ptr(), ldz, scale.data_ptr(), shift.data_ptr(),
+                                               mean.data_ptr(), invstd.data_ptr(), int(act), float(slope),
+                                               partials.data_ptr(), _stream()), "conv_backward_data_stats")
+    return rows
+
+
 def conv_wgrad_workspace(g: ConvGeom) -> int:
     gc = g.c()
     return int(lib().mpgan_conv_wgrad_workspace(C.byref(gc)))

@@ -109,6 +109,21 @@ int mpgan_conv_backward_data(const mpgan_conv_geom* g, const float* dy, int32_t 
                              const float* resid, int32_t ldr,
                              float* dx, int32_t lddx, void* stream);
 
+/* Backward-data AND the reduce pass of the norm layer in front of the conv's input, in one launch: dx is the
+ * gradient w.r.t. a = act(scale*z + shift); partials[rows][3][Cin] receive, per tile, the sums
+ * mpgan_norm_bwd_reduce would form by re-reading dx and z (sum gy, sum gy*zhat, sum g*min(y,0)); feed them to
+ * mpgan_norm_bwd_finalize with n = 1, chunks = rows.  BatchNorm only (scale/shift/mean/invstd: Cin values).
+ * mpgan_conv_bwd_stats_rows: rows the launch leaves; 0 = this geometry is served by a thin or patch kernel
+ * without fused sums.
+ * Replaces: the autograd backward of `Conv -> BatchNorm -> LeakyReLU` chains of the discriminator
+ * (GAN_final.py:167-189 under loss.backward(), :273,296). */
+int32_t mpgan_conv_bwd_stats_rows(const mpgan_conv_geom* g);
+int mpgan_conv_backward_data_stats(const mpgan_conv_geom* g, const float* dy, int32_t lddy,
+                                   const float* w_packed_bwd, float* dx, int32_t lddx,
+                                   const float* z, int32_t ldz, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, int32_t act, float slope,
+                                   float* partials, void* stream);
+
 /* Which kernel serves this geometry (for profiling labels): 1 = thin Cin==1 VALU
  * stencil, 2 = thin Cout==1 VALU stencil, 16 = fp32-MFMA patch kernel (2-D, <= 32
  * output channels, input patch + weights staged once in LDS; 17 = its merged form, one block per

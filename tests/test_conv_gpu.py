@@ -523,3 +523,39 @@ def test_batchnorm_statistics_through_accumulators_and_fold_on_load(cin, c, k, s
         s2 = A[2] / 256.0 + A[3] / 2.0 ** 56
         assert_close(s1.float(), z2_ref.double().sum((0, 2, 3)).float(), rtol=1e-4, what="accumulated sum")
         assert_close(s2.float(), (z2_ref.double() ** 2).sum((0, 2, 3)).float(), rtol=1e-4, what="accumulated sum of squares")
+
+
+@pytest.mark.parametrize("cin,cout,k,s,spatial,n", [(64, 128, 3, 1, (30, 26), 3), (128, 256, 4, 2, (22, 26), 2),
+                                                    (256, 256, 4, 2, (13, 11), 2), (64, 72, 3, 1, (9, 9, 10), 1)])
+def test_backward_data_with_fused_norm_backward_sums(cin, cout, k, s, spatial, n):
+    """mpgan_conv_backward_data_stats: the same dx as the plain launch, bit for bit, and partial rows whose column
+    sums equal what mpgan_norm_bwd_reduce forms by re-reading dx and z (BatchNorm + LeakyReLU(0.2) in front of the
+    conv's input: the discriminator's Conv -> BN -> LeakyReLU chain, GAN_final.py:167-189)."""
+    from mpgan_amd import ops
+    dims = len(spatial)
+    g = _geom(dims, n, cin, cout, k, s, 0, spatial)
+    rows = ops.conv_bwd_stats_rows(g)
+    assert rows > 0
+    gen = torch.Generator(device="cuda").manual_seed(31 + cin)
+    R = lambda *shape: torch.rand(*shape, device="cuda", generator=gen) * 2 - 1
+    dy = R(n, *g.out_dhw, cout)
+    z = R(n, *g.in_dhw, cin)
+    w = R(cout, cin, *([k] * dims)) / (cin * k ** dims) ** 0.5
+    wpb = ops.pack_weight(w, for_dgrad=True)
+    scale, shift = R(cin) * 0.5 + 1.0, R(cin) * 0.3
+    mean, invstd = R(cin) * 0.2, R(cin) * 0.3 + 1.0
+    dx0 = torch.empty_like(z)
+    ops.conv_backward_data(g, dy, wpb, dx0)
+    dx1 = torch.full_like(z, float("nan"))
+    part = torch.full((rows * 3 * cin,), float("nan"), device="cuda")
+    assert ops.conv_backward_data_stats(g, dy, wpb, dx1, z, scale, shift, mean, invstd, ops.ACT_LEAKY, 0.2, part) == rows
+    assert torch.equal(dx0, dx1)
+    got = part.view(rows, 3, cin).double().sum(0).cpu()
+    y = z.double() * scale.double() + shift.double()
+    zh = (z.double() - mean.double()) * invstd.double()
+    neg = y < 0
+    gy = torch.where(neg, dx0.double() * 0.2, dx0.double())
+    want = torch.stack([gy.reshape(-1, cin).sum(0), (gy * zh).reshape(-1, cin).sum(0),
+                        torch.where(neg, dx0.double() * y, torch.zeros_like(y)).reshape(-1, cin).sum(0)]).cpu()
+    scale_ = (gy.abs().reshape(-1, cin).sum(0).max().item())
+    assert (got - want).abs().max().item() <= 2e-5 * scale_, ((got - want).abs().max().item(), scale_)

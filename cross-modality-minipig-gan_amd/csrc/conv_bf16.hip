@@ -407,11 +407,315 @@ static int hb_check(const GatherConv& p, const char* what) {
   return MPGAN_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Patch form for stride-1 3x3x3 gathers (D.conv2 forward and backward-data at config C5: 64 -> 128 and 128 -> 64
+// channels, 27 taps).  The K-stepped kernel above re-stages every input pixel once per tap (27 x) and is bound by
+// the L2 -> LDS fill rate.  Here a block owns a 4 x 8 x 8 block of output pixels: the 6 x 10 x 10
+// input patch of one 64-channel chunk (75 KiB) is staged ONCE and all 27 taps read their A fragments from it at a
+// wave-uniform row offset; only the weights stream through the three-stage ring (BN rows x 128 B per tap).  Staged
+// bytes per FLOP drop 2.5x (forward) / 3.4x (backward-data).  Out-of-range patch rows (image borders, the
+// backward-data gather's halo) read the zero page, so no tap masks exist.  Eight waves, 64 x 64 (BN = 128) or
+// 64 x 32 (BN = 64) per wave; epilogue, statistics rows (one per tile) and swizzles as above.
+// ---------------------------------------------------------------------------
+constexpr int HP_TZ = 4, HP_TY = 8, HP_TX = 8;                 // output pixels per tile: 256
+constexpr int HP_PY = HP_TY + 2, HP_PX = HP_TX + 2;
+constexpr int HP_PROWS = (HP_TZ + 2) * HP_PY * HP_PX;          // 600 patch rows of 128 B
+constexpr int HP_PATCH = HP_PROWS * HB_ROWB;                   // 76,800 B
+constexpr int HP_PPIECES = (HP_PROWS * 8 + 511) / 512;         // LDS-DMA instructions per thread for one patch: 10
+
+template <int BN>
+struct HpTile {
+  static constexpr int WM = 4, WN = 2, TM = 2, TN = BN / WN / 32;
+  static constexpr int BPIECES = BN / 64;
+  static constexpr int BSTAGE = BN * HB_ROWB;
+  static constexpr int IMG_PITCH = BN + 4;
+  static constexpr int ROWPIX = HB_BM * IMG_PITCH * 4;
+  static constexpr int SMEM_LOOP = HP_PATCH + 3 * BSTAGE;
+  static constexpr int SMEM_EPI = ROWPIX + HB_BM * 4 + 4096;
+  static constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
+};
+
+struct HpGrid { int tiles_z, tiles_y, tiles_x; };
+
+template <int BN>
+__global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherConv p, const HpGrid tg) {
+  using T = HpTile<BN>;
+  constexpr int TM = T::TM, TN = T::TN, WN = T::WN;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const BlockId bid = conv_block_id(p);
+  const Phase& ph = p.ph[0];
+  const int n0 = bid.nt * BN;
+  const int stats_row = bid.mt;
+  const int Cout = p.Cout, Cin = p.Cin, Di = p.Di, Hi = p.Hi, Wi = p.Wi, ldi = p.ldi;
+  // tile origin
+  int t = bid.mt;
+  const int tx = t % tg.tiles_x; t /= tg.tiles_x;
+  const int ty = t % tg.tiles_y; t /= tg.tiles_y;
+  const int tz = t % tg.tiles_z;
+  const int n = t / tg.tiles_z;
+  const int oz0 = tz * HP_TZ, oy0 = ty * HP_TY, ox0 = tx * HP_TX;
+  // patch origin in the gathered tensor: the smallest input coordinate any tap of the tile's first pixel reads
+  const int mnz = ph.dz0 + (p.dstep[0] < 0 ? 2 * p.dstep[0] : 0), mny = ph.dy0 + (p.dstep[1] < 0 ? 2 * p.dstep[1] : 0),
+            mnx = ph.dx0 + (p.dstep[2] < 0 ? 2 * p.dstep[2] : 0);
+  const int pz0 = oz0 + mnz, py0 = oy0 + mny, px0 = ox0 + mnx;
+  const char* __restrict__ ginb = reinterpret_cast<const char*>(p.in);
+  const char* __restrict__ gwb = reinterpret_cast<const char*>(p.wp);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  // ---- this thread's patch pieces: piece q = tid + 512 i -> patch row q >> 3, LDS chunk position q & 7 ----
+  unsigned ppB[HP_PPIECES];            // byte offset of (pixel, channel 0) or ~0u: out of range / beyond the patch
+  const int pck = (tid & 7) ^ (((tid >> 3) >> 1) & 7);      // source chunk: (row >> 1) & 7 with row = (q >> 3); 64 i drops out
+#pragma unroll
+  for (int i = 0; i < HP_PPIECES; ++i) {
+    const int pr = (tid >> 3) + 64 * i;
+    const int pz = pr / (HP_PY * HP_PX), rem = pr - pz * (HP_PY * HP_PX);
+    const int py = rem / HP_PX, px = rem - py * HP_PX;
+    const int iz = pz0 + pz, iy = py0 + py, ix = px0 + px;
+    const bool ok = pr < HP_PROWS && (unsigned)iz < (unsigned)Di && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+    ppB[i] = ok ? (unsigned)((((n * Di + iz) * Hi + iy) * Wi + ix)) * (unsigned)ldi * 2u : 0xFFFFFFFFu;
+  }
+  const int r0 = tid >> 3, cc = tid & 7;
+  const int ck = cc ^ ((r0 >> 1) & 7);
+  const unsigned Ktot2 = (unsigned)(p.Kz * p.Ky * p.Kx * Cin) * 2u;
+  unsigned wrowB[T::BPIECES];
+#pragma unroll
+  for (int i = 0; i < T::BPIECES; ++i) {
+    int co = n0 + r0 + 64 * i;
+    co = co < Cout ? co : Cout - 1;
+    wrowB[i] = (unsigned)co * Ktot2;
+  }
+  const int nchunk = Cin / HB_BK;
+  char* const patch = lds;
+  char* const bring = lds + HP_PATCH;
+
+  auto issue_patch = [&](int chunk) {
+    const unsigned ciB = (unsigned)(chunk * HB_BK + pck * 8) * 2u;
+#pragma unroll
+    for (int i = 0; i < HP_PPIECES; ++i) {
+      const int pr = (tid >> 3) + 64 * i;
+      if (pr < HP_PROWS) {
+        const char* src = ppB[i] != 0xFFFFFFFFu ? ginb + (ppB[i] + ciB) : zero;
+        GLDS16(src, patch + (8 * wid + 64 * i) * HB_ROWB);
+      }
+    }
+  };
+  // weights of tap (jz, jy, jx) of the current chunk -> ring stage
+  int jx = 0, jy = 0, jz = 0, bstage = 0;
+  auto issue_b = [&](int chunk) {
+    const int kz = ph.kz0 + p.kstep[0] * jz, ky = ph.ky0 + p.kstep[1] * jy, kx = ph.kx0 + p.kstep[2] * jx;
+    const unsigned woffB = (unsigned)(((kz * p.Ky + ky) * p.Kx + kx) * Cin * 2);
+    const unsigned ciB = (unsigned)(chunk * HB_BK + ck * 8) * 2u;
+    char* Bs = bring + bstage * T::BSTAGE + (8 * wid) * HB_ROWB;
+#pragma unroll
+    for (int i = 0; i < T::BPIECES; ++i) GLDS16(gwb + (wrowB[i] + woffB + ciB), Bs + 64 * i * HB_ROWB);
+    jx += 1;
+    if (jx == 3) { jx = 0; jy += 1; }
+    if (jy == 3) { jy = 0; jz += 1; }
+    if (jz == 3) jz = 0;
+    bstage = bstage == 2 ? 0 : bstage + 1;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // A fragments: tile row of lane li in wave tile tm -> its patch row at tap offset (0, 0, 0)
+  int abase[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int q = wm * 64 + tm * 32 + li;
+    abase[tm] = ((q >> 6) * HP_PY + ((q >> 3) & 7)) * HP_PX + (q & 7);
+  }
+  // B fragments as in the K-stepped kernel
+  const int sw = (li >> 1) & 7;
+  int foff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) foff[s] = ((2 * s + lh) ^ sw) * 16;
+  const int brow = (wn * (BN / WN) + li) * HB_ROWB;
+  const unsigned lds_base = lds_addr(lds);
+  const unsigned ring_base = lds_base + HP_PATCH;
+
+  i32x4 fa[2][TM], fb[2][TN];
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    // every wave is done with the previous chunk's patch and ring: stage the new patch and the first two taps
+    asm volatile("s_waitcnt vmcnt(0) ; tail: chunk boundary" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    issue_patch(chunk);
+    issue_b(chunk);
+    issue_b(chunk);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::BPIECES) : "memory");      // patch + tap 0 landed (this wave's part)
+    asm volatile("s_barrier" ::: "memory");
+    issue_b(chunk);                                                        // tap 2 -> stage 2
+    int cstage = 0;
+    int tzo = p.dstep[0] < 0 ? 2 : 0, tyo = p.dstep[1] < 0 ? 2 : 0, txo = p.dstep[2] < 0 ? 2 : 0;   // tap 0's patch offset
+    int kx_ = 0, ky_ = 0;
+    auto read_frags = [&](int delta, int stage, int s, int set) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int pr = abase[tm] + delta;
+        fa[set][tm] = lds_read_b128(lds_base + pr * HB_ROWB + (((2 * s + lh) ^ ((pr >> 1) & 7)) << 4));
+      }
+      const unsigned Bs = ring_base + stage * T::BSTAGE + brow;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) fb[set][tn] = lds_read_b128(Bs + tn * 32 * HB_ROWB + foff[s]);
+    };
+    int delta = (tzo * HP_PY + tyo) * HP_PX + txo;
+    read_frags(delta, 0, 0, 0);
+    for (int tap = 0; tap < 27; ++tap) {
+      const int nstage = cstage == 2 ? 0 : cstage + 1;
+      // next tap's patch offset (wave-uniform walk, x fastest)
+      int ndelta = delta;
+      {
+        int nx = kx_ + 1, ny = ky_, carry_y = 0;
+        if (nx == 3) { nx = 0; ny += 1; }
+        if (ny == 3) { ny = 0; carry_y = 1; }
+        const int sx = p.dstep[2] < 0 ? -1 : 1, sy = p.dstep[1] < 0 ? -1 : 1, sz = p.dstep[0] < 0 ? -1 : 1;
+        ndelta += sx * (nx - kx_) + sy * (ny - ky_) * HP_PX + sz * carry_y * (HP_PY * HP_PX);
+        kx_ = nx; ky_ = ny;
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int set = s & 1;
+        lds_wait<TM, TN>(fa[set], fb[set]);
+        if (s < 3) {
+          read_frags(delta, cstage, s + 1, set ^ 1);
+        } else if (tap + 1 < 27) {
+          if (tap + 2 < 27) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::BPIECES) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0) ; tail: the last tap" ::: "memory");
+          asm volatile("s_barrier" ::: "memory");
+          read_frags(ndelta, nstage, 0, 0);
+          if (tap + 3 < 27) issue_b(chunk);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][tm]),
+                                                                  __builtin_bit_cast(bf16x8, fb[set][tn]), acc[tm][tn], 0, 0, 0);
+      }
+      cstage = nstage;
+      delta = ndelta;
+    }
+  }
+  asm volatile("s_barrier" ::: "memory");
+
+  // ---- epilogue (as the K-stepped kernel's): fp32 image -> statistics -> bf16 rows ----
+  float* img = reinterpret_cast<float*>(lds);
+  int* rowpix = reinterpret_cast<int*>(lds + T::ROWPIX);
+  if (tid < HB_BM) {
+    const int oz = oz0 + (tid >> 6), oy = oy0 + ((tid >> 3) & 7), ox = ox0 + (tid & 7);
+    rowpix[tid] = (oz < ph.Mz && oy < ph.My && ox < ph.Mx) ? ((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox : -1;
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = (wn * TN + tn) * 32 + li;
+    const float bv = (p.bias && n0 + col < Cout) ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        img[row * T::IMG_PITCH + col] = acc[tm][tn][r] + bv;
+      }
+  }
+  __syncthreads();
+  if (p.stats) {
+    float* part = reinterpret_cast<float*>(lds + T::ROWPIX + HB_BM * 4);
+    constexpr int HALVES = 512 / BN;
+    const int c = tid % BN, hf = tid / BN;
+    float sm = 0.f, sq = 0.f;
+    for (int row = hf * (HB_BM / HALVES); row < (hf + 1) * (HB_BM / HALVES); ++row) {
+      const float v = rowpix[row] >= 0 ? img[row * T::IMG_PITCH + c] : 0.f;
+      sm += v;
+      sq = fmaf(v, v, sq);
+    }
+    if (hf > 0) {
+      part[((hf - 1) * 2 + 0) * BN + c] = sm;
+      part[((hf - 1) * 2 + 1) * BN + c] = sq;
+    }
+    __syncthreads();
+    if (hf == 0 && n0 + c < Cout) {
+#pragma unroll
+      for (int h = 1; h < HALVES; ++h) {
+        sm += part[((h - 1) * 2 + 0) * BN + c];
+        sq += part[((h - 1) * 2 + 1) * BN + c];
+      }
+      float* row = p.stats + (long)stats_row * 2 * Cout;
+      row[n0 + c] = sm;
+      row[Cout + n0 + c] = sq;
+    }
+  }
+  char* goutb = reinterpret_cast<char*>(p.out);
+  constexpr int CHUNKS = BN / 8;
+  for (int q = tid; q < HB_BM * CHUNKS; q += 512) {
+    const int row = q / CHUNKS, ch = q % CHUNKS;
+    const int pix = rowpix[row];
+    if (pix < 0 || n0 + ch * 8 >= Cout) continue;
+    const float4 v0 = *reinterpret_cast<const float4*>(img + row * T::IMG_PITCH + ch * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(img + row * T::IMG_PITCH + ch * 8 + 4);
+    bf16x8 o;
+    o[0] = (__bf16)v0.x; o[1] = (__bf16)v0.y; o[2] = (__bf16)v0.z; o[3] = (__bf16)v0.w;
+    o[4] = (__bf16)v1.x; o[5] = (__bf16)v1.y; o[6] = (__bf16)v1.z; o[7] = (__bf16)v1.w;
+    *reinterpret_cast<bf16x8*>(goutb + ((long)pix * p.ldo + n0 + ch * 8) * 2) = o;
+  }
+}
+
+// stride-1 3x3x3 gather with one phase whose taps step by one pixel: the patch form serves it
+static bool hp_ok(const GatherConv& p) {
+  static const bool off = getenv("MPGAN_DBG_NO_HB_PATCH") != nullptr;
+  if (off || p.nphase != 1) return false;
+  const Phase& ph = p.ph[0];
+  if (!(ph.nz == 3 && ph.ny == 3 && ph.nx == 3 && p.Kz == 3 && p.Ky == 3 && p.Kx == 3)) return false;
+  for (int d = 0; d < 3; ++d)
+    if (p.istride[d] != 1 || p.ostride[d] != 1 || (p.dstep[d] != 1 && p.dstep[d] != -1)) return false;
+  return ph.oz == 0 && ph.oy == 0 && ph.ox == 0 && p.Do == ph.Mz && p.Ho == ph.My && p.Wo == ph.Mx && ph.Mz >= 2 * HP_TZ &&
+         ph.My >= 2 * HP_TY && ph.Mx >= 2 * HP_TX;
+}
+
+static HpGrid hp_grid(const GatherConv& p) {
+  const Phase& ph = p.ph[0];
+  return HpGrid{(ph.Mz + HP_TZ - 1) / HP_TZ, (ph.My + HP_TY - 1) / HP_TY, (ph.Mx + HP_TX - 1) / HP_TX};
+}
+
+template <int BN>
+static int hp_launch(const GatherConv& p, hipStream_t st) {
+  auto kern = gather_patch_bf16_kernel<BN>;
+  constexpr int smem = HpTile<BN>::SMEM;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      set_error("gather_patch_bf16: hipFuncSetAttribute(%d): %s", smem, hipGetErrorString(e));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const HpGrid tg = hp_grid(p);
+  GatherConv q = p;
+  q.mtiles = p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x;
+  q.ntiles = (p.Cout + BN - 1) / BN;
+  q.phase_outer = 0;
+  q.ksplit = 1;
+  dim3 grid((unsigned)q.mtiles * q.ntiles);
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, q, tg);
+  return check_launch("gather_patch_bf16");
+}
+
 static int hb_dispatch(const GatherConv& p, hipStream_t st, const char* what) {
   int rc = hb_check(p, what);
   if (rc) return rc;
   const long maxM = max_phase_pixels(p);
   if (maxM == 0) return MPGAN_OK;
+  if (hp_ok(p)) return p.Cout > 64 ? hp_launch<128>(p, st) : hp_launch<64>(p, st);
   const bool mask = !hb_all_in_range(p);
   static int nw = 0;
   if (!nw) {
@@ -843,6 +1147,10 @@ extern "C" int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g) {
   GatherConv p{};
   if (!g->transposed) build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
   else build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+  if (g->cin % HB_BK == 0 && hp_ok(p)) {     // patch form: one row per 4 x 8 x 8 tile
+    const HpGrid tg = hp_grid(p);
+    return p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x;
+  }
   return (int32_t)((max_phase_pixels(p) + HB_BM - 1) / HB_BM) * p.nphase;
 }
 

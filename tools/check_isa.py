@@ -16,6 +16,8 @@ KERNELS = {   # mangled-name fragment -> (min MFMAs, min LDS-DMA loads) in the K
     "gather_conv_bf16_kernelILi128ELb1ELi8": (16, 6),
     "gather_conv_bf16_kernelILi64ELb0ELi8": (8, 5),
     "gather_conv_bf16_kernelILi64ELb1ELi8": (8, 5),
+    "gather_patch_bf16_kernelILi128": (16, 2),            # patch form: weights only stream inside the tap loop
+    "gather_patch_bf16_kernelILi64": (8, 1),
     "wgrad_bf16_kernelILi4": (32, 12),
     "wgrad_bf16_kernelILi8": (16, 6),
 }

@@ -27,7 +27,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ uint4 g_zero_page[16];   // 256 B of zeros: what a masked LDS-DMA gather reads
 __device__ int g_hb_dbg;            // MPGAN_DBG_HB what-if bits (development): 1 = gathers confined to a 64 KiB window,
                                     // 2 = no MFMAs, 4 = no fragment reads either, 8 = weights confined to 16 KiB,
-                                    // 16 = no LDS-DMA (the contraction runs on whatever the LDS holds)
+                                    // 16 = no LDS-DMA (the contraction runs on whatever the LDS holds), 32 = no epilogue
 
 #define GLDS16(gptr, lptr)                                                                            \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),             \
@@ -274,6 +274,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_conv_bf16_kernel(const Gath
     cstage = nstage;
   }
   asm volatile("s_barrier" ::: "memory");             // all fragment reads done: LDS becomes the epilogue image
+  if (dbg & 32) return;                               // (what-if: no epilogue)
 
   // ---- epilogue: fp32 image [pixel][channel] in LDS -> statistics, bf16 rows stored 16 bytes per lane ----
   float* img = reinterpret_cast<float*>(lds);
@@ -607,6 +608,7 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
     }
   }
   asm volatile("s_barrier" ::: "memory");
+  if (g_hb_dbg & 32) return;                          // (what-if: no epilogue)
 
   // ---- epilogue (as the K-stepped kernel's): fp32 image -> statistics -> bf16 rows ----
   float* img = reinterpret_cast<float*>(lds);
@@ -698,6 +700,12 @@ static int hp_launch(const GatherConv& p, hipStream_t st) {
       return MPGAN_ERR_HIP;
     }
     attr_set = true;
+  }
+  static int dbg_set = -1;
+  if (dbg_set < 0) {
+    const char* e = getenv("MPGAN_DBG_HB");
+    dbg_set = e ? atoi(e) : 0;
+    if (dbg_set) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hb_dbg), &dbg_set, sizeof(int));
   }
   const HpGrid tg = hp_grid(p);
   GatherConv q = p;

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--dims", type=int, default=2)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--probe", default="", help="gbwd | dbwd: per-call HIP-event timing of that phase's calls")
+    ap.add_argument("--probe", default="", help="gfwd | gbwd | dbwd: per-call HIP-event timing of that phase's calls")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -48,7 +48,11 @@ def main():
             p.requires_grad_(True)
         opt_g.zero_grad()
         mark("start")
+        if a.probe == "gfwd" and probing[0]:
+            engine.set_probe(probe)
         y = G(x)
+        if a.probe == "gfwd":
+            engine.set_probe(None)
         mark("G fwd (train, grads)")
         def at_y(g):
             mark("D bwd (input grad only) + L1 bwd")

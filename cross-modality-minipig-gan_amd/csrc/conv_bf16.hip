@@ -1162,6 +1162,21 @@ extern "C" int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g) {
   return (int32_t)((max_phase_pixels(p) + HB_BM - 1) / HB_BM) * p.nphase;
 }
 
+// Which bf16 kernel serves this geometry (profiling labels): 0 = K-stepped gather_conv_bf16_kernel,
+// 1 = gather_patch_bf16_kernel (stride-1 3x3x3 gathers).
+extern "C" int32_t mpgan_conv_variant_bf16(const mpgan_conv_geom* g, int32_t backward_data) {
+  if (check_geom(g)) return -1;
+  GatherConv p{};
+  if (!backward_data) {
+    if (!g->transposed) build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+    else build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+  } else {
+    if (!g->transposed) build_transposed(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
+    else build_forward(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
+  }
+  return (p.Cin % HB_BK == 0 && hp_ok(p)) ? 1 : 0;
+}
+
 extern "C" int mpgan_conv_forward_bf16(const mpgan_conv_geom* g, const void* x, int32_t ldx, const void* w_packed,
                                        const float* bias, float* stats_partials, void* y, int32_t ldy, void* stream) {
   int rc = check_geom(g);

@@ -1338,6 +1338,15 @@ class DiscPlan:
 # --------------------------------------------------------------------------
 # discriminator (variant A), bf16 storage (BASELINE config C5)
 # --------------------------------------------------------------------------
+def _bf16_kernel_name(g: ConvGeom, backward_data: bool) -> str:
+    """rocprofv3's name of the bf16 kernel that serves this layer (labels of bench.py's probe)."""
+    gc = g.c()
+    bn = 128 if (g.cin if backward_data else g.cout) > 64 else 64
+    if lib().mpgan_conv_variant_bf16(C.byref(gc), int(backward_data)) == 1:
+        return f"gather_patch_bf16_kernel<{bn}>"
+    return f"gather_conv_bf16_kernel<{bn}, {'true' if backward_data else 'false'}, 8>"
+
+
 class DiscPlanBF16:
     """The same network as DiscPlan with bf16 activations, activation gradients and packed weights in HBM
     (code/GAN/GAN_final.py:159-209 at the reference's 3-D shape); fp32 accumulation, statistics, parameters,
@@ -1423,7 +1432,7 @@ class DiscPlanBF16:
                 f.add("conv_forward_bf16", L.mpgan_conv_forward_bf16, C.byref(gc), src.data_ptr(), g.cin,
                       w16(i).data_ptr(), cv.bias.data_ptr(), part.data_ptr(), z.data_ptr(), g.cout,
                       keep=(gc, src, z, part), desc=_gdesc(g),
-                      tag=(f"gather_conv_bf16_kernel<{128 if g.cout > 64 else 64}, false, 8>", 2.0 * conv_macs(g)))
+                      tag=(_bf16_kernel_name(g, False), 2.0 * conv_macs(g)))
             f.add("norm_finalize", L.mpgan_norm_finalize, part.data_ptr(), 1, rows, g.cout, rows_total, 0,
                   _p(bn.weight), _p(bn.bias), float(bn.eps), float(bn.momentum), _p(bn.running_mean),
                   _p(bn.running_var), _p(bn.num_batches_tracked), nb.scale.data_ptr(), nb.shift.data_ptr(),
@@ -1492,7 +1501,7 @@ class DiscPlanBF16:
             if i > 0:
                 b.add("conv_backward_data_bf16", L.mpgan_conv_backward_data_bf16, C.byref(gc), dz.data_ptr(), c,
                       w16b(i).data_ptr(), gas[i - 1].data_ptr(), g.cin, keep=(gc,), desc=_gdesc(g),
-                      tag=(f"dgrad:gather_conv_bf16_kernel<{128 if g.cin > 64 else 64}, true, 8>", 2.0 * conv_macs(g)))
+                      tag=("dgrad:" + _bf16_kernel_name(g, True), 2.0 * conv_macs(g)))
             elif want_input_grad:
                 self.g_x = E(n, *dhw, 1)
                 b.add("conv_backward_data_bf16_to_f32", L.mpgan_conv_backward_data_bf16_to_f32, C.byref(gc), dz.data_ptr(),

@@ -425,6 +425,10 @@ int mpgan_norm_act_add_fold(const float* z, int32_t ldz, const mpgan_prologue* p
 int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g);
 int mpgan_conv_forward_bf16(const mpgan_conv_geom* g, const void* x, int32_t ldx, const void* w_packed,
                             const float* bias, float* stats_partials, void* y, int32_t ldy, void* stream);
+/* Which bf16 kernel serves this geometry (profiling labels only): 0 = the K-stepped gather kernel,
+ * 1 = the patch form for stride-1 3x3x3 gathers (D.conv2 forward / backward-data at config C5). */
+int32_t mpgan_conv_variant_bf16(const mpgan_conv_geom* g, int32_t backward_data);
+
 /* dx (bf16) = conv_backward_data(dy (bf16)); w_packed_bwd: bf16, layout 1 of mpgan_pack_weights_bf16. */
 int mpgan_conv_backward_data_bf16(const mpgan_conv_geom* g, const void* dy, int32_t lddy, const void* w_packed_bwd,
                                   void* dx, int32_t lddx, void* stream);

@@ -1249,6 +1249,109 @@ static bool convt_quad_ok(const GatherConv& p) {
          p.Ho <= 2 * p.Hi && p.Wo <= 2 * p.Wi;
 }
 
+// ConvTranspose3d(Cin -> 1, k3 s2 p1, output_padding 1) forward -- the 3-D U-Net's last up-conv (the quad kernel's
+// 3-D sibling).  LANES = Cin/4 lanes share one INPUT voxel: its 2x2x2 neighbourhood is loaded once (16-byte channel
+// chunks) and produces the 2x2x2 output octet (2z+a, 2y+b, 2x+c) = all eight phases (27 tap terms); the lane
+// partials are folded with a transposing butterfly, after which lane (l & 7) = a + 2b + 4c owns one finished output.
+// The phase-by-phase gather it replaces read every input voxel 27/8 times and wrote each output row in eight
+// interleaved passes.
+template <int LANES>
+__global__ __launch_bounds__(256) void convt_oct_cout1_kernel(const GatherConv p) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [27][Cin]
+  const int Cin = p.Cin;
+  for (int i = threadIdx.x; i < 27 * Cin; i += 256) wl[i] = p.wp[i];
+  __syncthreads();
+  const Phase& ph = p.ph[0];                      // phase (0,0,0): m-grid == input grid
+  const unsigned Mtot = (unsigned)p.N * p.Di * p.Hi * p.Wi;
+  const unsigned gi = blockIdx.x * 256u + threadIdx.x;
+  const unsigned m = gi / LANES;
+  const int l = (int)(gi % LANES);
+  const bool live = m < Mtot;
+  unsigned q, ux, uy, uz;
+  fdivmod(live ? m : 0u, ph.fMx, q, ux);
+  fdivmod(q, ph.fMy, q, uy);
+  fdivmod(q, ph.fMz, q, uz);
+  const int n = (int)q, z = (int)uz, y = (int)uy, x = (int)ux;
+  const float* base = p.in + ((((long)n * p.Di + z) * p.Hi + y) * p.Wi + x) * p.ldi + 4 * l;
+  const bool z1 = z + 1 < p.Di, y1 = y + 1 < p.Hi, x1 = x + 1 < p.Wi;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v[2][2][2];
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const bool ok = live && (dz == 0 || z1) && (dy == 0 || y1) && (dx == 0 || x1);
+        v[dz][dy][dx] = ok ? *reinterpret_cast<const float4*>(base + (((long)dz * p.Hi + dy) * p.Wi + dx) * p.ldi) : z4;
+      }
+  auto W = [&](int kz, int ky, int kx) { return *reinterpret_cast<const float4*>(wl + ((kz * 3 + ky) * 3 + kx) * Cin + 4 * l); };
+  auto dot = [](const float4& a, const float4& b, float acc) {
+    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); return fmaf(a.w, b.w, acc);
+  };
+  // out[o] = sum_k in[(o + 1 - k) / 2] * w[k] per dimension:  even o <- (offset 0, k=1);  odd o <- (offset 1, k=0) + (offset 0, k=2)
+  float o[8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int ta = 0; ta <= a; ++ta)
+#pragma unroll
+          for (int tb = 0; tb <= b; ++tb)
+#pragma unroll
+            for (int tc = 0; tc <= c; ++tc) {
+              // parity 0: one term (offset 0, k 1); parity 1: term 0 = (offset 1, k 0), term 1 = (offset 0, k 2)
+              const int dz = a ? 1 - ta : 0, kz = a ? 2 * ta : 1;
+              const int dy = b ? 1 - tb : 0, ky = b ? 2 * tb : 1;
+              const int dx = c ? 1 - tc : 0, kx = c ? 2 * tc : 1;
+              s = dot(v[dz][dy][dx], W(kz, ky, kx), s);
+            }
+        o[a + 2 * b + 4 * c] = s;
+      }
+  // transposing butterfly over the lane bits 0..2: after it lane (l & 7) = i holds o[i] summed over those 8 lanes
+  float r4[4], r2[2];
+  const bool b0 = l & 1, b1 = l & 2, b2 = l & 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r4[i] = (b0 ? o[2 * i + 1] : o[2 * i]) + __shfl_xor(b0 ? o[2 * i] : o[2 * i + 1], 1, 64);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) r2[i] = (b1 ? r4[2 * i + 1] : r4[2 * i]) + __shfl_xor(b1 ? r4[2 * i] : r4[2 * i + 1], 2, 64);
+  float t = (b2 ? r2[1] : r2[0]) + __shfl_xor(b2 ? r2[0] : r2[1], 4, 64);
+#pragma unroll
+  for (int off = 8; off < LANES; off <<= 1) t += __shfl_xor(t, off, 64);
+  if (live && l < 8) {
+    const int oz = 2 * z + (l & 1), oy = 2 * y + ((l >> 1) & 1), ox = 2 * x + (l >> 2);
+    if (oz < p.Do && oy < p.Ho && ox < p.Wo) {
+      const long pix = (((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+      float vv = t + (p.bias ? p.bias[0] : 0.f);
+      if (p.resid) vv += p.resid[pix * p.ldr];
+      if (p.tanh_out) vv = tanhf(vv);
+      p.out[pix * p.ldo] = vv;
+    }
+  }
+}
+
+static bool convt_oct_ok(const GatherConv& p) {
+  static const bool off = getenv("MPGAN_DBG_NO_CONVT_OCT") != nullptr;
+  const int lanes = p.Cin / 4;
+  if (off || !(p.Cout == 1 && !p.pro.scale && !p.stats && !p.stats_acc && p.Cin % 4 == 0 && p.ldi % 4 == 0 &&
+               (lanes == 8 || lanes == 16) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0)))
+    return false;
+  if (!(p.nphase == 8 && p.Kz == 3 && p.Ky == 3 && p.Kx == 3)) return false;
+  for (int d = 0; d < 3; ++d)
+    if (p.ostride[d] != 2 || p.istride[d] != 1 || p.dstep[d] != -1) return false;
+  const Phase& a = p.ph[0];
+  const Phase& h = p.ph[7];
+  // k3 s2 p1: phase (0,0,0) = tap k=1 at offset 0; phase (1,1,1) = taps k=0 (offset +1), k=2 (offset 0) per dimension
+  return a.Mz == p.Di && a.My == p.Hi && a.Mx == p.Wi && a.nz == 1 && a.ny == 1 && a.nx == 1 && a.kz0 == 1 && a.ky0 == 1 &&
+         a.kx0 == 1 && a.dz0 == 0 && a.dy0 == 0 && a.dx0 == 0 && h.nz == 2 && h.ny == 2 && h.nx == 2 && h.kz0 == 0 &&
+         h.ky0 == 0 && h.kx0 == 0 && h.dz0 == 1 && h.dy0 == 1 && h.dx0 == 1 && p.Do <= 2 * p.Di && p.Ho <= 2 * p.Hi &&
+         p.Wo <= 2 * p.Wi;
+}
+
 static bool thin_cin1_ok(const GatherConv& p) {
   const int T = p.Kz * p.Ky * p.Kx;
   return p.Cin == 1 && !p.pro.scale && (long)T * ((p.Cout + 3) / 4 * 4) * 4 <= 48 * 1024;
@@ -1423,6 +1526,14 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
     else if (lanes == 8) hipLaunchKernelGGL(convt_quad_cout1_kernel<8>, qgrid, dim3(256), qsmem, st, p);
     else hipLaunchKernelGGL(convt_quad_cout1_kernel<16>, qgrid, dim3(256), qsmem, st, p);
     return check_launch("convt_quad_cout1");
+  }
+  if (convt_oct_ok(p)) {
+    const long othreads = (long)p.N * p.Di * p.Hi * p.Wi * lanes;
+    dim3 ogrid((unsigned)((othreads + 255) / 256));
+    const size_t osmem = (size_t)27 * p.Cin * sizeof(float);
+    if (lanes == 8) hipLaunchKernelGGL(convt_oct_cout1_kernel<8>, ogrid, dim3(256), osmem, st, p);
+    else hipLaunchKernelGGL(convt_oct_cout1_kernel<16>, ogrid, dim3(256), osmem, st, p);
+    return check_launch("convt_oct_cout1");
   }
   const long threads = maxM * lanes;
   dim3 grid((unsigned)((threads + 255) / 256), 1, (unsigned)p.nphase);

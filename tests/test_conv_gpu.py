@@ -45,7 +45,8 @@ CONVT_CASES = [
     (2, 16, 1, (7, 9), 2),                 # quad kernel, 4 lanes per pixel, odd extents
     (2, 64, 1, (5, 6), 2),                 # 16 lanes per pixel
     (3, 192, 32, (3, 4, 5), 1),
-    (3, 32, 1, (5, 4, 6), 2),
+    (3, 32, 1, (5, 4, 6), 2),              # octet kernel of ConvTranspose3d(C -> 1): 8 lanes per input voxel
+    (3, 64, 1, (3, 4, 5), 1),              # ... 16 lanes
     (3, 1024, 512, (2, 2, 2), 1),          # 7-level U-Net: deepest up-convolution (cat of 512 + 512)
     (3, 512, 128, (4, 4, 4), 1),
 ]

@@ -1352,6 +1352,90 @@ static bool convt_oct_ok(const GatherConv& p) {
          p.Wo <= 2 * p.Wi;
 }
 
+// 1 -> 1 channel, 3x3x3 (or 1x3x3), stride 1, padding 1: the top-level ResidualUnit's conv of every U-Net and its
+// backward-data (same footprint, taps reversed).  One thread = FOUR consecutive x outputs: each of the nine
+// (z, y) input rows is read as one 6-wide window (an unaligned 16-byte + an 8-byte load) instead of 27 scalar
+// loads per output with per-tap bounds tests; weights are wave-uniform (scalar loads).  Interior threads take the
+// vector path, the two border threads of a row read element by element.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+__global__ __launch_bounds__(256) void thin_c1c1_rows4_kernel(const GatherConv p) {
+  const Phase& ph = p.ph[0];
+  const int Mx = ph.Mx, groups = (Mx + 3) >> 2;
+  const long total = (long)p.N * ph.Mz * ph.My * groups;
+  const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gi >= total) return;
+  const int gx = (int)(gi % groups);
+  long r = gi / groups;
+  const int y = (int)(r % ph.My); r /= ph.My;
+  const int z = (int)(r % ph.Mz);
+  const int n = (int)(r / ph.Mz);
+  const int x0 = 4 * gx;
+  const bool interior = x0 >= 1 && x0 + 5 <= p.Wi;          // window x0-1 .. x0+4 inside the row
+  float o[4];
+  const float bv = p.bias ? p.bias[0] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = bv;
+  for (int jz = 0; jz < ph.nz; ++jz) {
+    const int iz = z + ph.dz0 + p.dstep[0] * jz, kz = ph.kz0 + p.kstep[0] * jz;
+    if ((unsigned)iz >= (unsigned)p.Di) continue;
+#pragma unroll
+    for (int jy = 0; jy < 3; ++jy) {
+      const int iy = y + ph.dy0 + p.dstep[1] * jy, ky = ph.ky0 + p.kstep[1] * jy;
+      if ((unsigned)iy >= (unsigned)p.Hi) continue;
+      const float* __restrict__ row = p.in + (((long)n * p.Di + iz) * p.Hi + iy) * p.Wi;
+      float win[6];
+      if (interior) {
+        const f32x4u a = *reinterpret_cast<const f32x4u*>(row + x0 - 1);
+        const f32x2u b = *reinterpret_cast<const f32x2u*>(row + x0 + 3);
+        win[0] = a.x; win[1] = a.y; win[2] = a.z; win[3] = a.w; win[4] = b.x; win[5] = b.y;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int xi = x0 - 1 + i;
+          win[i] = (unsigned)xi < (unsigned)p.Wi ? row[xi] : 0.f;
+        }
+      }
+      const float* __restrict__ wr = p.wp + (kz * 3 + ky) * 3;      // packed [1][tap][1]
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx) {
+        const int off = ph.dx0 + p.dstep[2] * jx + 1;                // 0 .. 2: window position of output 0's sample
+        const float w = wr[ph.kx0 + p.kstep[2] * jx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaf(w, off == 0 ? win[j] : (off == 1 ? win[j + 1] : win[j + 2]), o[j]);
+      }
+    }
+  }
+  const long obase = (((long)n * p.Do + z) * p.Ho + y) * p.Wo + x0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (x0 + j >= Mx) break;
+    float v = o[j];
+    if (p.resid) v += p.resid[obase + j];
+    if (p.tanh_out) v = tanhf(v);
+    p.out[obase + j] = v;
+  }
+}
+
+static bool thin_c1c1_ok(const GatherConv& p) {
+  static const bool off = getenv("MPGAN_DBG_NO_THIN_ROWS") != nullptr;
+  if (off || !(p.Cin == 1 && p.Cout == 1 && p.ldi == 1 && p.ldo == 1 && (!p.resid || p.ldr == 1) && p.nphase == 1 &&
+               !p.pro.scale && !p.stats && !p.stats_acc && !p.in_bf16 && !p.out_bf16 && p.Ky == 3 && p.Kx == 3 &&
+               (p.Kz == 3 || p.Kz == 1)))
+    return false;
+  const Phase& ph = p.ph[0];
+  if (!(ph.ny == 3 && ph.nx == 3 && ph.nz == p.Kz && ph.oz == 0 && ph.oy == 0 && ph.ox == 0 && p.Do == ph.Mz &&
+        p.Ho == ph.My && p.Wo == ph.Mx && p.Wi == ph.Mx && p.Hi == ph.My && p.Di == ph.Mz))
+    return false;
+  for (int d = 0; d < 3; ++d) {
+    if (p.istride[d] != 1 || p.ostride[d] != 1) return false;
+    if (d == 0 && p.Kz == 1) continue;
+    const int d0 = d == 0 ? ph.dz0 : (d == 1 ? ph.dy0 : ph.dx0);
+    if (!((p.dstep[d] == 1 && d0 == -1) || (p.dstep[d] == -1 && d0 == 1))) return false;   // offsets -1, 0, +1
+  }
+  return true;
+}
+
 static bool thin_cin1_ok(const GatherConv& p) {
   const int T = p.Kz * p.Ky * p.Kx;
   return p.Cin == 1 && !p.pro.scale && (long)T * ((p.Cout + 3) / 4 * 4) * 4 <= 48 * 1024;
@@ -1485,6 +1569,12 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
     else if (lanes_b == 8) hipLaunchKernelGGL((thin_cout1_kernel<8, true>), grid, dim3(256), smem, st, p);
     else hipLaunchKernelGGL((thin_cout1_kernel<16, true>), grid, dim3(256), smem, st, p);
     return check_launch("thin_cout1_bf16");
+  }
+  if (thin_c1c1_ok(p)) {
+    const Phase& ph0 = p.ph[0];
+    const long threads4 = (long)p.N * ph0.Mz * ph0.My * ((ph0.Mx + 3) / 4);
+    hipLaunchKernelGGL(thin_c1c1_rows4_kernel, dim3((unsigned)((threads4 + 255) / 256)), dim3(256), 0, st, p);
+    return check_launch("thin_c1c1_rows4");
   }
   if (thin_cin1_ok(p)) {
     const bool v4 = (p.Cout % 4 == 0) && (p.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);

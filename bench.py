@@ -50,13 +50,14 @@ def note(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def kernel_source_hash():
-    """sha256 over the sources of the dominant (fp32 implicit-GEMM) kernel -- conv_igemm.hip and every header
-    in csrc/: profiles/traffic.json is only quoted when it was measured on exactly these."""
+def kernel_source_hash(main="conv_igemm.hip"):
+    """sha256 over the sources of the dominant kernel -- `main` (conv_igemm.hip: the fp32 implicit-GEMM kernels;
+    conv_bf16.hip: the bf16 ones) and every header in csrc/: a traffic file under profiles/ is only quoted when it
+    was measured on exactly these."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "cross-modality-minipig-gan_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name == "conv_igemm.hip" or name.endswith(".h"):
+        if name == main or name.endswith(".h"):
             h.update(name.encode())
             h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
@@ -319,13 +320,16 @@ def main():
         summ = summ_all.get(dominant, dict(calls=0, ms=0.0, flops=0.0))
         achieved = summ["flops"] / (summ["ms"] * 1e-3) / 1e12 if summ["ms"] > 0 else 0.0
         traffic, traffic_src = None, None
-        src_hash = kernel_source_hash()
-        tp = os.path.join(ROOT, "profiles", "traffic.json")       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(tp) and args.dims == 2 and args.size == 256 and args.batch == 16 and args.dtype == "f32":
+        c3 = args.dims == 2 and args.size == 256 and args.batch == 16 and args.dtype == "f32"
+        c5 = args.dims == 3 and args.size == 128 and args.batch == 4 and args.dtype == "bf16"
+        src_hash = kernel_source_hash("conv_bf16.hip" if args.dtype == "bf16" else "conv_igemm.hip")
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same configuration (tools/make_traffic.py)
+        tp = os.path.join(ROOT, "profiles", "traffic.json" if c3 else "traffic_c5_bf16.json")
+        if os.path.exists(tp) and (c3 or c5):
             tj = json.load(open(tp))
             traffic_src = tj.get("_source_sha256_16")
             if traffic_src == src_hash:            # only quoted when measured on exactly these kernel sources
-                traffic = tj.get(dominant, {}).get("hbm_bytes_per_launch")
+                traffic = tj.get(dominant.replace("dgrad:", ""), {}).get("hbm_bytes_per_launch")
         fam = {}
         for k, d in summ_all.items():
             f = fam.setdefault(family_of(k), dict(calls=0, ms=0.0, flops=0.0))

@@ -1319,6 +1319,23 @@ __global__ __launch_bounds__(256) void convt_oct_cout1_kernel(const GatherConv p
   for (int i = 0; i < 4; ++i) r4[i] = (b0 ? o[2 * i + 1] : o[2 * i]) + __shfl_xor(b0 ? o[2 * i] : o[2 * i + 1], 1, 64);
 #pragma unroll
   for (int i = 0; i < 2; ++i) r2[i] = (b1 ? r4[2 * i + 1] : r4[2 * i]) + __shfl_xor(b1 ? r4[2 * i] : r4[2 * i + 1], 2, 64);
+  if constexpr (LANES == 4) {
+    // four lanes per voxel: the butterfly ends after two stages, lane l owns outputs (a, b) = (l & 1, l >> 1) for c = 0, 1
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int oz = 2 * z + (l & 1), oy = 2 * y + ((l >> 1) & 1), ox = 2 * x + c;
+        if (oz < p.Do && oy < p.Ho && ox < p.Wo) {
+          const long pix = (((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+          float vv = r2[c] + (p.bias ? p.bias[0] : 0.f);
+          if (p.resid) vv += p.resid[pix * p.ldr];
+          if (p.tanh_out) vv = tanhf(vv);
+          p.out[pix * p.ldo] = vv;
+        }
+      }
+    }
+    return;
+  }
   float t = (b2 ? r2[1] : r2[0]) + __shfl_xor(b2 ? r2[0] : r2[1], 4, 64);
 #pragma unroll
   for (int off = 8; off < LANES; off <<= 1) t += __shfl_xor(t, off, 64);
@@ -1338,7 +1355,7 @@ static bool convt_oct_ok(const GatherConv& p) {
   static const bool off = getenv("MPGAN_DBG_NO_CONVT_OCT") != nullptr;
   const int lanes = p.Cin / 4;
   if (off || !(p.Cout == 1 && !p.pro.scale && !p.stats && !p.stats_acc && p.Cin % 4 == 0 && p.ldi % 4 == 0 &&
-               (lanes == 8 || lanes == 16) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0)))
+               (lanes == 4 || lanes == 8 || lanes == 16) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0)))
     return false;
   if (!(p.nphase == 8 && p.Kz == 3 && p.Ky == 3 && p.Kx == 3)) return false;
   for (int d = 0; d < 3; ++d)
@@ -1621,7 +1638,8 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
     const long othreads = (long)p.N * p.Di * p.Hi * p.Wi * lanes;
     dim3 ogrid((unsigned)((othreads + 255) / 256));
     const size_t osmem = (size_t)27 * p.Cin * sizeof(float);
-    if (lanes == 8) hipLaunchKernelGGL(convt_oct_cout1_kernel<8>, ogrid, dim3(256), osmem, st, p);
+    if (lanes == 4) hipLaunchKernelGGL(convt_oct_cout1_kernel<4>, ogrid, dim3(256), osmem, st, p);
+    else if (lanes == 8) hipLaunchKernelGGL(convt_oct_cout1_kernel<8>, ogrid, dim3(256), osmem, st, p);
     else hipLaunchKernelGGL(convt_oct_cout1_kernel<16>, ogrid, dim3(256), osmem, st, p);
     return check_launch("convt_oct_cout1");
   }

@@ -32,4 +32,7 @@ python3 $R/tools/bench_conv.py --layers all --pro --reps 10 > $O/layer_bench.txt
 python3 $R/tools/bench_bf16.py --reps 5 > $O/layer_bench_bf16.txt 2>&1
 python3 $R/tools/phase_times.py --steps 5 > $O/phase_times.txt 2>&1
 python3 $R/tools/bench_variant_b.py --batch 7 --steps 3 > $O/variant_b_bs7.txt 2>&1
+echo "[10] PMC FETCH_SIZE / WRITE_SIZE, C5 bf16"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_c5_fetch -- python3 $R/bench.py --dims 3 --size 128 --batch 4 --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-gfwd > $O/pmc_c5_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_c5_write -- python3 $R/bench.py --dims 3 --size 128 --batch 4 --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-gfwd > $O/pmc_c5_write.log 2>&1
 echo done

@@ -4,7 +4,8 @@
     hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
 FETCH_SIZE / WRITE_SIZE are in KiB; the factor 2 is the gfx950 half-count correction of
 /opt/skills/guides/MI355X_MICROARCH.md ("HBM" section).  Usage:
-    tools/make_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
+    tools/make_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [main source]
+(main source: the .hip file whose hash stamps the result; conv_igemm.hip by default, conv_bf16.hip for config C5)"""
 import collections
 import csv
 import json
@@ -31,7 +32,7 @@ def main():
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     import bench
     # stamped with the kernel sources the passes ran on: bench.py quotes these bytes only for the same sources
-    out = {"_source_sha256_16": bench.kernel_source_hash()}
+    out = {"_source_sha256_16": bench.kernel_source_hash(sys.argv[4] if len(sys.argv) > 4 else "conv_igemm.hip")}
     for k, (f, n) in sorted(fetch.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
         w = write.get(k, (0.0, 0))[0]
         out[k] = {"launches": n, "fetch_bytes_per_launch_corrected": 2 * f * 1024,

@@ -19,3 +19,6 @@ cp $P/variant_b_bs7.txt profiles/r02_variant_b_bs7.txt
 python3 tools/make_traffic.py "$(newest "$P/pmc_fetch/runc/*_counter_collection.csv")" "$(newest "$P/pmc_write/runc/*_counter_collection.csv")" profiles/traffic.json | head -4
 python3 tools/make_traffic.py "$(newest "$P/pmc_gfwd_fetch/runc/*_counter_collection.csv")" "$(newest "$P/pmc_gfwd_write/runc/*_counter_collection.csv")" profiles/r02_gfwd_traffic.json | head -3
 python3 tools/make_sq_summary.py "$(newest "$P/pmc_sq/runc/*_counter_collection.csv")" profiles/r02_pmc_dconv_sq_counters.csv
+if ls $P/pmc_c5_fetch/runc/*_counter_collection.csv > /dev/null 2>&1; then
+  python3 tools/make_traffic.py "$(newest "$P/pmc_c5_fetch/runc/*_counter_collection.csv")" "$(newest "$P/pmc_c5_write/runc/*_counter_collection.csv")" profiles/traffic_c5_bf16.json conv_bf16.hip | head -6
+fi

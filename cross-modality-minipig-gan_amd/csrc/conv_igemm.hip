@@ -1203,32 +1203,7 @@ __global__ __launch_bounds__(256) void convt_quad_cout1_kernel(const GatherConv 
 #pragma unroll
   for (int off = 4; off < LANES; off <<= 1) t += __shfl_xor(t, off, 64);
   float sv = 0.f;                               // raw output (with bias) of this lane, 0 if it owns none
-  // Stores.  When a block's 256 / LANES input pixels are one run of an input row, its outputs are two runs of
-  // 2 * 256 / LANES consecutive floats (rows 2y and 2y+1): they go through LDS and leave as full, coalesced lines
-  // (written lane by lane they cost 9x their size in HBM write traffic: PMC WRITE_SIZE, profiles/r02_gfwd_traffic.json).
-  constexpr int PB = 256 / LANES;               // input pixels per block
-  __shared__ float orow[2][2 * PB];
-  const bool rowrun = (p.Wi % PB) == 0 && p.Wo == 2 * p.Wi && p.Ho == 2 * p.Hi && p.ldo == 1 && (!p.resid || p.ldr == 1);
-  if (rowrun) {                                 // block-uniform
-    if (live && l < 4) {
-      const float v = t + (p.bias ? p.bias[0] : 0.f);
-      sv = v;
-      orow[l & 1][2 * (int)(threadIdx.x / LANES) + (l >> 1)] = v;
-    }
-    __syncthreads();
-    const unsigned m0 = blockIdx.x * (unsigned)PB;
-    if (m0 < Mtot && threadIdx.x < 4 * PB) {
-      unsigned q0, ux0, uy0;
-      fdivmod(m0, ph.fMx, q0, ux0);
-      fdivmod(q0, ph.fMy, q0, uy0);
-      const int a = threadIdx.x / (2 * PB), j = threadIdx.x % (2 * PB);
-      const long pix = ((long)q0 * p.Ho + 2 * (int)uy0 + a) * p.Wo + 2 * (int)ux0 + j;
-      float v = orow[a][j];
-      if (p.resid) v += p.resid[pix];
-      if (p.tanh_out) v = tanhf(v);
-      p.out[pix] = v;
-    }
-  } else if (live && l < 4) {
+  if (live && l < 4) {
     const int oy = 2 * y + (l & 1), ox = 2 * x + (l >> 1);
     if (oy < p.Ho && ox < p.Wo) {
       const long pix = ((long)n * p.Ho + oy) * p.Wo + ox;

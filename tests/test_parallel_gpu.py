@@ -58,3 +58,29 @@ def test_two_ranks_fit_batch_data_parallel(tmp_path):
         mean = 0.5 * (r0["local_logged"][k] + r1["local_logged"][k])
         assert abs(r0["synced_logged"][k] - mean) <= 1e-6 * max(1.0, abs(mean)), k
         assert r0["synced_logged"][k] == r1["synced_logged"][k]
+
+
+def test_bench_line_contract_small_size():
+    """bench.py at a small size (one rank, no CPU baseline): ONE JSON line on stdout with the driver's keys, the
+    roofline object and a dominant kernel named as rocprofv3 would name it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--size", "64", "--batch", "4", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline", "--no-gfwd"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["dtype"] == "f32" and j["unit"] == "slices/s"
+    assert abs(j["value"] - 4 * 1000.0 / j["ms_per_step"]) < 1e-6 * j["value"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "dense_families"):
+        assert k in r, k
+    # (at this size no launch reaches the probe's 20-GFLOP floor, so `achieved` may be 0: the line still names a kernel)
+    assert r["bound"] == "mfma" and r["peak"] == 157.3 and 0.0 <= r["frac"] < 1.0 and "kernel" in r["kernel"]
+    assert "workload" in j["config"] and "model" not in j["config"]

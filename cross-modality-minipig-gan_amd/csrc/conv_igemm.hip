@@ -2694,6 +2694,202 @@ static int launch_pipe_pro(const GatherConv& p, int variant, long maxM, hipStrea
   return launch_pipe_bn<WRAPS, 2>(p, variant, maxM, st);
 }
 
+// ---------------------------------------------------------------------------
+// 3-D patch kernel, 16 -> 16 channels, 3x3x3, stride 1 (the U-Net's 64^3 level at config C5: down0.unit1, the
+// up-path ResidualUnit conv and their backward-data gathers -- the generator's most expensive layers there).
+// The K-stepped kernel pads 16 output channels to a 32-wide MFMA tile and re-stages every input pixel once per
+// tap; here a block owns 2 x 8 x 8 output pixels, stages their 4 x 10 x 10 input patch ONCE (producer's
+// BatchNorm + PReLU applied per element on the way in; out-of-range = the conv's zero padding) together with all
+// 27 taps' weights, and contracts from LDS with v_mfma_f32_16x16x4_f32 (no padded columns): per tap and wave two A
+// reads, one B read, eight MFMAs.  73 KiB of LDS: two blocks per CU, one's staging under the other's MFMAs.
+// Fused BatchNorm statistics: one [sum | sum^2] row per tile.
+// ---------------------------------------------------------------------------
+constexpr int P3_TZ = 2, P3_TY = 8, P3_TX = 8;
+constexpr int P3_PY = P3_TY + 2, P3_PX = P3_TX + 2;
+constexpr int P3_PROWS = (P3_TZ + 2) * P3_PY * P3_PX;          // 400 patch pixels
+constexpr int P3_PA = 24, P3_PW = 20;                          // LDS pitches (floats) of a patch pixel / a weight row
+constexpr int P3_SMEM = (P3_PROWS * P3_PA + 27 * 16 * P3_PW + 4 * 2 * 16) * 4;
+struct P3Grid { int tiles_z, tiles_y, tiles_x; };
+
+template <bool HAS_PRO>
+__global__ __launch_bounds__(256, 2) void gather_patch3d_c16_kernel(const GatherConv p, const P3Grid tg) {
+  extern __shared__ __attribute__((aligned(16))) float sm3[];
+  float* patch = sm3;
+  float* wl = sm3 + P3_PROWS * P3_PA;
+  float* st = wl + 27 * 16 * P3_PW;                             // [4 waves][2][16]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const Phase& ph = p.ph[0];
+  // persistent blocks: the 27 taps' weights are staged once, then the block walks tiles (XCD-contiguous ranges)
+  {
+    const float* __restrict__ gw = p.wp;                       // packed [Cout = 16][27][Cin = 16]
+#pragma unroll
+    for (int i = 0; i < (27 * 16 * 4 + 255) / 256; ++i) {
+      const int e = tid + 256 * i;
+      if (e < 27 * 16 * 4) {
+        const int k4 = e & 3, row = e >> 2;                    // row = co * 27 + tap
+        const int co = row / 27, tap = row - co * 27;
+        *reinterpret_cast<float4*>(wl + (tap * 16 + co) * P3_PW + 4 * k4) = *reinterpret_cast<const float4*>(gw + (long)row * 16 + 4 * k4);
+      }
+    }
+  }
+  const unsigned ntiles = (unsigned)(p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x);
+  const unsigned per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const unsigned w0 = xcd_remap(blockIdx.x, gridDim.x) * per;
+  for (unsigned tt = w0; tt < w0 + per && tt < ntiles; ++tt) {
+  unsigned t = tt;
+  const int stats_row = (int)t;
+  const int tx = t % tg.tiles_x; t /= tg.tiles_x;
+  const int ty = t % tg.tiles_y; t /= tg.tiles_y;
+  const int tz = t % tg.tiles_z;
+  const int n = t / tg.tiles_z;
+  const int oz0 = tz * P3_TZ, oy0 = ty * P3_TY, ox0 = tx * P3_TX;
+  const int mnz = ph.dz0 + (p.dstep[0] < 0 ? 2 * p.dstep[0] : 0), mny = ph.dy0 + (p.dstep[1] < 0 ? 2 * p.dstep[1] : 0),
+            mnx = ph.dx0 + (p.dstep[2] < 0 ? 2 * p.dstep[2] : 0);
+  const int pz0 = oz0 + mnz, py0 = oy0 + mny, px0 = ox0 + mnx;
+  // ---- stage the patch (prologue applied once per element) and the weights ----
+  {
+    const float* __restrict__ gin = p.in;
+    const int c4 = tid & 3;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float slope = 1.f;
+    if constexpr (HAS_PRO) {
+      sc = *reinterpret_cast<const float4*>(p.pro.scale + 4 * c4);
+      sh = *reinterpret_cast<const float4*>(p.pro.shift + 4 * c4);
+      slope = pro_slope(p.pro);
+    }
+    const int act = p.pro.act;
+#pragma unroll
+    for (int i = 0; i < (P3_PROWS * 4 + 255) / 256; ++i) {
+      const int e = tid + 256 * i;
+      const int pr = e >> 2;
+      if (pr < P3_PROWS) {
+        const int pz = pr / (P3_PY * P3_PX), rem = pr - pz * (P3_PY * P3_PX);
+        const int py = rem / P3_PX, px = rem - py * P3_PX;
+        const int iz = pz0 + pz, iy = py0 + py, ix = px0 + px;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
+          v = *reinterpret_cast<const float4*>(gin + ((((long)n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * p.ldi + 4 * c4);
+          if constexpr (HAS_PRO) {
+            v.x = act_apply(fmaf(v.x, sc.x, sh.x), act, slope);
+            v.y = act_apply(fmaf(v.y, sc.y, sh.y), act, slope);
+            v.z = act_apply(fmaf(v.z, sc.z, sh.z), act, slope);
+            v.w = act_apply(fmaf(v.w, sc.w, sh.w), act, slope);
+          }
+        }
+        *reinterpret_cast<float4*>(patch + pr * P3_PA + 4 * c4) = v;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- contraction: wave = 32 pixels (two 16-row blocks) x 16 channels ----
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int ln = lane & 15, g = lane >> 4;
+  int abase[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int q = wid * 32 + rb * 16 + ln;
+    abase[rb] = (((q >> 6) * P3_PY) + ((q >> 3) & 7)) * P3_PX + (q & 7);
+  }
+  f32x4 acc[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[rb][i] = 0.f;
+  const int fz = p.dstep[0] < 0 ? 2 : 0, fy = p.dstep[1] < 0 ? 2 : 0, fx = p.dstep[2] < 0 ? 2 : 0;
+#pragma unroll
+  for (int jz = 0; jz < 3; ++jz)
+#pragma unroll
+    for (int jy = 0; jy < 3; ++jy)
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx) {
+        const int off = ((fz + p.dstep[0] * jz) * P3_PY + (fy + p.dstep[1] * jy)) * P3_PX + (fx + p.dstep[2] * jx);
+        const int tap = ((ph.kz0 + p.kstep[0] * jz) * 3 + (ph.ky0 + p.kstep[1] * jy)) * 3 + (ph.kx0 + p.kstep[2] * jx);
+        const float4 b = *reinterpret_cast<const float4*>(wl + (tap * 16 + ln) * P3_PW + 4 * g);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const float4 a = *reinterpret_cast<const float4*>(patch + (abase[rb] + off) * P3_PA + 4 * g);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[rb], 0, 0, 0);
+        }
+      }
+  // ---- epilogue: D[row = 4 g + i][col = ln] -> out[pixel][channel], bias / residual, statistics of z = acc + bias ----
+  const float bv = p.bias ? p.bias[ln] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = wid * 32 + rb * 16 + 4 * g + i;
+      const int oz = oz0 + (q >> 6), oy = oy0 + ((q >> 3) & 7), ox = ox0 + (q & 7);
+      if (oz < ph.Mz && oy < ph.My && ox < ph.Mx) {
+        const long pix = (((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+        const float z = acc[rb][i] + bv;
+        s1 += z;
+        s2 = fmaf(z, z, s2);
+        float v = z;
+        if (p.resid) v += p.resid[pix * p.ldr + ln];
+        p.out[pix * p.ldo + ln] = v;
+      }
+    }
+  if (p.stats) {
+    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (g == 0) { st[(wid * 2 + 0) * 16 + ln] = s1; st[(wid * 2 + 1) * 16 + ln] = s2; }
+    __syncthreads();
+    if (tid < 32) {
+      const int sq = tid >> 4, c = tid & 15;
+      p.stats[(long)stats_row * 32 + tid] = (st[(0 * 2 + sq) * 16 + c] + st[(1 * 2 + sq) * 16 + c]) +
+                                            (st[(2 * 2 + sq) * 16 + c] + st[(3 * 2 + sq) * 16 + c]);
+    }
+  }
+  __syncthreads();                                             // patch and st are rewritten by the next tile
+  }
+}
+
+static bool patch3d_ok(const GatherConv& p) {
+  static const bool off = getenv("MPGAN_DBG_NO_PATCH3D") != nullptr;
+  if (off || !(p.Cin == 16 && p.Cout == 16 && p.ldi % 4 == 0 && p.nphase == 1 && p.Kz == 3 && p.Ky == 3 && p.Kx == 3 &&
+               !p.tanh_out && !p.fold.acc && !p.stats_acc && !p.bwd.part && !p.in_bf16 && !p.out_bf16 && p.ksplit <= 1 &&
+               p.pro.n_stride == 0 && ((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.wp)) & 15) == 0 &&
+               (!p.pro.scale || ((reinterpret_cast<uintptr_t>(p.pro.scale) | reinterpret_cast<uintptr_t>(p.pro.shift)) & 15) == 0)))
+    return false;
+  const Phase& ph = p.ph[0];
+  if (!(ph.nz == 3 && ph.ny == 3 && ph.nx == 3 && ph.oz == 0 && ph.oy == 0 && ph.ox == 0 && p.Do == ph.Mz && p.Ho == ph.My &&
+        p.Wo == ph.Mx && ph.Mz >= 2 && ph.My >= 4 && ph.Mx >= 4))
+    return false;
+  for (int d = 0; d < 3; ++d)
+    if (p.istride[d] != 1 || p.ostride[d] != 1 || (p.dstep[d] != 1 && p.dstep[d] != -1) || (p.kstep[d] != 1)) return false;
+  return (long)p.N * p.Di * p.Hi * p.Wi * p.ldi < (1L << 31);
+}
+
+static P3Grid patch3d_grid(const GatherConv& p) {
+  const Phase& ph = p.ph[0];
+  return P3Grid{(ph.Mz + P3_TZ - 1) / P3_TZ, (ph.My + P3_TY - 1) / P3_TY, (ph.Mx + P3_TX - 1) / P3_TX};
+}
+
+static int launch_patch3d(const GatherConv& p, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_patch3d_c16_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_patch3d_c16_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      set_error("gather_patch3d: hipFuncSetAttribute: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const P3Grid tg = patch3d_grid(p);
+  const long ntiles = (long)p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x;
+  dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512));          // two resident blocks per CU, each walking its range of tiles
+  if (p.pro.scale) hipLaunchKernelGGL(gather_patch3d_c16_kernel<true>, grid, dim3(256), P3_SMEM, st, p, tg);
+  else hipLaunchKernelGGL(gather_patch3d_c16_kernel<false>, grid, dim3(256), P3_SMEM, st, p, tg);
+  return check_launch("gather_patch3d_c16");
+}
+
 static int launch_gather(const GatherConv& p, hipStream_t st) {
   const long maxM = max_phase_pixels(p);
   if (maxM == 0) return MPGAN_OK;
@@ -2709,6 +2905,7 @@ static int launch_gather(const GatherConv& p, hipStream_t st) {
     MPGAN_UNSUPPORTED(p.bwd.part != nullptr, "thin conv: no fused norm-backward sums (mpgan_conv_bwd_stats_rows() == 0)");
     return launch_thin(p, maxM, st);
   }
+  if (patch3d_ok(p)) return launch_patch3d(p, st);
   {
     PatchLaunch pl;
     int smem = 0;
@@ -2826,6 +3023,10 @@ extern "C" int32_t mpgan_conv_stats_rows(const mpgan_conv_geom* g, int32_t has_p
     PatchLaunch pl;
     patch_plan(p, &pl, nullptr);
     return (int32_t)(pl.tiles_x * pl.tiles_y * p.N * p.nphase);
+  }
+  if (v == 18) {              // 3-D patch kernel: one partial row per 2 x 8 x 8 tile
+    const P3Grid tg = patch3d_grid(p);
+    return (int32_t)(p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x);
   }
   return (int32_t)((max_phase_pixels(p) + BM - 1) / BM) * p.nphase;
 }
@@ -3029,6 +3230,7 @@ extern "C" int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward
   const bool t2 = p.Cout == 1 && !p.pro.scale && p.Cin % 4 == 0 && lanes >= 1 && lanes <= 64 &&
                   (lanes & (lanes - 1)) == 0 && (long)T * p.Cin * 4 <= 48 * 1024;
   const int v = select_variant(p, max_phase_pixels(p), t1, t2);
+  if (v > 2 && patch3d_ok(p)) return 18;                                      // 3-D patch kernel, 16 -> 16 channels
   if (v > 2) {
     PatchLaunch pl;
     if (patch_plan(p, &pl, nullptr)) return pl.merged ? 17 : 16;

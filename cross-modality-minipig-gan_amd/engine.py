@@ -267,6 +267,8 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
         return "thin_cin1_kernel"
     if v == 2:
         return "thin_cout1_kernel"
+    if v == 18:
+        return f"gather_patch3d_c16_kernel<{'true' if has_pro else 'false'}>"
     cin_eff = g.cout if backward_data else g.cin
     if v in (16, 17):
         cout_eff = g.cin if backward_data else g.cout

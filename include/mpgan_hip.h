@@ -127,7 +127,8 @@ int mpgan_conv_backward_data_stats(const mpgan_conv_geom* g, const float* dy, in
 /* Which kernel serves this geometry (for profiling labels): 1 = thin Cin==1 VALU
  * stencil, 2 = thin Cout==1 VALU stencil, 16 = fp32-MFMA patch kernel (2-D, <= 32
  * output channels, input patch + weights staged once in LDS; 17 = its merged form, one block per
- * tile walking every phase of a strided backward-data / transposed conv), 32/64/128 = fp32-MFMA
+ * tile walking every phase of a strided backward-data / transposed conv), 18 = the 3-D patch kernel
+ * (16 -> 16 channels, 3x3x3, stride 1: 2x8x8 output tiles, 16x16x4 MFMA), 32/64/128 = fp32-MFMA
  * K-stepped implicit GEMM with that output-channel tile.
  * 1128 = the 128 tile's mask-free instance (pad-free forward conv, Cout % 128 == 0, has_prologue 3).
  * 2032 / 2064 = the 32 / 64 tile with the K axis split over two 4-wave groups inside the block (output grids

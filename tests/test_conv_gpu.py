@@ -30,6 +30,8 @@ CONV_CASES = [
     (3, 1, 16, 3, 2, 1, (8, 10, 12), 2),   # 3-D variants (reference's true shape)
     (3, 16, 32, 3, 2, 1, (8, 10, 12), 1),
     (3, 32, 32, 3, 1, 1, (6, 5, 7), 2),
+    (3, 16, 16, 3, 1, 1, (5, 12, 11), 2),  # 3-D patch kernel (16 -> 16): ragged 2x8x8 tiles, padding on every side
+    (3, 16, 16, 3, 1, 0, (6, 10, 18), 1),  # ... pad-free
     (3, 64, 128, 3, 1, 0, (6, 6, 6), 1),
     (3, 128, 256, 4, 2, 0, (8, 8, 10), 1),
     (3, 256, 512, 3, 1, 0, (5, 5, 5), 2),  # variant-B D conv4
@@ -560,3 +562,56 @@ def test_backward_data_with_fused_norm_backward_sums(cin, cout, k, s, spatial, n
                         torch.where(neg, dx0.double() * y, torch.zeros_like(y)).reshape(-1, cin).sum(0)]).cpu()
     scale_ = (gy.abs().reshape(-1, cin).sum(0).max().item())
     assert (got - want).abs().max().item() <= 2e-5 * scale_, ((got - want).abs().max().item(), scale_)
+
+
+@pytest.mark.parametrize("spatial,n,p", [((5, 12, 11), 2, 1), ((6, 10, 18), 1, 0)])
+def test_patch3d_prologue_residual_statistics_and_slices(spatial, n, p):
+    """The 3-D 16 -> 16 patch kernel with everything the U-Net hangs on it: producer BatchNorm + PReLU (device
+    slope) applied on load, zero padding of the ACTIVATED tensor, bias, residual add, input / output / residual as
+    channel slices of wider buffers, fused statistics rows -- and its backward-data gather with a residual."""
+    import ctypes
+    from mpgan_amd import ops
+    from mpgan_amd._lib import lib
+    cin = cout = 16
+    g = _geom(3, n, cin, cout, 3, 1, p, spatial)
+    gc = g.c()
+    assert lib().mpgan_conv_variant(ctypes.byref(gc), 0, 1) == 18 and lib().mpgan_conv_variant(ctypes.byref(gc), 1, 0) == 18
+    gen = torch.Generator().manual_seed(99)
+    z = torch.rand(n, cin, *spatial, generator=gen) * 2 - 1
+    sc, sh = torch.rand(cin, generator=gen) + 0.5, torch.rand(cin, generator=gen) - 0.5
+    alpha = 0.3
+    a = z * sc[None, :, None, None, None] + sh[None, :, None, None, None]
+    a = torch.where(a > 0, a, alpha * a)
+    w = (torch.rand(cout, cin, 3, 3, 3, generator=gen) - 0.5) / (cin * 27) ** 0.5
+    b = torch.rand(cout, generator=gen) - 0.5
+    y_ref = F.conv3d(a, w, b, padding=p)
+    res = torch.rand(y_ref.shape, generator=gen) - 0.5
+    # operands as channel slices of wider buffers
+    zbuf = torch.full((n, *spatial, cin + 8), float("nan"), device="cuda")
+    zbuf[..., 4:4 + cin] = to_cl(z)
+    ybuf = torch.full((n, *g.out_dhw, cout + 16), float("nan"), device="cuda")
+    rbuf = torch.zeros(n, *g.out_dhw, cout + 4, device="cuda")
+    rbuf[..., :cout] = to_cl(res)
+    pro = ops.Prologue(sc.cuda(), sh.cuda(), 0, ops.ACT_LEAKY, 1.0, torch.tensor([alpha], device="cuda"))
+    rows = ops.conv_stats_rows(g, 1)
+    assert rows == n * ((g.out_dhw[0] + 1) // 2) * ((g.out_dhw[1] + 7) // 8) * ((g.out_dhw[2] + 7) // 8)
+    part = torch.full(((rows + 32) * 2 * cout,), float("nan"), device="cuda")
+    ops.conv_forward(g, zbuf[..., 4:4 + cin], ops.pack_weight(w.cuda()), b.cuda(), ybuf[..., 8:8 + cout], pro=pro,
+                     stats_partials=part)
+    assert_close(from_cl(ybuf[..., 8:8 + cout], 3), y_ref, what="conv output")
+    assert torch.isnan(ybuf[..., :8]).all() and torch.isnan(ybuf[..., 8 + cout:]).all()      # nothing written outside
+    got = part[:rows * 2 * cout].view(rows, 2, cout).double().sum(0).cpu()
+    want = torch.stack([y_ref.double().transpose(0, 1).reshape(cout, -1).sum(1),
+                        (y_ref.double() ** 2).transpose(0, 1).reshape(cout, -1).sum(1)])
+    assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    # residual in the epilogue (statistics are not asked for together with it)
+    y2 = torch.empty(n, *g.out_dhw, cout, device="cuda")
+    ops.conv_forward(g, zbuf[..., 4:4 + cin], ops.pack_weight(w.cuda()), b.cuda(), y2, pro=pro, resid=rbuf[..., :cout])
+    assert_close(from_cl(y2, 3), y_ref + res, what="conv output + residual")
+    # backward-data with an accumulate-into residual
+    dy = torch.rand(y_ref.shape, generator=gen) * 2 - 1
+    dx_ref = torch.nn.grad.conv3d_input(a.shape, w, dy, padding=p)
+    acc0 = torch.rand(n, *spatial, cin, generator=gen)
+    dx = acc0.cuda()
+    ops.conv_backward_data(g, to_cl(dy), ops.pack_weight(w.cuda(), for_dgrad=True), dx, resid=dx)
+    assert_close(from_cl(dx, 3), dx_ref + acc0.permute(0, 4, 1, 2, 3), what="backward data + residual")

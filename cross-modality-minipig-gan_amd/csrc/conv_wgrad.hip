@@ -795,6 +795,133 @@ static void launch_thin_rows(const WgradParams& p, int T, int blocks, hipStream_
   else hipLaunchKernelGGL((thin_wgrad_rows_kernel<27, DENSE_BF16>), dim3(blocks), dim3(256), 0, st, p);
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradient of the 16 -> 16 3x3x3 stride-1 conv (the 3-D U-Net's 64^3 level; conv_igemm.hip's
+// gather_patch3d_c16_kernel serves its forward and backward-data): dW[co][tap][ci] = sum_px dy[px][co] * a[px + tap][ci].
+// The MFMA pipeline above tiles this 16 x 432 result as 32 x 128 (a quarter of each tile is real) and re-stages
+// every input pixel once per tap.  Here a persistent block walks 2 x 8 x 8 pixel tiles: dy's tile and the
+// 4 x 10 x 10 input patch (producer's BatchNorm + PReLU applied on the way in, zero outside = the padding) are
+// staged once, then v_mfma_f32_16x16x4_f32 contracts over PIXELS: A[co][px] from the dy tile, B[px][ci] from the
+// patch shifted by the tap -- wave w owns taps w, w+4, ... (7 accumulators of 4 registers), the last wave also the
+// bias gradient (B = ones).  Accumulators live across the block's tiles; one partial slab per block goes through
+// the fixed-order reducer.
+// ---------------------------------------------------------------------------
+constexpr int WP3_TZ = 2, WP3_TY = 8, WP3_TX = 8, WP3_PY = 10, WP3_PX = 10, WP3_PROWS = 400, WP3_BLOCKS = 512;
+struct WP3Grid { int tiles_z, tiles_y, tiles_x; };
+
+template <bool HAS_PRO>
+__global__ __launch_bounds__(256, 2) void wgrad_patch3d_c16_kernel(const WgradParams p, const WP3Grid tg) {
+  __shared__ __attribute__((aligned(16))) float patch[WP3_PROWS * 16];   // [patch pixel][ci]
+  __shared__ __attribute__((aligned(16))) float dyt[128 * 16];           // [tile pixel][co]
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ln = lane & 15, g = lane >> 4;
+  f32x4 acc[7], accb;
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[k][i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = 0.f;
+  const int c4 = tid & 3;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  float slope = 1.f;
+  if constexpr (HAS_PRO) {
+    sc = *reinterpret_cast<const float4*>(p.pro.scale + 4 * c4);
+    sh = *reinterpret_cast<const float4*>(p.pro.shift + 4 * c4);
+    slope = pro_slope(p.pro);
+  }
+  const int act = p.pro.act;
+  int toff[7];                                                  // this wave's taps: patch offset of tap w + 4 k (floats)
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int tap = __builtin_amdgcn_readfirstlane(wid) + 4 * k;
+    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    toff[k] = ((kz * WP3_PY + ky) * WP3_PX + kx) * 16;
+  }
+  const bool last_wave = __builtin_amdgcn_readfirstlane(wid) == 3;   // 6 taps + the bias column sums
+  const unsigned ntiles = (unsigned)(p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x);
+  const unsigned per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const unsigned w0 = xcd_remap(blockIdx.x, gridDim.x) * per;
+  for (unsigned tt = w0; tt < w0 + per && tt < ntiles; ++tt) {
+    unsigned t = tt;
+    const int tx = t % tg.tiles_x; t /= tg.tiles_x;
+    const int ty = t % tg.tiles_y; t /= tg.tiles_y;
+    const int tz = t % tg.tiles_z;
+    const int n = t / tg.tiles_z;
+    const int oz0 = tz * WP3_TZ, oy0 = ty * WP3_TY, ox0 = tx * WP3_TX;
+    __syncthreads();                                            // the previous tile's reads are done
+#pragma unroll
+    for (int i = 0; i < (WP3_PROWS * 4 + 255) / 256; ++i) {
+      const int e = tid + 256 * i, pr = e >> 2;
+      if (pr < WP3_PROWS) {
+        const int pz = pr / (WP3_PY * WP3_PX), rem = pr - pz * (WP3_PY * WP3_PX);
+        const int py = rem / WP3_PX, px = rem - py * WP3_PX;
+        const int iz = oz0 - p.pz + pz, iy = oy0 - p.py + py, ix = ox0 - p.px + px;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)iz < (unsigned)p.Gz && (unsigned)iy < (unsigned)p.Gy && (unsigned)ix < (unsigned)p.Gx) {
+          v = *reinterpret_cast<const float4*>(p.gath + ((((long)n * p.Gz + iz) * p.Gy + iy) * p.Gx + ix) * p.ldg + 4 * c4);
+          if constexpr (HAS_PRO) {
+            v.x = act_apply(fmaf(v.x, sc.x, sh.x), act, slope);
+            v.y = act_apply(fmaf(v.y, sc.y, sh.y), act, slope);
+            v.z = act_apply(fmaf(v.z, sc.z, sh.z), act, slope);
+            v.w = act_apply(fmaf(v.w, sc.w, sh.w), act, slope);
+          }
+        }
+        *reinterpret_cast<float4*>(patch + pr * 16 + 4 * c4) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 256 * i, q = e >> 2;                  // tile pixel 0..127
+      const int oz = oz0 + (q >> 6), oy = oy0 + ((q >> 3) & 7), ox = ox0 + (q & 7);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (oz < p.Mz && oy < p.My && ox < p.Mx)
+        v = *reinterpret_cast<const float4*>(p.dense + ((((long)n * p.Mz + oz) * p.My + oy) * p.Mx + ox) * p.ldd + 4 * c4);
+      *reinterpret_cast<float4*>(dyt + q * 16 + 4 * c4) = v;
+    }
+    __syncthreads();
+    // ---- contraction over the tile's 128 pixels, four at a time: k = pixel 4 j + g ----
+#pragma unroll 4
+    for (int j = 0; j < 32; ++j) {
+      const int q = 4 * j + g;
+      const float a = dyt[q * 16 + ln];                          // A[row = co = ln][k]
+      const int pb = (((q >> 6) * WP3_PY) + ((q >> 3) & 7)) * WP3_PX + (q & 7);
+      const float* brow = patch + pb * 16 + ln;                  // B[k][col = ci = ln] at tap (0, 0, 0)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[toff[k]], acc[k], 0, 0, 0);
+      if (last_wave) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(a, 1.0f, accb, 0, 0, 0);       // taps 3, 7, .. 23: six
+      else acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[toff[6]], acc[6], 0, 0, 0);    // taps w + 24 <= 26
+    }
+  }
+  // ---- D[row = co = 4 g + i][col = ci = ln] -> partial[block][co][tap * 16 + ci]; bias partial [block][co] ----
+  float* out = p.partial + (long)blockIdx.x * 16 * 432;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int tap = wid + 4 * k;
+    if (tap < 27)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[(4 * g + i) * 432 + tap * 16 + ln] = acc[k][i];
+  }
+  if (wid == 3 && p.bias_partial && ln == 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p.bias_partial[(long)blockIdx.x * 16 + 4 * g + i] = accb[i];
+}
+
+static bool wgrad_p3_geom_ok(const mpgan_conv_geom* g) {
+  static const bool off = getenv("MPGAN_DBG_NO_PATCH3D") != nullptr;
+  if (off || g->transposed || g->cin != 16 || g->cout != 16) return false;
+  for (int d = 0; d < 3; ++d)
+    if (g->k[d] != 3 || g->stride[d] != 1 || g->pad[d] < 0 || g->pad[d] > 1) return false;
+  return g->out_dhw[0] >= 2 && g->out_dhw[1] >= 4 && g->out_dhw[2] >= 4;
+}
+
+static int wgrad_p3_blocks(const mpgan_conv_geom* g) {
+  const long tiles = (long)g->n * ((g->out_dhw[0] + WP3_TZ - 1) / WP3_TZ) * ((g->out_dhw[1] + WP3_TY - 1) / WP3_TY) *
+                     ((g->out_dhw[2] + WP3_TX - 1) / WP3_TX);
+  return (int)(tiles < WP3_BLOCKS ? tiles : WP3_BLOCKS);
+}
+
 struct ThinWgradPlan { int blocks; long chunk; bool ok; };
 static ThinWgradPlan plan_thin_wgrad(int Cd, int Cg, int T, long M, bool has_pro, long lds_cap = 64 * 1024) {
   ThinWgradPlan t;
@@ -947,6 +1074,10 @@ extern "C" int64_t mpgan_conv_wgrad_workspace(const mpgan_conv_geom* g) {
     const int64_t tneed = ((int64_t)tp.blocks * Cd * T + (int64_t)tp.blocks * Cd) * (int64_t)sizeof(float);
     if (tneed > need) need = tneed;
   }
+  if (wgrad_p3_geom_ok(g)) {                     // 3-D patch form: one [16][432] slab + 16 bias sums per persistent block
+    const int64_t pneed = (int64_t)wgrad_p3_blocks(g) * (16 * 432 + 16) * (int64_t)sizeof(float);
+    if (pneed > need) need = pneed;
+  }
   return need;
 }
 
@@ -996,6 +1127,24 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
   }
   p.fMx = make_fastdiv(p.Mx); p.fMy = make_fastdiv(p.My); p.fMz = make_fastdiv(p.Mz);
   hipStream_t st0 = (hipStream_t)stream;
+  if (wgrad_p3_geom_ok(g) && p.ldd % 4 == 0 && p.ldg % 4 == 0 && p.pro.n_stride == 0 &&
+      ((reinterpret_cast<uintptr_t>(p.dense) | reinterpret_cast<uintptr_t>(p.gath)) & 15) == 0 &&
+      (!p.pro.scale || ((reinterpret_cast<uintptr_t>(p.pro.scale) | reinterpret_cast<uintptr_t>(p.pro.shift)) & 15) == 0)) {
+    const int nb = wgrad_p3_blocks(g);
+    const int64_t pslab = (int64_t)nb * 16 * 432;
+    MPGAN_CHECK_ARG(workspace_bytes >= (pslab + (int64_t)nb * 16) * (int64_t)sizeof(float),
+                    "conv_backward_weight: workspace too small for the 3-D patch form");
+    p.bias_partial = dbias ? p.partial + pslab : nullptr;
+    const WP3Grid tg{(p.Mz + WP3_TZ - 1) / WP3_TZ, (p.My + WP3_TY - 1) / WP3_TY, (p.Mx + WP3_TX - 1) / WP3_TX};
+    if (p.pro.scale) hipLaunchKernelGGL(wgrad_patch3d_c16_kernel<true>, dim3(nb), dim3(256), 0, st0, p, tg);
+    else hipLaunchKernelGGL(wgrad_patch3d_c16_kernel<false>, dim3(nb), dim3(256), 0, st0, p, tg);
+    int rcp = check_launch("wgrad_patch3d_c16");
+    if (rcp) return rcp;
+    const int bbp = dbias ? 1 : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((16 * 16 * 27 + 31) / 32 + bbp), dim3(256), 0, st0, p.partial, dw, nb, 16, 16,
+                       27, beta, p.bias_partial, nb, dbias, bbp);
+    return check_launch("wgrad_patch3d_reduce");
+  }
   {
     ThinWgradPlan tp = plan_thin_wgrad(Cd, Cg, T, M, p.pro.scale != nullptr);
     const bool v4 = (p.Cd % 4 == 0) && (p.ldd % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.dense) & 15) == 0);

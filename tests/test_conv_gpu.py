@@ -608,6 +608,20 @@ def test_patch3d_prologue_residual_statistics_and_slices(spatial, n, p):
     y2 = torch.empty(n, *g.out_dhw, cout, device="cuda")
     ops.conv_forward(g, zbuf[..., 4:4 + cin], ops.pack_weight(w.cuda()), b.cuda(), y2, pro=pro, resid=rbuf[..., :cout])
     assert_close(from_cl(y2, 3), y_ref + res, what="conv output + residual")
+    # weight gradient (the patch form's pixel-contracting kernel): prologue on x, bias gradient, accumulate
+    ar = a.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    gy = torch.rand(y_ref.shape, generator=gen) * 2 - 1
+    F.conv3d(ar, wr, br, padding=p).backward(gy)
+    dw = torch.ones_like(w).cuda()
+    db = torch.ones(cout, device="cuda")
+    ws = torch.empty(ops.conv_wgrad_workspace(g) // 4, device="cuda")
+    gybuf = torch.zeros(n, *g.out_dhw, cout + 4, device="cuda")
+    gybuf[..., :cout] = to_cl(gy)
+    ops.conv_backward_weight(g, zbuf[..., 4:4 + cin], gybuf[..., :cout], dw, ws, pro=pro, beta=1.0, dbias=db)
+    assert_close(dw.cpu() - 1.0, wr.grad, what="wgrad (patch form)")
+    assert_close(db.cpu() - 1.0, br.grad, what="bias grad (patch form)")
     # backward-data with an accumulate-into residual
     dy = torch.rand(y_ref.shape, generator=gen) * 2 - 1
     dx_ref = torch.nn.grad.conv3d_input(a.shape, w, dy, padding=p)

@@ -80,6 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the N>1 code path where ranks must share one GPU)")
     ap.add_argument("--no-gfwd", action="store_true", help="skip the side measurement of the G forward (clean profiles)")
+    ap.add_argument("--no-phases", action="store_true", help="skip the per-pass breakdown of one step (clean profiles)")
     ap.add_argument("--norm", default="batch", choices=("batch", "instance", "instance_affine"),
                     help="generator norm layers: the reference's BatchNorm (default, the headline) or north_star's InstanceNorm")
     ap.add_argument("--lr", type=float, default=1e-6,
@@ -87,6 +88,9 @@ def parse_args(argv=None):
                          "sigmoid saturation within ONE step (its own checkpoints show g_loss=100.03, d_loss=45.00), "
                          "after which every D gradient is exactly zero; all-zero MFMA operands let the chip clock up, "
                          "so the default keeps the same work on non-degenerate data.")
+    ap.add_argument("--dense-min-gflop", type=float, default=DENSE_MIN_GFLOP,
+                    help="launches with at least this much algorithmic work are timed as the dense families (default: "
+                         "D's conv2/3/4 in all directions, nothing of G); tests lower it at small sizes")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, form the process group, all-reduce one number and print the JSON stub: "
                          "the launcher's own test (no GPU work)")
@@ -102,9 +106,11 @@ def _free_port():
 
 
 def launch_ranks(args) -> int:
-    """Parent of an N-rank run: no GPU call has been made in this process (counting devices does not
-    initialise the runtime).  Starts N fresh interpreters of this file, one rank each, and returns
-    the first non-zero exit status (0 when every rank succeeded)."""
+    """Parent of an N-rank run.  It counts devices and nothing else -- which may already have initialised
+    HIP/HSA in this process -- so it must only ever SPAWN children (`subprocess.Popen` of fresh interpreters,
+    one rank each) and wait for them; it must never `os.exec*` into another program or re-exec a launcher
+    (on this pool an exec from a process that has touched the GPU takes the machine down).  Returns the
+    first non-zero exit status (0 when every rank succeeded)."""
     import torch
     ndev = torch.cuda.device_count()
     if args.backend == "nccl" and not args.rendezvous_only and ndev < args.gpus:
@@ -165,12 +171,14 @@ def host_cores():
             break
         except (OSError, ValueError, IndexError):
             continue
+    capped = False
     if os.environ.get("MPGAN_HOST_CORES"):
         n, how = int(os.environ["MPGAN_HOST_CORES"]), "MPGAN_HOST_CORES"
     elif how == "affinity mask" and n > 32:
         # no quota visible, yet the mask lists a whole multi-GPU host: one GPU's job gets a 16-core share of it
-        n, how = 16, "16-core per-GPU share of the host; the affinity mask lists all %d cores and no cgroup quota is visible" % n
-    return n, how
+        n, how, capped = 16, ("16-core per-GPU share of the host; the affinity mask lists all %d cores and no cgroup "
+                              "quota is visible" % n), True
+    return n, how, capped
 
 
 def cpu_baseline_leg(gan, spatial, sample_bs=16, timed_steps=3):
@@ -179,7 +187,7 @@ def cpu_baseline_leg(gan, spatial, sample_bs=16, timed_steps=3):
     G-output L1 of the HIP path against it (same weights, same input)."""
     import torch
     from oracle import refmodel as R
-    cores, how = host_cores()
+    cores, how, capped = host_cores()
     torch.set_num_threads(cores)
     ref = R.GAN((1, *spatial), dimensions=2, norm=gan.generator.norm)
     ref.generator.load_state_dict({k: v.cpu() for k, v in gan.generator.state_dict().items()})
@@ -204,10 +212,90 @@ def cpu_baseline_leg(gan, spatial, sample_bs=16, timed_steps=3):
         ref.step(batch, i + 1, opts)
         note(f"cpu baseline: step {i} done")
     dt = time.perf_counter() - t0
-    return {"value": sample_bs * timed_steps / dt, "unit": "slices/s", "cores": cores, "kind": "port",
+    return {"value": sample_bs * timed_steps / dt, "unit": "slices/s", "cores": cores, "cores_capped": capped,
+            "kind": "port",
             "sample": f"{timed_steps} G+D steps of the torch-CPU oracle at 256x256, bs {sample_bs} (1 warm-up), "
                       f"{cores} threads = every core this job may use ({how})",
             "g_output_l1_vs_cpu": l1, "g_output_psnr_vs_cpu_db": psnr}
+
+
+def phase_breakdown(gan, opts, batch, steps=3, on_phase=None):
+    """One G+D step of `GAN.fit_batch` (same calls, same order, no all-reduce) with a HIP event between its network
+    passes; returns [(phase name, ms, passes of G, passes of D)] averaged over `steps`, where the pass counts price
+    the phase's algorithmic work (forward = 1, backward-data only = 1, full backward = 2; SURVEY.md 8d:
+    step = 4 F_G + 8 F_D).  Events sit on the caller's stream; every program joins its side stream before it
+    returns, so a phase boundary is a boundary for both.  `on_phase(name, starting)` lets tools/phase_times.py
+    switch its per-call probe on for one phase."""
+    import torch
+    from mpgan_amd.gan import adversarial_loss, reconstruction_loss, scalar_axpby
+    G, D = gan.generator, gan.discriminator
+    opt_g, opt_d = opts
+    x, t = batch["t1w"], batch["t2w"]
+    n, dev = x.shape[0], x.device
+    marks = []
+    hook = on_phase or (lambda name, starting: None)
+
+    def mark(name, g=0.0, d=0.0):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append((name, e, g, d))
+
+    def step():
+        for p in D.parameters():
+            p.requires_grad_(False)
+        for p in G.parameters():
+            p.requires_grad_(True)
+        opt_g.zero_grad()
+        mark("start")
+        hook("gfwd", True)
+        y = G(x)
+        hook("gfwd", False)
+        mark("G fwd (train, grads)", g=1)
+
+        def at_y(grad):
+            mark("D bwd (input grad only) + L1 bwd", d=1)
+            hook("gbwd", True)
+        y.register_hook(at_y)
+        pr = D(y)
+        mark("D fwd (fake)", d=1)
+        loss = scalar_axpby(adversarial_loss(pr, torch.ones(n, 1, device=dev)), 1.0, reconstruction_loss(y, t), 1.0)
+        mark("losses")
+        loss.backward()
+        hook("gbwd", False)
+        mark("G bwd", g=2)
+        opt_g.step()
+        mark("Adam G")
+        for p in D.parameters():
+            p.requires_grad_(True)
+        for p in G.parameters():
+            p.requires_grad_(False)
+        opt_d.zero_grad()
+        mark("zero_grad D")
+        with torch.no_grad():
+            y2 = G(x)
+        mark("G fwd (no grad)", g=1)
+        lr = adversarial_loss(D(t), torch.full((n, 1), float(gan.hparams.one_sided_label_value), device=dev))
+        mark("D fwd (real)", d=1)
+        lf = adversarial_loss(D(y2), torch.zeros(n, 1, device=dev))
+        mark("D fwd (fake, detached)", d=1)
+        d_loss = scalar_axpby(lr, 0.5, lf, 0.5)
+        hook("dbwd", True)
+        d_loss.backward()
+        hook("dbwd", False)
+        mark("D bwd x2 (dgrad + wgrad)", d=4)
+        opt_d.step()
+        mark("Adam D")
+        for p in G.parameters():
+            p.requires_grad_(True)
+
+    tot = None
+    for _ in range(steps):
+        marks.clear()
+        step()
+        torch.cuda.synchronize()
+        row = [(n1, e0.elapsed_time(e1), g1, d1) for (_, e0, _, _), (n1, e1, g1, d1) in zip(marks[:-1], marks[1:])]
+        tot = row if tot is None else [(a[0], a[1] + b[1], a[2], a[3]) for a, b in zip(tot, row)]
+    return [(nm, ms / steps, g, d) for nm, ms, g, d in tot]
 
 
 def family_of(name: str) -> str:
@@ -293,7 +381,7 @@ def main():
         gan.fit_batch(batch, i, opts)
         torch.cuda.synchronize()
         note(f"warm-up step {i} done")
-    probe = engine.KernelProbe(min_flops=DENSE_MIN_GFLOP * 1e9)
+    probe = engine.KernelProbe(min_flops=args.dense_min_gflop * 1e9)
     engine.set_probe(probe)
     barrier()
     t0 = time.perf_counter()
@@ -309,16 +397,27 @@ def main():
         dt = t.item()
     ddp.sync_logged()                              # mean over ranks of the four logged scalars
     losses = {k: float(v) for k, v in gan.logged.items()}
+    ranks_seen = 1
+    if world > 1:                                  # every rank contributes a one through the backend that was timed
+        ones = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(round(ones.item()))
 
     if rank == 0:
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_FP32_TFLOPS
         summ_all = probe.summary()
-        # dominant kernel = the one with the most time among the dense launches (named, so rocprof can be matched)
+        # dominant kernel = the one with the most measured time among the dense launches (named as rocprofv3 names
+        # it); the best-performing one is reported beside it, not instead of it
         dominant = max(summ_all, key=lambda k: summ_all[k]["ms"]) if summ_all else DOMINANT
-        if args.dims == 2 and args.dtype == "f32" and DOMINANT in summ_all:
-            dominant = DOMINANT
-        summ = summ_all.get(dominant, dict(calls=0, ms=0.0, flops=0.0))
+        summ = summ_all.get(dominant, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
         achieved = summ["flops"] / (summ["ms"] * 1e-3) / 1e12 if summ["ms"] > 0 else 0.0
+        rate = lambda d: d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        per_kernel = {k.replace("dgrad:", "dgrad of "): {"launches_per_step": d["calls"] / max(args.steps, 1),
+                                                           "ms_per_step": d["ms"] / max(args.steps, 1),
+                                                           "tflops": rate(d), "frac": rate(d) / peak,
+                                                           "algorithmic_gb_per_s": d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] else 0.0}
+                      for k, d in sorted(summ_all.items(), key=lambda kv: -kv[1]["ms"])}
+        best = max(summ_all, key=lambda k: rate(summ_all[k])) if summ_all else dominant
         traffic, traffic_src = None, None
         c3 = args.dims == 2 and args.size == 256 and args.batch == 16 and args.dtype == "f32"
         c5 = args.dims == 3 and args.size == 128 and args.batch == 4 and args.dtype == "bf16"
@@ -332,12 +431,15 @@ def main():
                 traffic = tj.get(dominant.replace("dgrad:", ""), {}).get("hbm_bytes_per_launch")
         fam = {}
         for k, d in summ_all.items():
-            f = fam.setdefault(family_of(k), dict(calls=0, ms=0.0, flops=0.0))
-            for key in ("calls", "ms", "flops"):
+            f = fam.setdefault(family_of(k), dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            for key in ("calls", "ms", "flops", "bytes"):
                 f[key] += d[key]
+        # algorithmic_gb_per_s: each launch's gathered + dense operand once over its measured time --
+        # the HBM rate the kernel NEEDS at this speed (the measured PMC traffic of the dominant kernel is `traffic`)
         fam_out = {k: {"launches_per_step": d["calls"] / max(args.steps, 1), "ms_per_step": d["ms"] / max(args.steps, 1),
                        "tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] else 0.0,
-                       "frac": d["flops"] / (d["ms"] * 1e-3) / 1e12 / peak if d["ms"] else 0.0}
+                       "frac": d["flops"] / (d["ms"] * 1e-3) / 1e12 / peak if d["ms"] else 0.0,
+                       "algorithmic_gb_per_s": d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] else 0.0}
                    for k, d in sorted(fam.items())}
         tot_ms = sum(d["ms"] for d in fam.values())
         tot_fl = sum(d["flops"] for d in fam.values())
@@ -345,10 +447,15 @@ def main():
         roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": traffic, "traffic_kernel_sources": traffic_src,
                     "kernel_sources": src_hash, "kernel": dominant.replace("dgrad:", ""),
+                    "kernel_role": family_of(dominant), "selected_by": "largest measured time among the dense launches",
                     "launches_per_step": summ["calls"] / max(args.steps, 1),
                     "avg_launch_ms": summ["ms"] / max(summ["calls"], 1),
                     "avg_launch_gflop": summ["flops"] / max(summ["calls"], 1) / 1e9,
-                    "dense_families": fam_out}
+                    "algorithmic_gb_per_s": summ["bytes"] / (summ["ms"] * 1e-3) / 1e9 if summ["ms"] else 0.0,
+                    "best_kernel": {"kernel": best.replace("dgrad:", ""), "role": family_of(best),
+                                    "tflops": rate(summ_all[best]) if summ_all else 0.0,
+                                    "frac": rate(summ_all[best]) / peak if summ_all else 0.0},
+                    "dense_kernels": per_kernel, "dense_families": fam_out}
         # G-forward-only (config C2) on the side: not part of `value`
         g_fwd_ms = None
         with torch.no_grad():
@@ -368,6 +475,19 @@ def main():
         else:
             g_flops_sample, step_flops_sample = 145.131e9 * (args.size / 128.0) ** 3, 16.64e12 * (args.size / 128.0) ** 3
         g_fwd_flops = g_flops_sample * args.batch
+        d_flops_sample = (step_flops_sample - 4 * g_flops_sample) / 8
+        # where the step's time goes: the same step once more with an event between its network passes (after the
+        # timed region: not part of `value`), each pass priced at the peak of the pipe it runs on
+        phases = None
+        if not args.no_phases:
+            d_peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_FP32_TFLOPS
+            phases = []
+            for nm, ms, gp, dp in phase_breakdown(gan, opts, batch, steps=3):
+                fl = (gp * g_flops_sample + dp * d_flops_sample) * args.batch
+                floor_ms = (gp * g_flops_sample / PEAK_FP32_TFLOPS + dp * d_flops_sample / d_peak) * args.batch / 1e9
+                phases.append({"phase": nm, "ms": ms, "gflop": fl / 1e9, "tflops": fl / (ms * 1e-3) / 1e12 if ms else 0.0,
+                               "roofline_frac": floor_ms / ms if ms and fl else None})
+            note("phases: " + ", ".join(f"{ph['phase']} {ph['ms']:.2f}" for ph in phases if ph["ms"] >= 0.05))
         if args.dims == 2:
             workload = f"C3: {args.size}x{args.size} bs{args.batch}/GPU"
         elif args.dtype == "bf16":
@@ -386,8 +506,9 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "adam_lr": args.lr,
                        "d_head_weight_scale": head_scale},
             "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
-                     "backend": dist.get_backend() if world > 1 else None},
+                     "backend": dist.get_backend() if world > 1 else None, "ranks_seen": ranks_seen},
             "roofline": roofline,
+            "phases": phases,
             # the step's matrix work priced at the peak of the pipe it runs on, over the step time (bf16 storage:
             # D's share -- everything but G's forward x2 + backward = 4 x g_flops -- on the bf16 pipe, G on the fp32 pipe)
             "step_mfma_frac": ((step_flops_sample * args.batch) / PEAK_FP32_TFLOPS if args.dtype == "f32" else

@@ -2848,12 +2848,13 @@ __global__ __launch_bounds__(256, 2) void gather_patch3d_c16_kernel(const Gather
   }
 }
 
-static bool patch3d_ok(const GatherConv& p) {
+// Geometry / launch-mode half of the 3-D patch kernel's predicate: what mpgan_conv_variant and
+// mpgan_conv_stats_rows can decide from the conv alone (the caller sizes its partial rows from it).
+static bool patch3d_geom_ok(const GatherConv& p) {
   static const bool off = getenv("MPGAN_DBG_NO_PATCH3D") != nullptr;
-  if (off || !(p.Cin == 16 && p.Cout == 16 && p.ldi % 4 == 0 && p.nphase == 1 && p.Kz == 3 && p.Ky == 3 && p.Kx == 3 &&
+  if (off || !(p.Cin == 16 && p.Cout == 16 && p.nphase == 1 && p.Kz == 3 && p.Ky == 3 && p.Kx == 3 &&
                !p.tanh_out && !p.fold.acc && !p.stats_acc && !p.bwd.part && !p.in_bf16 && !p.out_bf16 && p.ksplit <= 1 &&
-               p.pro.n_stride == 0 && ((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.wp)) & 15) == 0 &&
-               (!p.pro.scale || ((reinterpret_cast<uintptr_t>(p.pro.scale) | reinterpret_cast<uintptr_t>(p.pro.shift)) & 15) == 0)))
+               p.pro.n_stride == 0))
     return false;
   const Phase& ph = p.ph[0];
   if (!(ph.nz == 3 && ph.ny == 3 && ph.nx == 3 && ph.oz == 0 && ph.oy == 0 && ph.ox == 0 && p.Do == ph.Mz && p.Ho == ph.My &&
@@ -2861,7 +2862,14 @@ static bool patch3d_ok(const GatherConv& p) {
     return false;
   for (int d = 0; d < 3; ++d)
     if (p.istride[d] != 1 || p.ostride[d] != 1 || (p.dstep[d] != 1 && p.dstep[d] != -1) || (p.kstep[d] != 1)) return false;
-  return (long)p.N * p.Di * p.Hi * p.Wi * p.ldi < (1L << 31);
+  return (long)p.N * p.Di * p.Hi * p.Wi * p.Cin < (1L << 31);
+}
+
+// The operand half: pitches, alignment and the 32-bit offset range of the tensors actually passed.
+static bool patch3d_operands_ok(const GatherConv& p) {
+  return p.ldi % 4 == 0 && ((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.wp)) & 15) == 0 &&
+         (!p.pro.scale || ((reinterpret_cast<uintptr_t>(p.pro.scale) | reinterpret_cast<uintptr_t>(p.pro.shift)) & 15) == 0) &&
+         (long)p.N * p.Di * p.Hi * p.Wi * p.ldi < (1L << 31);
 }
 
 static P3Grid patch3d_grid(const GatherConv& p) {
@@ -2905,7 +2913,13 @@ static int launch_gather(const GatherConv& p, hipStream_t st) {
     MPGAN_UNSUPPORTED(p.bwd.part != nullptr, "thin conv: no fused norm-backward sums (mpgan_conv_bwd_stats_rows() == 0)");
     return launch_thin(p, maxM, st);
   }
-  if (patch3d_ok(p)) return launch_patch3d(p, st);
+  if (patch3d_geom_ok(p)) {
+    if (patch3d_operands_ok(p)) return launch_patch3d(p, st);
+    // the caller sized its partial rows for one row per 2x8x8 tile (mpgan_conv_stats_rows): the K-stepped fallback
+    // would write a different number of them
+    MPGAN_UNSUPPORTED(p.stats != nullptr, "gather_conv: fused statistics of a 3-D patch-kernel geometry need 16-byte "
+                                          "aligned operands, a channel pitch % 4 == 0 and < 2^31 input elements");
+  }
   {
     PatchLaunch pl;
     int smem = 0;
@@ -3230,7 +3244,7 @@ extern "C" int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward
   const bool t2 = p.Cout == 1 && !p.pro.scale && p.Cin % 4 == 0 && lanes >= 1 && lanes <= 64 &&
                   (lanes & (lanes - 1)) == 0 && (long)T * p.Cin * 4 <= 48 * 1024;
   const int v = select_variant(p, max_phase_pixels(p), t1, t2);
-  if (v > 2 && patch3d_ok(p)) return 18;                                      // 3-D patch kernel, 16 -> 16 channels
+  if (v > 2 && patch3d_geom_ok(p)) return 18;                                     // 3-D patch kernel, 16 -> 16 channels
   if (v > 2) {
     PatchLaunch pl;
     if (patch_plan(p, &pl, nullptr)) return pl.merged ? 17 : 16;

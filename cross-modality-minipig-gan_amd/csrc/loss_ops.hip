@@ -154,6 +154,15 @@ __global__ void vec_sum_accum_kernel(const float* __restrict__ v, int n, float* 
   }
 }
 
+// out[0] = sum_i v[i] * w[i] in index order (a few dozen device scalars: the perceptual loss's per-tap terms)
+__global__ void weighted_sum_kernel(const float* __restrict__ v, const float* __restrict__ w, int n, float* out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += v[i] * w[i];
+    *out = s;
+  }
+}
+
 // ---- sigmoid + BCE ----------------------------------------------------------
 __global__ __launch_bounds__(256) void sigmoid_bce_kernel(const float* __restrict__ logit, int n, float target,
                                                           float loss_scale, float* __restrict__ prob,
@@ -410,6 +419,12 @@ extern "C" int mpgan_scale_by_device_scalar(const float* x, const float* scalar,
   hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(ew_blocks2(numel)), dim3(256), 0, (hipStream_t)stream, x, scalar,
                      (long)numel, y);
   return check_launch("scale_by_device_scalar");
+}
+
+extern "C" int mpgan_weighted_sum(const float* v, const float* w, int32_t n, float* out, void* stream) {
+  MPGAN_CHECK_ARG(v && w && out && n > 0 && n <= 4096, "weighted_sum: bad argument (1..4096 terms)");
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, v, w, n, out);
+  return check_launch("weighted_sum");
 }
 
 extern "C" int32_t mpgan_l1_partials(void) { return L1_PARTIALS; }

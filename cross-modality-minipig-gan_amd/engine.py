@@ -39,16 +39,17 @@ class KernelProbe:
         self.want = want            # None = every tagged call, else a set of kernel names
         self.detail = detail        # True: time EVERY call, keyed "<c entry point> <geometry>" (tools/profile_step.py)
         self.min_flops = min_flops  # only launches with at least this much algorithmic work (the dense families)
-        self.samples = []           # (kernel, flops, ev0, ev1)
+        self.samples = []           # (kernel, flops, ev0, ev1, algorithmic bytes)
 
     def summary(self):
         """kernel -> dict(calls, ms, flops): durations read after a synchronize."""
         out = {}
-        for k, fl, e0, e1 in self.samples:
-            d = out.setdefault(k, dict(calls=0, ms=0.0, flops=0.0))
+        for k, fl, e0, e1, by in self.samples:
+            d = out.setdefault(k, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
             d["calls"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += fl
+            d["bytes"] += by
         return out
 
 
@@ -225,7 +226,8 @@ class Program:
             timed = False
             if probe is not None:
                 if probe.detail:
-                    tag = (f"{self.names[i]} {self.descs[i]}".strip(), tag[1] if tag else 0.0)
+                    tag = (f"{self.names[i]} {self.descs[i]}".strip(), tag[1] if tag else 0.0,
+                           tag[2] if tag and len(tag) > 2 else 0.0)
                 timed = (tag is not None and (probe.want is None or tag[0] in probe.want)
                          and tag[1] >= probe.min_flops)
             if timed:                              # events go on the stream the kernel is launched on
@@ -236,7 +238,7 @@ class Program:
                 raise RuntimeError(f"{self.names[i]} failed (status {rc}): {lib().mpgan_last_error().decode()}")
             if timed:
                 e1.record(side if on_side else main)
-                probe.samples.append((tag[0], tag[1], e0, e1))
+                probe.samples.append((tag[0], tag[1], e0, e1, tag[2] if len(tag) > 2 else 0.0))
         if side_busy:                              # never leave work un-joined behind a program
             ev = self._event(-1)
             ev.record(side)
@@ -250,6 +252,13 @@ def conv_macs(g: ConvGeom) -> int:
     """Algorithmic multiply-accumulates of one conv (transposed conv counted input-side)."""
     grid = g.in_dhw if g.transposed else g.out_dhw
     return g.n * grid[0] * grid[1] * grid[2] * g.cin * g.cout * g.taps
+
+
+def conv_bytes(g: ConvGeom, esize: int = 4) -> int:
+    """Algorithmic HBM bytes of one conv in any direction: the gathered side read or written once
+    plus the dense side read or written once; weights and norm vectors are not counted."""
+    i, o = g.in_dhw, g.out_dhw
+    return g.n * (i[0] * i[1] * i[2] * g.cin + o[0] * o[1] * o[2] * g.cout) * esize
 
 
 def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_sample_norm: bool = False,
@@ -358,10 +367,24 @@ class ParamStore:
     def attach_grads(self):
         """Re-point .grad at the flat gradient views (an optimizer's
         zero_grad(set_to_none=True) detaches them)."""
-        for p in self._params:
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * self._off[id(p)]:
-                o = self._off[id(p)]
-                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        lost = [p for p in self._params
+                if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * self._off[id(p)]]
+        if not lost:
+            return
+        # A gradient that was set to None (torch.optim's zero_grad default) counts as zeroed: the kernels ACCUMULATE
+        # into the flat buffer, so its slice must not keep the previous step's values.
+        all_none = len(lost) == len(self._params) and all(p.grad is None for p in lost)
+        if all_none:
+            self.flat_grad.zero_()
+        for p in lost:
+            o = self._off[id(p)]
+            view = self.flat_grad[o:o + p.numel()].view(p.shape)
+            if p.grad is None:
+                if not all_none:
+                    view.zero_()
+            else:
+                view.copy_(p.grad)                 # a foreign gradient tensor: adopt its values
+            p.grad = view
 
     def offset(self, p) -> int:
         return self._off[id(p)]
@@ -447,17 +470,22 @@ class ParamStore:
         self._pack_state.clear()               # a new packed buffer holds nothing yet
 
     def emit_pack(self, prog: Program):
-        """The repack launch, skipped while the parameters are known to be unchanged since the last pack: torch
-        bumps the flat buffer's version counter on every in-place write through it or a parameter view, and the
-        fused Adam (which writes through a raw pointer) calls `touch()`.  Back-to-back forwards on constant
-        weights (inference, the discriminator's real/fake pair of one step) then pack once."""
+        """The repack launch, skipped while the parameters are known to be unchanged since the last pack.
+        Every Parameter keeps its OWN version counter (`p.data = flat[...]` aliases the storage, not the counter),
+        so the key holds the counters of all packed parameters -- `load_state_dict`, `nn.init.*`, `weight.mul_()`
+        and a stock `torch.optim.Adam` bump those -- next to the flat buffer's counter (writes through `store.flat`)
+        and `touch()` (the fused Adam writes through a raw pointer).  Back-to-back forwards on constant weights
+        (inference, the discriminator's real/fake pair of one step) then pack once."""
         self.frozen = True
         fn = lib().mpgan_pack_weights
         args = (self.flat.data_ptr(), self.packed.data_ptr(), self.table.data_ptr(), self.table.shape[0], self._max_elems)
         state = self._pack_state
+        packed_params = [r.mod.weight for r in self.convs]
+        for f in self.fused:
+            packed_params += [f.a.mod.bias, f.b.mod.bias]
 
         def pack_if_stale(stream):
-            key = (self.flat._version, self.version, self._touched)
+            key = (self.flat._version, self.version, self._touched, sum(p._version for p in packed_params))
             if state.get("key") == key and not _ALWAYS_PACK:
                 return 0
             rc = fn(*args, stream)
@@ -533,7 +561,7 @@ def emit_conv_fwd(prog, g: ConvGeom, x, wp, bias, y, pro=None, resid=None, tanh=
     gc = g.c()
     pc = pro.c() if pro is not None else None
     tag = (gather_kernel_name(g, False, pro is not None, bool(pro is not None and pro.n_stride), _fast_leaky(pro)),
-           2.0 * conv_macs(g))
+           2.0 * conv_macs(g), conv_bytes(g))
     if fold is None and stats_acc is None:
         prog.add("conv_forward", lib().mpgan_conv_forward, C.byref(gc), x.data_ptr(), _ld(x), wp.data_ptr(), _p(bias),
                  C.byref(pc) if pc is not None else None, _p(resid), _ld(resid), int(tanh), _p(stats), y.data_ptr(),
@@ -552,7 +580,7 @@ def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):
     gc = g.c()
     prog.add("conv_backward_data", lib().mpgan_conv_backward_data, C.byref(gc), dy.data_ptr(), _ld(dy),
              wp_bwd.data_ptr(), _p(resid), _ld(resid), dx.data_ptr(), _ld(dx), keep=(gc, dy, wp_bwd, dx, resid),
-             desc=_gdesc(g), tag=("dgrad:" + gather_kernel_name(g, True, False), 2.0 * conv_macs(g)))
+             desc=_gdesc(g), tag=("dgrad:" + gather_kernel_name(g, True, False), 2.0 * conv_macs(g), conv_bytes(g)))
 
 
 _FUSE_BWD_STATS = not os.environ.get("MPGAN_DBG_NO_FUSE_BWD_STATS")
@@ -572,7 +600,7 @@ def emit_conv_dgrad_stats(prog, g: ConvGeom, dy, wp_bwd, dx, z, nb: "NormBuf", s
              wp_bwd.data_ptr(), dx.data_ptr(), _ld(dx), z.data_ptr(), _ld(z), nb.scale.data_ptr(), nb.shift.data_ptr(),
              nb.mean.data_ptr(), nb.invstd.data_ptr(), ACT_LEAKY, float(slope), partials.data_ptr(),
              keep=(gc, dy, wp_bwd, dx, z, nb, partials), desc=_gdesc(g),
-             tag=("dgrad:" + gather_kernel_name(g, True, False), 2.0 * conv_macs(g)))
+             tag=("dgrad:" + gather_kernel_name(g, True, False), 2.0 * conv_macs(g), conv_bytes(g)))
     return rows
 
 
@@ -586,7 +614,7 @@ def emit_conv_wgrad(prog, g: ConvGeom, x, dy, dw, ws, pro=None, dbias=None, lane
     prog.add("conv_backward_weight", lib().mpgan_conv_backward_weight, C.byref(gc), x.data_ptr(), _ld(x),
              C.byref(pc) if pc is not None else None, dy.data_ptr(), _ld(dy), dw.data_ptr(), _p(dbias), 1.0,
              ws.data_ptr(), ws.numel() * 4, keep=(gc, pc, x, dy, dw, dbias, ws, pro), desc=_gdesc(g),
-             tag=("wgrad_kernel", 2.0 * conv_macs(g)), lane=lane)
+             tag=("wgrad_kernel", 2.0 * conv_macs(g), conv_bytes(g)), lane=lane)
 
 
 def emit_bias_grad(prog, dy, db, partials):
@@ -1428,13 +1456,14 @@ class DiscPlanBF16:
                 rows = (rows_total + 255) // 256
                 f.add("conv_forward_f32_to_bf16", L.mpgan_conv_forward_f32_to_bf16, C.byref(gc), src.data_ptr(), 1,
                       store.wp(recs[0]).data_ptr(), cv.bias.data_ptr(), part.data_ptr(), z.data_ptr(), g.cout,
-                      keep=(gc, src, z, part), desc=_gdesc(g), tag=("thin_cin1_full_kernel<16, true>", 2.0 * conv_macs(g)))
+                      keep=(gc, src, z, part), desc=_gdesc(g), tag=("thin_cin1_full_kernel<16, true>", 2.0 * conv_macs(g),
+                           conv_bytes(g, 2) + 2 * src.numel()))
             else:
                 rows = ops.conv_stats_rows_bf16(g)
                 f.add("conv_forward_bf16", L.mpgan_conv_forward_bf16, C.byref(gc), src.data_ptr(), g.cin,
                       w16(i).data_ptr(), cv.bias.data_ptr(), part.data_ptr(), z.data_ptr(), g.cout,
                       keep=(gc, src, z, part), desc=_gdesc(g),
-                      tag=(_bf16_kernel_name(g, False), 2.0 * conv_macs(g)))
+                      tag=(_bf16_kernel_name(g, False), 2.0 * conv_macs(g), conv_bytes(g, 2)))
             f.add("norm_finalize", L.mpgan_norm_finalize, part.data_ptr(), 1, rows, g.cout, rows_total, 0,
                   _p(bn.weight), _p(bn.bias), float(bn.eps), float(bn.momentum), _p(bn.running_mean),
                   _p(bn.running_var), _p(bn.num_batches_tracked), nb.scale.data_ptr(), nb.shift.data_ptr(),
@@ -1494,16 +1523,16 @@ class DiscPlanBF16:
                     b.add("conv_backward_weight_bf16", L.mpgan_conv_backward_weight_bf16, C.byref(gc),
                           acts[i - 1].data_ptr(), g.cin, dz.data_ptr(), c, gv(cv.weight).data_ptr(), 1.0,
                           ws.data_ptr(), ws.numel() * 4, keep=(gc, ws), desc=_gdesc(g),
-                          tag=("wgrad_bf16_kernel<8>", 2.0 * conv_macs(g)))
+                          tag=("wgrad_bf16_kernel<8>", 2.0 * conv_macs(g), conv_bytes(g, 2)))
                 else:
                     b.add("conv_backward_weight_bf16dy", L.mpgan_conv_backward_weight_bf16dy, C.byref(gc),
                           self.x_in.data_ptr(), 1, dz.data_ptr(), c, gv(cv.weight).data_ptr(), gv(cv.bias).data_ptr(),
                           1.0, ws.data_ptr(), ws.numel() * 4, keep=(gc, ws), desc=_gdesc(g),
-                          tag=("wgrad_thin_kernel", 2.0 * conv_macs(g)))
+                          tag=("wgrad_thin_kernel", 2.0 * conv_macs(g), conv_bytes(g, 2) + 2 * self.x_in.numel()))
             if i > 0:
                 b.add("conv_backward_data_bf16", L.mpgan_conv_backward_data_bf16, C.byref(gc), dz.data_ptr(), c,
                       w16b(i).data_ptr(), gas[i - 1].data_ptr(), g.cin, keep=(gc,), desc=_gdesc(g),
-                      tag=("dgrad:" + _bf16_kernel_name(g, True), 2.0 * conv_macs(g)))
+                      tag=("dgrad:" + _bf16_kernel_name(g, True), 2.0 * conv_macs(g), conv_bytes(g, 2)))
             elif want_input_grad:
                 self.g_x = E(n, *dhw, 1)
                 b.add("conv_backward_data_bf16_to_f32", L.mpgan_conv_backward_data_bf16_to_f32, C.byref(gc), dz.data_ptr(),
@@ -1595,7 +1624,20 @@ class PatchDiscPlan:
         # gradients arriving through the perceptual taps of the three head tensors (zero unless a
         # perceptual loss deposited them) and the per-layer (z, y, a) coefficients
         self.tap_g_h, self.tap_g_logit, self.tap_g_prob = Z(*self.h.shape), Z(n), Z(n)
-        self.coef = [Z(4) for _ in convs]
+        self.coef_all = Z(4 * len(convs))                      # one buffer: the perceptual loss fills it in one launch
+        self.coef = [self.coef_all[4 * i:4 * i + 4] for i in range(len(convs))]
+        # constant weights of the perceptual loss (test_runs/GAN.py:288-298: every tap's L1 mean / its numel; Flatten
+        # repeats the last activation, key 12): forward terms in the order [layer0 z, y, a, layer1 ..., h, logit, prob]
+        nl = len(convs)
+        wf, wb = [], []
+        for i, z in enumerate(self.zs):
+            nel = float(z.numel())
+            last = 2.0 if i == nl - 1 else 1.0
+            wf += [1.0 / nel, 1.0 / nel, last / nel]
+            wb += [1.0 / (nel * nel), 1.0 / (nel * nel), last / (nel * nel), 0.0]
+        wf += [1.0 / self.h.numel(), 1.0 / self.logit.numel(), 1.0 / self.prob.numel()]
+        self.perc_w_fwd = torch.tensor(wf, device=dev)
+        self.perc_w_bwd = torch.tensor(wb, device=dev)
         if want_input_grad:
             self.g_x = E(n, *dhw, 1)
 

@@ -146,6 +146,18 @@ class FusedAdam(torch.optim.Optimizer):
         store = self._state()
         params = list(self.net.parameters())
         g = sd["param_groups"][0]
+        # validate everything before touching the moments: a checkpoint of a differently shaped network must leave
+        # this optimizer as it was
+        names = [n for n, _ in self.net.named_parameters()]
+        for i, st in sd["state"].items():
+            if not 0 <= int(i) < len(params):
+                raise ValueError(f"FusedAdam.load_state_dict: state entry {i} but the network has {len(params)} parameters")
+            p = params[int(i)]
+            for key in ("exp_avg", "exp_avg_sq"):
+                if key not in st or st[key].numel() != p.numel():
+                    got = tuple(st[key].shape) if key in st else None
+                    raise ValueError(f"FusedAdam.load_state_dict: {key} of parameter {int(i)} ({names[int(i)]}, shape "
+                                     f"{tuple(p.shape)}) has shape {got}")
         self.param_groups[0].update(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"])
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
@@ -337,6 +349,10 @@ def load_reference_checkpoint(model: nn.Module, path: str, strict: bool = False,
                 break
     res = model.load_state_dict(sd, strict=strict)
     if optimizers is not None and isinstance(blob, dict) and blob.get("optimizer_states"):
-        for opt, st in zip(optimizers, blob["optimizer_states"]):
+        states = blob["optimizer_states"]
+        if len(states) != len(optimizers):
+            raise ValueError(f"{path}: {len(states)} optimizer_states for {len(optimizers)} optimizers "
+                             "(configure_optimizers order: generator, discriminator)")
+        for opt, st in zip(optimizers, states):
             opt.load_state_dict(st)
     return res

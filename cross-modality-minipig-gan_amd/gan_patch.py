@@ -76,18 +76,15 @@ class _PerceptualFn(torch.autograd.Function):
         pf, pr = taps_fake.plan, taps_real.plan
         dev = h_fake.device
         part = torch.empty(ops.tap_l1_partials(), device=dev)
-        total = torch.zeros(1, device=dev)
         nl = len(pf.zs)
-        for i in range(nl):
-            out3 = torch.empty(3, device=dev)
-            ops.tap_l1(pf.zs[i], pf.lrelu(pf.nbs[i]), pr.zs[i], pr.lrelu(pr.nbs[i]), part, out3)
-            w = torch.tensor([1.0, 1.0, 2.0 if i == nl - 1 else 1.0], device=dev)   # Flatten repeats the last activation
-            total += (out3 * w).sum() / pf.zs[i].numel()
+        vals = torch.empty(3 * nl + 3, device=dev)     # the 16 L1 means ([z, y, a] per layer; a of the last layer
+        for i in range(nl):                            # stands for keys 11 and 12), weighted by pf.perc_w_fwd
+            ops.tap_l1(pf.zs[i], pf.lrelu(pf.nbs[i]), pr.zs[i], pr.lrelu(pr.nbs[i]), part, vals[3 * i:3 * i + 3])
         l1part = torch.empty(ops.l1_partials(), device=dev)
-        for a, b in ((pf.h, pr.h), (pf.logit, pr.logit), (pf.prob, pr.prob)):
-            v = torch.empty((), device=dev)
-            ops.l1_loss(a.reshape(-1), b.reshape(-1), l1part, v)
-            total += v / a.numel()
+        for k, (a, b) in enumerate(((pf.h, pr.h), (pf.logit, pr.logit), (pf.prob, pr.prob))):
+            ops.l1_loss(a.reshape(-1), b.reshape(-1), l1part, vals[3 * nl + k])
+        total = torch.empty(1, device=dev)
+        ops.weighted_sum(vals, pf.perc_w_fwd, total)
         ctx.taps = (taps_fake, taps_real)
         return total
 
@@ -102,12 +99,8 @@ class _PerceptualFn(torch.autograd.Function):
                 continue
             pm, po = mine.plan, other.plan
             dev = gout.device
-            nl = len(pm.zs)
             g = gout.reshape(1).contiguous()
-            for i in range(nl):
-                nel = float(pm.zs[i].numel())
-                w = torch.tensor([1.0, 1.0, 2.0 if i == nl - 1 else 1.0, 0.0], device=dev) / (nel * nel)
-                pm.coef[i].copy_(w * g)
+            ops.scale_by_device_scalar(pm.perc_w_bwd, g, pm.coef_all)      # every layer's (z, y, a) coefficients
             l1part = torch.empty(ops.l1_partials(), device=dev)
             dummy = torch.empty((), device=dev)
             for a, b, dst in ((pm.h, po.h, pm.tap_g_h), (pm.logit, po.logit, pm.tap_g_logit),
@@ -115,7 +108,7 @@ class _PerceptualFn(torch.autograd.Function):
                 tmp = torch.empty(a.numel(), device=dev)
                 ops.l1_loss(a.reshape(-1), b.reshape(-1), l1part, dummy, tmp, 1.0 / a.numel())   # sign/numel^2
                 ops.scale_by_device_scalar(tmp, g, tmp)
-                dst.view(-1).add_(tmp)
+                ops.axpby(dst.view(-1), 1.0, tmp, 1.0, dst.view(-1))
             pm.peer = po
             pm.peer_lease = other.lease           # keep the peer's buffers alive until our backward has run
             grads.append(torch.zeros(1, device=dev))

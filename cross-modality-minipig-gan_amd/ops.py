@@ -457,6 +457,14 @@ def scale_by_device_scalar(x, scalar, y):
     return y
 
 
+def weighted_sum(v, w, out):
+    """out[0] = sum_i v[i] * w[i] (device vectors of equal length, index order)."""
+    if v.numel() != w.numel() or not v.is_contiguous() or not w.is_contiguous():
+        raise ValueError("weighted_sum: v and w must be contiguous and of equal length")
+    check(lib().mpgan_weighted_sum(v.data_ptr(), w.data_ptr(), v.numel(), out.data_ptr(), _stream()), "weighted_sum")
+    return out
+
+
 def l1_partials() -> int:
     return int(lib().mpgan_l1_partials())
 

@@ -301,6 +301,10 @@ int mpgan_sigmoid_forward(const float* logit, int32_t n, float* prob, void* stre
 int mpgan_sigmoid_backward(const float* dprob, const float* prob, int32_t n, float* dlogit, void* stream);
 /* y = x * (*scalar)  (scalar on the device: an upstream autograd gradient) */
 int mpgan_scale_by_device_scalar(const float* x, const float* scalar, int64_t numel, float* y, void* stream);
+/* out[0] = sum_i v[i]*w[i], i = 0..n-1 in index order (n <= 4096 device scalars).  Replaces the running sum of
+ * `F.l1_loss(...) / numel` over the 16 perceptual taps (test_runs/GAN.py:288-298): v holds the taps' L1 means, w
+ * their 1/numel weights. */
+int mpgan_weighted_sum(const float* v, const float* w, int32_t n, float* out, void* stream);
 
 /* loss = mean |a-b| (F.l1_loss, GAN_final.py:247-248); grad_a = scale*sign(a-b)/numel
  * (written when grad_a != null).  partials: >= mpgan_l1_partials() floats. */

@@ -1,0 +1,232 @@
+"""BASELINE config C5 as an ASSEMBLED step: the reference's true graph (3-D U-Net cascade + Conv3d discriminator,
+code/GAN/GAN_final.py:106-114,167-189,250-296) through `GAN(..., storage_dtype="bf16").fit_batch` -- the bf16-storage
+discriminator feeding its input gradient into the fp32 generator's backward, both optimizers, BatchNorm bookkeeping.
+
+Checker: oracle/refmodel.py (fp32, the generator) + oracle/bf16_emul.py (the discriminator under the bf16-storage
+contract of DESIGN.md section 3a).  Two implementations of a bf16-storage network agree on LOSSES and FORWARD values
+at the 1e-3 level but not on whole-network gradients (a rounding to bf16 turns an fp32-level difference into
+one-ulp flips that BatchNorm's backward amplifies: tests/test_bf16_gpu.py measures 2-10 %), so the gradient checks
+are arranged to be well-conditioned:
+  * the generator's gradient is compared TEACHER-FORCED at the hand-off: the upstream gradient dL/dy our bf16
+    discriminator + L1 loss produced is fed to the fp32 oracle generator's backward, and every parameter gradient
+    must then agree at fp32 level (flat relative L2 2e-2, per tensor with the fp64-free kink bound of
+    test_networks_gpu.py) -- this pins the g_x -> GeneratorPlan.backward wiring, the 3-D patch kernels
+    (gather_patch3d_c16 / wgrad_patch3d_c16 at a size where persistent blocks walk several tiles, with ragged
+    tiles) and all statistics rows;
+  * dL/dy itself and the discriminator's gradients are held against the emulation by the sanity bound of
+    test_bf16_gpu.py (no further from the emulation than the emulation is from pure fp32, + 2e-2), the head
+    (no cancellation yet) to 1e-2."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PRE_BN_BIAS = ("model_conv.0.bias", "model_conv.3.bias", "model_conv.6.bias", "model_conv.9.bias")
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-300)).item()
+
+
+class _GradTap:
+    """Stands where DataParallelGAN would: copies each network's raw flat gradient before Adam."""
+
+    def __init__(self):
+        self.grads = {}
+
+    def reduce_gradients(self, net, opt):
+        self.grads[id(net)] = {n: p.grad.detach().clone().cpu() for n, p in net.named_parameters()}
+
+
+def test_c5_step_bf16_storage_against_emulation_and_oracle():
+    """One full G+D step at 72^3, bs 2 (the 16 -> 16 level is 36^3: 18 x 5 x 5 = 450 tiles of 2x8x8 per volume,
+    ragged in y and x, 900 tiles over <= 512 persistent blocks)."""
+    import torch.nn.functional as F
+    from mpgan_amd import ops
+    from mpgan_amd.gan import GAN
+    from oracle import bf16_emul as E
+    from oracle import refmodel as R
+    S, n = 72, 2
+    shape = (1, S, S, S)
+    ref = R.GAN(shape, dimensions=3)
+    R.closed_form_fill_(ref.generator)
+    R.closed_form_fill_(ref.discriminator)
+    ref.train()
+    gen = torch.Generator().manual_seed(77)
+    t1 = torch.rand(n, *shape, generator=gen) * 2 - 1
+    t2 = torch.rand(n, *shape, generator=gen) * 2 - 1
+
+    ours = GAN(1, S, S, S, dimensions=3, storage_dtype="bf16")
+    ours.generator.load_state_dict(ref.generator.state_dict())
+    ours.discriminator.load_state_dict(ref.discriminator.state_dict())
+    ours.train()
+    # the 64^3-class level really runs the 3-D patch kernels, and more tiles than persistent blocks
+    g16 = ops.ConvGeom(n, (S // 2,) * 3, 16, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    assert ops.conv_variant(g16, False, 1) == 18 and ops.conv_variant(g16, True, 0) == 18
+    assert n * ((S // 2 + 1) // 2) * ((S // 2 + 7) // 8) ** 2 > 512
+    tap = _GradTap()
+    ours.ddp = tap
+    captured = {}
+    rec = ours.reconstruction_loss
+
+    def rec_and_capture(y_hat, y):
+        y_hat.register_hook(lambda g: captured.__setitem__("gy", g.detach().clone()))
+        captured["y"] = y_hat.detach().clone()
+        return rec(y_hat, y)
+
+    ours.reconstruction_loss = rec_and_capture
+    opts, _ = ours.configure_optimizers()
+    log = {k: float(v) for k, v in ours.fit_batch({"t1w": t1.cuda(), "t2w": t2.cuda()}, 0, opts).items()}
+    torch.cuda.synchronize()
+
+    # ---------------- G step on the oracle side ----------------
+    rg, rd = ref.generator, ref.discriminator
+    y_ref = rg(t1)
+    assert (captured["y"].cpu() - y_ref).abs().mean().item() < 1e-4              # fp32 generator: north_star's L1 bound
+    assert (captured["y"].cpu() - y_ref).abs().max().item() < 2e-3
+    adv = E.disc_step(rd, y_ref.detach(), 1.0)
+    g_recon = F.l1_loss(y_ref, t2)
+    assert abs(log["g_recon_loss"] - g_recon.item()) <= 2e-3 * g_recon.item()
+    assert abs(log["g_adv_loss"] - adv["loss"].item()) <= 5e-3 * abs(adv["loss"].item()) + 1e-4, (log["g_adv_loss"], adv["loss"].item())
+    assert abs(log["g_loss"] - (adv["loss"].item() + g_recon.item())) <= 5e-3 * abs(adv["loss"].item() + g_recon.item()) + 1e-4
+    # dL/dy: ours vs the emulation (sanity bound: the emulation's own distance to pure fp32)
+    gy_l1 = torch.autograd.grad(g_recon, y_ref, retain_graph=True)[0]
+    gy_emul = adv["grad_x"] + gy_l1
+    yr = y_ref.detach().clone().requires_grad_(True)
+    F.binary_cross_entropy(rd(yr), torch.ones(n, 1)).backward()                  # (advances the oracle D's running stats once)
+    gy_f32 = yr.grad + gy_l1
+    gy = captured["gy"].cpu()
+    e_gy, cost_gy = _rel(gy, gy_emul), _rel(gy_emul, gy_f32)
+    print(f"dL/dy: ours vs bf16 emulation {e_gy:.4f}; emulation vs fp32 oracle (precision cost) {cost_gy:.4f}")
+    assert e_gy <= cost_gy + 2e-2, (e_gy, cost_gy)
+    # teacher-forced: OUR upstream gradient through the oracle generator's backward
+    y_ref.backward(gy)
+    gg = tap.grads[id(ours.generator)]
+    rp = dict(rg.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in rp.values())
+    errs = {}
+    for name, p in rp.items():
+        if name.endswith("conv.bias") and (name[:-len("conv.bias")] + "adn.N.weight") in rp:
+            assert gg[name].abs().max().item() <= 1e-4 * gmax + 1e-6, name      # true gradient: zero
+            continue
+        if p.numel() == 1:
+            continue
+        errs[name] = _rel(gg[name], p.grad)
+    flat_o = torch.cat([gg[k].reshape(-1) for k in rp])
+    flat_r = torch.cat([p.grad.reshape(-1) for p in rp.values()])
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print("G gradient, teacher-forced at dL/dy: flat rel-L2", _rel(flat_o, flat_r), "worst tensors", worst)
+    assert _rel(flat_o, flat_r) <= 2e-2
+    assert worst[0][1] <= 5e-2, worst            # a PReLU-kink flip spreads over its layer
+    slopes = {k: (gg[k].item(), p.grad.item()) for k, p in rp.items() if p.numel() == 1}
+    smax = max(abs(w) for _, w in slopes.values())
+    assert max(abs(g - w) for g, w in slopes.values()) <= 5e-2 * smax
+
+    # ---------------- D step: same generator weights on both sides ----------------
+    with torch.no_grad():
+        ours_g = dict(ours.generator.named_parameters())
+        for name, p in rg.named_parameters():
+            p.copy_(ours_g[name].detach().cpu())
+        y2 = rg(t1)
+    real = E.disc_step(rd, t2, 0.9)
+    fake = E.disc_step(rd, y2, 0.0)
+    d_loss = 0.5 * (real["loss"].item() + fake["loss"].item())
+    assert abs(log["d_loss"] - d_loss) <= 5e-3 * abs(d_loss) + 1e-4, (log["d_loss"], d_loss)
+    # the pure-fp32 oracle's D step: the precision cost the sanity bound is measured against (and D's running stats)
+    for p in rd.parameters():
+        p.grad = None
+    (0.5 * (F.binary_cross_entropy(rd(t2), torch.full((n, 1), 0.9)) +
+            F.binary_cross_entropy(rd(y2), torch.zeros(n, 1)))).backward()
+    gd = tap.grads[id(ours.discriminator)]
+    errs, cost = {}, {}
+    for name, p in rd.named_parameters():
+        if name in PRE_BN_BIAS:
+            continue
+        want = 0.5 * (real["grads"][name] + fake["grads"][name]).reshape(p.shape)
+        errs[name], cost[name] = _rel(gd[name], want), _rel(want, p.grad)
+    print("D gradients, ours vs bf16 emulation:", {k: round(e, 4) for k, e in errs.items()})
+    print("bf16 emulation vs fp32 oracle (precision cost):", {k: round(e, 4) for k, e in cost.items()})
+    for name, e in errs.items():
+        tight = name.startswith("model_linear") or name == "model_conv.10.weight"
+        assert e <= (1e-2 if tight else cost[name] + 2e-2), (name, e, cost[name])
+
+    # ---------------- BatchNorm bookkeeping: G saw 2 forwards, D 3 ----------------
+    sd_g, sd_d = ours.generator.state_dict(), ours.discriminator.state_dict()
+    for k, v in rg.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(sd_g[k]) == 2 == int(v), k
+        elif "running_" in k:
+            assert (sd_g[k].cpu() - v).abs().max().item() <= 1e-4 * v.abs().max().item() + 1e-5, k
+    for k, v in rd.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(sd_d[k]) == 3 == int(v), k
+        elif "running_" in k:      # statistics come from fp32 accumulators over bf16-stored activations
+            assert (sd_d[k].cpu() - v).abs().max().item() <= 1e-2 * v.abs().max().item() + 1e-4, k
+
+
+def test_c5_full_size_step_is_finite_deterministic_and_g_matches_oracle():
+    """Config C5 itself: 128^3, bs 4, bf16 storage in D.  The CPU oracle cannot check a whole step at this size in
+    test time, so: (a) the (16, 32, 64, 128) generator's forward on ONE 128^3 volume against the oracle (L1 < 1e-4);
+    (b) a full `fit_batch` -- all four logged losses finite and in BCE / L1 range, every parameter and gradient
+    finite, BatchNorm counters 2 (G) and 3 (D); (c) the same step with the second stream switched off is
+    bit-identical (weight gradients beside the backward chain, no floating-point atomics anywhere)."""
+    from mpgan_amd import engine
+    from mpgan_amd.gan import GAN
+    from oracle import refmodel as R
+    S, n = 128, 4
+    ref_g = R.CasNetGenerator((1, S, S, S), 6, dimensions=3)
+    R.closed_form_fill_(ref_g)
+    ref_g.train()
+    sd_g = {k: v.clone() for k, v in ref_g.state_dict().items()}
+    torch.manual_seed(0)
+    shell_d = R.Discriminator((1, S, S, S), dimensions=3)
+    R.closed_form_fill_(shell_d)
+    sd_d = {k: v.clone() for k, v in shell_d.state_dict().items()}
+    del shell_d
+    gen = torch.Generator().manual_seed(1234)
+    t1 = torch.rand(n, 1, S, S, S, generator=gen) * 2 - 1
+    t2 = torch.rand(n, 1, S, S, S, generator=gen) * 2 - 1
+    batch = {"t1w": t1.cuda(), "t2w": t2.cuda()}
+
+    def run(single_stream):
+        m = GAN(1, S, S, S, dimensions=3, storage_dtype="bf16", g_lr=1e-4, d_lr=1e-4)
+        m.generator.load_state_dict(sd_g)
+        m.discriminator.load_state_dict(sd_d)
+        m.train()
+        saved = engine._SINGLE_STREAM
+        engine._SINGLE_STREAM = single_stream
+        try:
+            y1 = None
+            if not single_stream:
+                with torch.no_grad():
+                    y1 = m.generator(batch["t1w"][:1]).cpu()      # (a): one volume, train-mode statistics of that volume
+                m.generator.load_state_dict(sd_g)                  # running stats back to the start
+            opts, _ = m.configure_optimizers()
+            log = {k: float(v) for k, v in m.fit_batch(batch, 0, opts).items()}
+            torch.cuda.synchronize()
+        finally:
+            engine._SINGLE_STREAM = saved
+        return m, log, y1
+
+    m, log, y1 = run(False)
+    with torch.no_grad():
+        y_ref = ref_g(t1[:1])
+    l1 = (y1 - y_ref).abs().mean().item()
+    assert l1 < 1e-4 and (y1 - y_ref).abs().max().item() < 2e-3, (l1, (y1 - y_ref).abs().max().item())
+    for k in ("g_adv_loss", "g_recon_loss", "g_loss", "d_loss"):
+        assert k in log and log[k] == log[k] and 0.0 <= log[k] <= 101.0, (k, log.get(k))      # BCE's -100 clamp bounds it
+    assert 0.0 < log["g_recon_loss"] < 2.0
+    for net, fwd in ((m.generator, 2), (m.discriminator, 3)):
+        assert torch.isfinite(net.store.flat).all() and torch.isfinite(net.store.flat_grad).all()
+        assert net.store.flat_grad.abs().max().item() > 0.0
+        for k, v in net.state_dict().items():
+            if k.endswith("num_batches_tracked"):
+                assert int(v) == fwd, (k, int(v))
+            elif "running_" in k:
+                assert torch.isfinite(v).all(), k
+    m1, log1, _ = run(True)
+    assert log == log1, (log, log1)
+    assert torch.equal(m.generator.store.flat, m1.generator.store.flat)
+    assert torch.equal(m.discriminator.store.flat, m1.discriminator.store.flat)
+    assert torch.equal(m.generator.store.flat_grad, m1.generator.store.flat_grad)
+    assert torch.equal(m.discriminator.store.flat_grad, m1.discriminator.store.flat_grad)

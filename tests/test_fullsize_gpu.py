@@ -116,7 +116,7 @@ class _GradTap:
         self.grads[id(net)] = {n: p.grad.detach().clone().cpu() for n, p in net.named_parameters()}
 
 
-G_GRAD_TOL = 5e-2     # per parameter tensor (measured: 1.9-2.9 % worst per U-Net, 0.7 % over the whole flat gradient)
+YARD_EPS = 2e-3       # err(ours, f64) <= 3 err(oracle f32, f64) + YARD_EPS, per gradient tensor (relative L2)
 
 
 def _rel_l2(a, b):
@@ -127,24 +127,31 @@ def test_full_gd_step_at_c3_matches_oracle():
     """BASELINE config C3 itself: ONE full G+D step at 256x256, bs 16, closed-form weights, against the
     CPU oracle's step (about 10-20 s of host time).  What is pinned, in the order the step produces it:
       * g_adv / g_recon / g_loss (computed before any update) to 2e-3 relative;
-      * the generator's raw flat gradient by relative L2: 2e-2 over the whole buffer, 5e-2 per tensor (pre-norm
-        conv biases, whose true gradient is zero, only by magnitude; the scalar PReLU slopes against the
-        largest of them);
+      * the generator's raw gradient, tensor by tensor, against an fp64 run of the oracle's G step as the
+        yardstick: err(ours, f64) <= 3 err(oracle f32, f64) + 2e-3 in relative L2 -- i.e. no further from the
+        true gradient than torch's own fp32 arithmetic is (an activation within fp32 rounding of a PReLU kink
+        lands on either side in ANY fp32 implementation and BatchNorm spreads that flip over the layer, DESIGN
+        section 8: the fp32 oracle carries such flips against fp64 as we do, so the bound needs no calibrated
+        constant).  Every PReLU slope gradient is held individually the same way (absolute, against the largest
+        slope gradient); pre-norm conv biases, whose true gradient is zero, by magnitude; the whole flat
+        gradient additionally to 2e-2 against the fp32 oracle;
       * d_loss to 2e-3 -- the oracle's generator is OVERWRITTEN with our updated parameters after the G
         update, so the D step of both sides starts from identical weights (Adam turns rounding noise in
         tiny gradients into +-lr steps; without the overwrite only 5 % could be asked);
-      * the discriminator's raw gradients: the 952,576-input head's weight, the first layer's weight,
-        and every other parameter by relative L2;
+      * the discriminator's raw gradients: the 952,576-input head to 2e-3 against the fp32 oracle, every other
+        tensor by the same fp64 yardstick (the fp64 oracle's D step, generator overwritten likewise);
       * BatchNorm running statistics and batch counters of both networks (G: 2 forwards, D: 3);
       * the same step with the stream overlap switched off is bit-identical (side-stream G forward in
         the D step, weight gradients beside the backward-data chain)."""
     from mpgan_amd import engine
     from mpgan_amd.gan import GAN
     from oracle import refmodel as R
+    import copy
     ref = R.GAN((1, 256, 256), dimensions=2)
     R.closed_form_fill_(ref.generator)
     R.closed_form_fill_(ref.discriminator)
     ref.train()
+    ref64 = copy.deepcopy(ref).double()          # the yardstick: the same step in fp64
     gen = torch.Generator().manual_seed(1234)
     t1 = torch.rand(16, 1, 256, 256, generator=gen) * 2 - 1
     t2 = torch.rand(16, 1, 256, 256, generator=gen) * 2 - 1
@@ -186,39 +193,60 @@ def test_full_gd_step_at_c3_matches_oracle():
     for k in ("g_adv_loss", "g_recon_loss", "g_loss"):
         got, want = log[k], float(ref.logged[k])
         assert abs(got - want) <= 2e-3 * abs(want) + 1e-6, (k, got, want)
+    # the same G step in fp64
+    b64 = {"t1w": t1.double(), "t2w": t2.double()}
+    for p in ref64.discriminator.parameters():
+        p.requires_grad_(False)
+    ref64.training_step(b64, 0, 0).backward()
     gg = tap.grads[id(ours.generator)]
+    p64 = dict(ref64.generator.named_parameters())
     keys = set(dict(ref.generator.named_parameters()).keys())
     gmax = max(p.grad.abs().max().item() for p in ref.generator.parameters())
-    errs, scalars = {}, {}
+    table, scalars, bad = {}, {}, []
     for name, p in ref.generator.named_parameters():
         if name.endswith("conv.bias") and (name[:-len("conv.bias")] + "adn.N.weight") in keys:
             assert gg[name].abs().max().item() <= 1e-4 * gmax + 1e-6, name          # true gradient: zero
             continue
-        if p.numel() == 1:            # PReLU slopes: one number = a sum over a whole layer with heavy cancellation;
-            scalars[name] = (gg[name].item(), p.grad.item())     # held against the largest of them below
+        g64 = p64[name].grad
+        if p.numel() == 1:            # PReLU slopes: one number = a sum over a whole layer with heavy cancellation
+            scalars[name] = (gg[name].item(), p.grad.item(), g64.item())
             continue
-        errs[name] = _rel_l2(gg[name], p.grad)
+        e_ours, e_32 = _rel_l2(gg[name], g64), _rel_l2(p.grad, g64)
+        table[name] = (e_ours, e_32)
+        if e_ours > 3 * e_32 + YARD_EPS:
+            bad.append((name, e_ours, e_32))
+    smax = max(abs(w64) for _, _, w64 in scalars.values())
+    for name, (g, w32, w64) in scalars.items():
+        if abs(g - w64) > 3 * abs(w32 - w64) + YARD_EPS * smax:
+            bad.append((name, abs(g - w64) / smax, abs(w32 - w64) / smax))
     flat_ours = torch.cat([gg[n].reshape(-1) for n, _ in ref.generator.named_parameters()])
     flat_ref = torch.cat([p.grad.reshape(-1) for _, p in ref.generator.named_parameters()])
+    flat_64 = torch.cat([p64[n].grad.reshape(-1) for n, _ in ref.generator.named_parameters()])
     flat_err = _rel_l2(flat_ours, flat_ref)
-    per_unet = [max(v for k, v in errs.items() if k.startswith(f"model.{u}.")) for u in range(6)]
-    print("G grad rel-L2: flat", flat_err, "worst per U-Net", per_unet)
-    # An activation within fp32 rounding of a PReLU kink lands on opposite sides in two correct implementations
-    # and BatchNorm's batch coupling spreads that one flip over its layer's gradient: at
-    # 16 x 256^2 some flips are certain, so single tensors are held to 5 %, the whole flat gradient to 2 %.
-    for u in range(6):
-        assert per_unet[u] <= G_GRAD_TOL, (u, per_unet[u], sorted(errs.items(), key=lambda kv: -kv[1])[:5])
+    per_unet = [(max(v[0] for k, v in table.items() if k.startswith(f"model.{u}.")),
+                 max(v[1] for k, v in table.items() if k.startswith(f"model.{u}.")) ) for u in range(6)]
+    print("G grad rel-L2 vs fp64, worst per U-Net (ours, oracle f32):", [(round(a, 5), round(b, 5)) for a, b in per_unet])
+    print("G flat gradient: ours vs f32", flat_err, "ours vs f64", _rel_l2(flat_ours, flat_64), "f32 vs f64",
+          _rel_l2(flat_ref, flat_64))
+    print("PReLU slope grads / largest: worst (ours - f64)", max(abs(g - w64) for g, _, w64 in scalars.values()) / smax,
+          "worst (f32 - f64)", max(abs(w32 - w64) for _, w32, w64 in scalars.values()) / smax)
+    assert not bad, sorted(bad, key=lambda r: -r[1])[:8]
     assert flat_err <= 2e-2, flat_err
-    smax = max(abs(w) for _, w in scalars.values())
-    sworst = max(abs(g - w) for g, w in scalars.values())
-    print("PReLU slope grads: max |ref|", smax, "worst abs diff", sworst)
-    assert sworst <= 5e-2 * smax, (sworst, smax)
+    assert _rel_l2(flat_ours, flat_64) <= 3 * _rel_l2(flat_ref, flat_64) + YARD_EPS
     for p in ref.discriminator.parameters():
         p.requires_grad_(True)
     # ---- level the field: our updated generator into the oracle (buffers stay the oracle's own) ----
     with torch.no_grad():
+        ours_g = dict(ours.generator.named_parameters())
         for name, p in ref.generator.named_parameters():
-            p.copy_(dict(ours.generator.named_parameters())[name].detach().cpu())
+            p.copy_(ours_g[name].detach().cpu())
+        for name, p in ref64.generator.named_parameters():
+            p.copy_(ours_g[name].detach().cpu().double())
+    for p in ref64.discriminator.parameters():
+        p.requires_grad_(True)
+    for p in ref64.generator.parameters():
+        p.requires_grad_(False)
+    ref64.training_step(b64, 0, 1).backward()
     # ---- oracle, D step ----
     for p in ref.generator.parameters():
         p.requires_grad_(False)
@@ -230,14 +258,17 @@ def test_full_gd_step_at_c3_matches_oracle():
     rd = dict(ref.discriminator.named_parameters())
     gmax_d = max(p.grad.abs().max().item() for p in rd.values())
     derr = {}
+    rd64 = dict(ref64.discriminator.named_parameters())
     for name, p in rd.items():
         if name in ("model_conv.0.bias", "model_conv.3.bias", "model_conv.6.bias", "model_conv.9.bias"):
             assert gd[name].abs().max().item() <= 1e-4 * gmax_d + 1e-6, name
             continue
-        tol = 2e-3 if name.startswith("model_linear") else 5e-2     # head: no BatchNorm / kink between it and the loss
-        derr[name] = _rel_l2(gd[name], p.grad)
-        assert derr[name] <= tol, (name, derr[name])
-    print("D grad rel-L2:", {k: round(v, 6) for k, v in derr.items()})
+        e_ours, e_32 = _rel_l2(gd[name], rd64[name].grad), _rel_l2(p.grad, rd64[name].grad)
+        derr[name] = (round(e_ours, 6), round(e_32, 6))
+        if name.startswith("model_linear"):      # head: no BatchNorm / kink between it and the loss
+            assert _rel_l2(gd[name], p.grad) <= 2e-3, (name, _rel_l2(gd[name], p.grad))
+        assert e_ours <= 3 * e_32 + YARD_EPS, (name, e_ours, e_32)
+    print("D grad rel-L2 vs fp64 (ours, oracle f32):", derr)
     # ---- BatchNorm bookkeeping of both networks ----
     for net, rnet, fwd in ((ours.generator, ref.generator, 2), (ours.discriminator, ref.discriminator, 3)):
         sd = net.state_dict()

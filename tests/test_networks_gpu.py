@@ -348,6 +348,16 @@ def test_fused_adam_state_round_trips_in_torch_adam_format():
     assert opt.step_count == 3
     assert torch.equal(d.store.flat, d2.store.flat), (d.store.flat - d2.store.flat).abs().max().item()
     assert torch.equal(opt.exp_avg, opt2.exp_avg) and torch.equal(opt.exp_avg_sq, opt2.exp_avg_sq)
+    # a state of a differently shaped network is refused BEFORE anything is overwritten
+    other = Discriminator((1, 40, 40), dimensions=2, device="cuda")          # another Linear width
+    o3 = FusedAdam(other, lr=1e-3, betas=(0.5, 0.999))
+    o3.zero_grad()
+    other(torch.rand(2, 1, 40, 40, device="cuda")).sum().backward()
+    o3.step()
+    m_before, steps_before = opt.exp_avg.clone(), opt.step_count
+    with pytest.raises(ValueError, match="model_linear.1.weight"):
+        opt.load_state_dict(o3.state_dict())
+    assert torch.equal(opt.exp_avg, m_before) and opt.step_count == steps_before
 
 
 def test_boundary_tensors_are_used_in_place_and_guarded():
@@ -393,3 +403,68 @@ def test_boundary_tensors_are_used_in_place_and_guarded():
     # the plan is returned to the pool and usable again
     y = g(x_al)
     y.sum().backward()
+
+
+def test_parameter_writes_after_a_forward_reach_the_packed_weights():
+    """The conv weights are re-packed whenever a parameter changed, whichever way it was written: after a forward
+    has packed once, `load_state_dict`, an in-place `weight.mul_()` / `nn.init` and a stock `torch.optim.Adam`
+    step (all of which bump the Parameter's own version counter, not the flat buffer's) must be seen by the next
+    forward.  Checked against a fresh module holding the same weights, and one Adam step against the oracle."""
+    R = _oracle()
+    from mpgan_amd.networks import CasNetGenerator, Discriminator
+    torch.manual_seed(11)
+    x = (torch.rand(2, 1, 32, 32) * 2 - 1).cuda()
+    for make in (lambda: CasNetGenerator((1, 32, 32), 2, dimensions=2), lambda: Discriminator((1, 32, 32), dimensions=2)):
+        a = make().cuda().train()
+        with torch.no_grad():
+            y0 = a(x).clone()                                   # packs once
+        torch.manual_seed(12)
+        other = make()                                          # different weights
+        sd = {k: v.clone() for k, v in other.state_dict().items()}
+        a.load_state_dict(sd)
+        fresh = make()
+        fresh.load_state_dict(sd)
+        fresh.cuda().train()
+        with torch.no_grad():
+            y1, y_f = a(x), fresh(x)
+        assert not torch.equal(y0, y1)
+        assert torch.equal(y1, y_f), (y1 - y_f).abs().max().item()
+        # in-place edit of one conv weight through the Parameter
+        name, w = next((n, p) for n, p in a.named_parameters() if n.endswith("weight") and p.dim() >= 4)
+        with torch.no_grad():
+            w.mul_(1.5)
+        fresh2 = make()
+        fresh2.load_state_dict({k: v.clone() for k, v in a.state_dict().items()})   # weights AND BatchNorm buffers
+        fresh2.cuda().train()
+        with torch.no_grad():
+            y2, y3 = a(x), fresh2(x)
+        assert not torch.equal(y1, y2)
+        assert torch.equal(y2, y3), (name, (y2 - y3).abs().max().item())
+    # a stock torch.optim.Adam on the engine's parameters (INTEGRATION.md): one step, then a forward, vs the oracle
+    torch.manual_seed(13)
+    ref = R.Discriminator((1, 32, 32), dimensions=2)
+    R.closed_form_fill_(ref)
+    ours = Discriminator((1, 32, 32), dimensions=2)
+    ours.load_state_dict(ref.state_dict())
+    ours.cuda().train()
+    opt_r = torch.optim.Adam(ref.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    opt_o = torch.optim.Adam(ours.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    xc = x.cpu()
+    for it in range(2):                                         # two steps: zero_grad() (set_to_none, torch's default)
+        for net, opt, inp in ((ref, opt_r, xc), (ours, opt_o, x)):   # must not leave the first step's gradients behind
+            opt.zero_grad()
+            net(inp).sum().backward()
+            if it == 1:
+                g_first = dict(net.named_parameters())["model_linear.1.weight"].grad.detach().cpu().clone()
+                if net is ref:
+                    g_ref = g_first
+                else:
+                    assert_close(g_first, g_ref, rtol=2e-3, what="head weight gradient on the second step")
+            opt.step()
+    with torch.no_grad():
+        p_r, p_o = ref(xc), ours(x).cpu()
+    assert_close(p_o, p_r, rtol=2e-3, atol=2e-4, what="D output after a torch.optim.Adam step")
+    # the step really moved the conv weights the second forward used
+    w_r = dict(ref.named_parameters())["model_conv.3.weight"]
+    w_o = dict(ours.named_parameters())["model_conv.3.weight"].detach().cpu()
+    assert (w_o - w_r).abs().max().item() <= 4.5e-3             # two Adam steps of +-lr: sign noise on ~zero gradients aside

@@ -60,27 +60,48 @@ def test_two_ranks_fit_batch_data_parallel(tmp_path):
         assert r0["synced_logged"][k] == r1["synced_logged"][k]
 
 
-def test_bench_line_contract_small_size():
+@pytest.mark.parametrize("extra,unit,dtype,peak,per_step", [
+    (["--size", "64", "--batch", "4"], "slices/s", "f32", 157.3, 4),
+    (["--dims", "3", "--size", "40", "--batch", "2", "--dtype", "bf16"], "volumes/s", "bf16", 2500.0, 2),   # C5's path
+])
+def test_bench_line_contract_small_size(extra, unit, dtype, peak, per_step):
     """bench.py at a small size (one rank, no CPU baseline): ONE JSON line on stdout with the driver's keys, the
-    roofline object and a dominant kernel named as rocprofv3 would name it."""
+    roofline object -- its kernel chosen by measured time and named as rocprofv3 would name it, the best kernel
+    beside it -- the per-pass `phases` of one step and the rank count seen by a collective.  Second case: the
+    3-D bf16-storage configuration (BASELINE config C5's code path)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--size", "64", "--batch", "4", "--steps", "2",
-                          "--warmup", "1", "--no-cpu-baseline", "--no-gfwd"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *extra, "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-gfwd", "--dense-min-gflop", "0.05"], capture_output=True, text=True,
+                         timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     j = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "phases", "dist"):
         assert k in j, k
-    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["dtype"] == "f32" and j["unit"] == "slices/s"
-    assert abs(j["value"] - 4 * 1000.0 / j["ms_per_step"]) < 1e-6 * j["value"]
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["dtype"] == dtype and j["unit"] == unit
+    assert abs(j["value"] - per_step * 1000.0 / j["ms_per_step"]) < 1e-6 * j["value"]
+    assert j["dist"]["ranks_seen"] == 1 and j["vs_baseline"] is None
     r = j["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "dense_families"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_role", "best_kernel",
+              "dense_kernels", "dense_families", "algorithmic_gb_per_s"):
         assert k in r, k
-    # (at this size no launch reaches the probe's 20-GFLOP floor, so `achieved` may be 0: the line still names a kernel)
-    assert r["bound"] == "mfma" and r["peak"] == 157.3 and 0.0 <= r["frac"] < 1.0 and "kernel" in r["kernel"]
+    assert r["bound"] == "mfma" and r["peak"] == peak and 0.0 < r["frac"] < 1.0 and "kernel" in r["kernel"]
+    # the named kernel is the one with the most measured time; the best one is at least as fast
+    by_time = max(r["dense_kernels"].items(), key=lambda kv: kv[1]["ms_per_step"])
+    assert by_time[0].replace("dgrad of ", "") == r["kernel"], (by_time[0], r["kernel"])
+    assert r["best_kernel"]["frac"] >= r["frac"] - 1e-12
+    for fam in ("fwd", "dgrad", "wgrad"):
+        assert r["dense_families"][fam]["algorithmic_gb_per_s"] > 0.0, fam
+    # phases: every network pass of the step, times adding up to about one step
+    names = [ph["phase"] for ph in j["phases"]]
+    assert sum(n.startswith("G fwd") for n in names) == 2 and sum(n.startswith("D fwd") for n in names) == 3
+    assert "G bwd" in names and any(n.startswith("D bwd x2") for n in names)
+    total = sum(ph["ms"] for ph in j["phases"])
+    assert 0.5 * j["ms_per_step"] <= total <= 2.0 * j["ms_per_step"], (total, j["ms_per_step"])
+    assert all(ph["roofline_frac"] is None or 0.0 < ph["roofline_frac"] < 1.0 for ph in j["phases"])
     assert "workload" in j["config"] and "model" not in j["config"]

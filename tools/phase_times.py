@@ -9,7 +9,7 @@ os.environ.setdefault("MPGAN_SINGLE_STREAM", "1")
 import torch
 import bench
 from mpgan_amd import engine
-from mpgan_amd.gan import GAN, adversarial_loss, reconstruction_loss, scalar_axpby
+from mpgan_amd.gan import GAN
 
 
 def main():
@@ -30,84 +30,19 @@ def main():
     gan.train()
     opt_g, opt_d = gan.configure_optimizers()[0]
     batch = bench.synthetic_batch(a.batch, sp, 0, dev)
-    x, t = batch["t1w"], batch["t2w"]
-    G, D = gan.generator, gan.discriminator
-    marks = []
     probe = engine.KernelProbe(detail=True)
-    probing = [False]
 
-    def mark(name):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        marks.append((name, e))
+    def on_phase(name, starting):
+        if name == a.probe:
+            engine.set_probe(probe if starting else None)
 
-    def step():
-        for p in D.parameters():
-            p.requires_grad_(False)
-        for p in G.parameters():
-            p.requires_grad_(True)
-        opt_g.zero_grad()
-        mark("start")
-        if a.probe == "gfwd" and probing[0]:
-            engine.set_probe(probe)
-        y = G(x)
-        if a.probe == "gfwd":
-            engine.set_probe(None)
-        mark("G fwd (train, grads)")
-        def at_y(g):
-            mark("D bwd (input grad only) + L1 bwd")
-            if a.probe == "gbwd" and probing[0]:
-                engine.set_probe(probe)
-        y.register_hook(at_y)
-        p = D(y)
-        mark("D fwd (fake)")
-        valid = torch.ones(a.batch, 1, device=dev)
-        loss = scalar_axpby(adversarial_loss(p, valid), 1.0, reconstruction_loss(y, t), 1.0)
-        mark("losses")
-        loss.backward()
-        if a.probe == "gbwd":
-            engine.set_probe(None)
-        mark("G bwd")
-        opt_g.step()
-        mark("Adam G")
-        for p_ in D.parameters():
-            p_.requires_grad_(True)
-        for p_ in G.parameters():
-            p_.requires_grad_(False)
-        opt_d.zero_grad()
-        mark("zero_grad D")
-        with torch.no_grad():
-            y2 = G(x)
-        mark("G fwd (no grad)")
-        lr = adversarial_loss(D(t), torch.full((a.batch, 1), 0.9, device=dev))
-        mark("D fwd (real)")
-        lf = adversarial_loss(D(y2), torch.zeros(a.batch, 1, device=dev))
-        mark("D fwd (fake)")
-        d_loss = scalar_axpby(lr, 0.5, lf, 0.5)
-        if a.probe == "dbwd" and probing[0]:
-            engine.set_probe(probe)
-        d_loss.backward()
-        engine.set_probe(None)
-        mark("D bwd x2 (dgrad + wgrad)")
-        opt_d.step()
-        mark("Adam D")
-
-    for _ in range(2):
-        step()
+    for i in range(2):
+        gan.fit_batch(batch, i, [opt_g, opt_d])
     torch.cuda.synchronize()
-    probing[0] = True
-    tot = {}
-    order = []
-    for _ in range(a.steps):
-        marks.clear()
-        step()
-        torch.cuda.synchronize()
-        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
-            key = f"{len(order):02d} {n1}" if len(order) < len(marks) - 1 else None
-            if key is not None:
-                order.append(key)
-        for i, ((n0, e0), (n1, e1)) in enumerate(zip(marks[:-1], marks[1:])):
-            tot[order[i]] = tot.get(order[i], 0.0) + e0.elapsed_time(e1)
+    rows = bench.phase_breakdown(gan, [opt_g, opt_d], batch, steps=a.steps, on_phase=on_phase if a.probe else None)
+    engine.set_probe(None)
+    order = [f"{i:02d} {nm}" for i, (nm, _, _, _) in enumerate(rows)]
+    tot = {k: r[1] * a.steps for k, r in zip(order, rows)}
     s = 0.0
     for k in order:
         ms = tot[k] / a.steps

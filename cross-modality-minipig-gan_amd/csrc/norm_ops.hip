@@ -292,44 +292,109 @@ __global__ __launch_bounds__(256) void partials_compact_kernel(const float* __re
   if (w == 0 && c < W) compact[(long)g * W + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
+// PReLU-slope gradient: the sum of the third partial over every row and channel, by ONE block, formed directly
+// from the rows (a few thousand values for the U-Net's layers) -- no per-channel hand-off, hence no second launch.
+// Rows are [3][C]; with C % 4 == 0 the third section is read as float4 (16-byte aligned: 3*C*4*r + 2*C*4), so a
+// 1024-row x 16-channel layer is 16 independent loads per thread instead of 64.
+__device__ __forceinline__ void slope_grad_block(const float* __restrict__ partials, int rows, int C, float* dslope) {
+  __shared__ double red[256];
+  double s = 0.0;
+  const int t = (int)threadIdx.x;
+  if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(partials) & 15) == 0) {
+    const int cq = C >> 2;                                 // float4 per row
+    const long total = (long)rows * cq;
+    for (long i = t; i < total; i += 256 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long e = i + 256L * u;
+        if (e < total) {
+          const long r = e / cq;
+          const int q = (int)(e - r * cq);
+          v[u] = *reinterpret_cast<const float4*>(partials + r * 3 * C + 2 * C + 4 * q);
+        } else {
+          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
+    }
+  } else {
+    const long total = (long)rows * C;
+    for (long i = t; i < total; i += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long e = i + 256L * u;
+        const long r = e / C;
+        v[u] = e < total ? partials[r * 3 * C + 2 * C + (e - r * C)] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+  }
+  red[t] = s;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (t < h) red[t] += red[t + h];
+    __syncthreads();
+  }
+  if (t == 0) *dslope += (float)red[0];
+}
+
+// BatchNorm with >= 512 partial rows (the 128^2 / 256^2 levels of the generator: 1024-4096 rows; the rows a
+// backward-data epilogue leaves: one per tile): ONE BLOCK per channel, thread t takes rows t, t + 256, ... with
+// four independent row pairs in flight, fixed-order tree in LDS.  (One wave per channel walked 4096 rows in 16
+// dependent trips: 16-75 us for per-channel scalar work.)  The grid's last block is the slope gradient.
+__global__ __launch_bounds__(256) void norm_bwd_finalize_wide_kernel(const float* __restrict__ partials, int rows, int C,
+                                                                     double cnt, float* dgamma, float* dbeta,
+                                                                     float* dslope, float* __restrict__ c1,
+                                                                     float* __restrict__ c2) {
+  if (dslope && blockIdx.x == gridDim.x - 1) {
+    slope_grad_block(partials, rows, C, dslope);
+    return;
+  }
+  __shared__ double r1[256], r2[256];
+  const int c = blockIdx.x, t = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = t; r < rows; r += 1024) {
+    float v[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r + u * 256;
+      const float* row = partials + (long)(rr < rows ? rr : r) * 3 * C;
+      const float m = rr < rows ? 1.f : 0.f;
+      v[u][0] = row[c] * m;
+      v[u][1] = row[C + c] * m;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s1 += (double)v[u][0];
+      s2 += (double)v[u][1];
+    }
+  }
+  r1[t] = s1;
+  r2[t] = s2;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (t < h) { r1[t] += r1[t + h]; r2[t] += r2[t + h]; }
+    __syncthreads();
+  }
+  if (t != 0) return;
+  c1[c] = (float)(r1[0] / cnt);
+  c2[c] = (float)(r2[0] / cnt);
+  if (dgamma) dgamma[c] += (float)r2[0];
+  if (dbeta) dbeta[c] += (float)r1[0];
+}
+
 // One wave per channel (dgamma, dbeta, c1, c2).
-// The grid's LAST block (when dslope != null) adds the PReLU-slope gradient instead: the sum of the
-// third partial over every row and channel, formed directly from the rows (a few thousand values for
-// the U-Net's layers) -- no per-channel hand-off, hence no second launch.
+// The grid's LAST block (when dslope != null) adds the PReLU-slope gradient instead (slope_grad_block).
 __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __restrict__ partials, int N, int chunks,
                                                                 int C, long P, int instance, float* dgamma,
                                                                 float* dbeta, float* dslope,
                                                                 float* __restrict__ c1, float* __restrict__ c2) {
   if (dslope && blockIdx.x == gridDim.x - 1) {
-    __shared__ double red[256];
-    const int rows = N * chunks;
-    double s = 0.0;
-    // thread = (row group, channel): no division in the loop; 8 loads in flight per lane so that this
-    // block does not outlast the per-channel waves beside it
-    const int cw = C <= 256 ? C : 256;                     // channels covered per pass
-    const int c0 = (int)threadIdx.x % cw, rg = (int)threadIdx.x / cw, nrg = 256 / cw;
-    for (int cb = 0; cb < C; cb += cw) {
-      const int c = cb + c0;
-      if (c >= C || rg >= nrg) continue;
-      const float* col = partials + 2 * C + c;
-      for (int r = rg; r < rows; r += 8 * nrg) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int rr = r + u * nrg;
-          v[u] = rr < rows ? col[(long)rr * 3 * C] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += (double)v[u];
-      }
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
-      if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) *dslope += (float)red[0];
+    slope_grad_block(partials, N * chunks, C, dslope);
     return;
   }
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -732,6 +797,12 @@ extern "C" int mpgan_norm_bwd_finalize(const float* partials, int32_t n, int32_t
   MPGAN_UNSUPPORTED(dslope && (long)n * chunks * c > (1L << 18),
                     "norm_bwd_finalize: slope gradient over %ld partials (sized for the generator's layers)",
                     (long)n * chunks * c);
+  const long rows = (long)n * chunks;
+  if (!instance && rows >= 512 && rows < (1L << 31)) {   // many rows: a block per channel (see the kernel)
+    hipLaunchKernelGGL(norm_bwd_finalize_wide_kernel, dim3(c + (dslope ? 1 : 0)), dim3(256), 0, (hipStream_t)stream,
+                       partials, (int)rows, c, (double)P * n, dgamma, dbeta, dslope, c1, c2);
+    return check_launch("norm_bwd_finalize_wide");
+  }
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((c + 3) / 4 + (dslope ? 1 : 0)), dim3(256), 0, (hipStream_t)stream,
                      partials, n, chunks, c, (long)P, instance, dgamma, dbeta, dslope, c1, c2);
   return check_launch("norm_bwd_finalize");

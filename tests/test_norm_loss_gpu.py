@@ -26,6 +26,8 @@ def _norm_forward(z_cl, gamma, beta, instance, running=None, eps=1e-5, momentum=
 
 @pytest.mark.parametrize("c,spatial,n", [(16, (1, 40, 36), 3), (1, (1, 64, 64), 2), (128, (1, 9, 7), 2),
                                          (8, (1, 300, 280), 8),   # > 512 partial rows: folded before finalize
+                                         (16, (1, 128, 128), 16), (1, (1, 256, 256), 4),   # 1024 rows: block-per-channel
+                                         (6, (1, 160, 160), 8),                            # backward finalize, scalar slope sum
                                          (192, (1, 8, 8), 2), (32, (6, 10, 12), 2), (512, (2, 2, 2), 4)])
 @pytest.mark.parametrize("instance", [False, True])
 def test_norm_prelu_forward_backward(c, spatial, n, instance):

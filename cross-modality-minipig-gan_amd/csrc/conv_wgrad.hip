@@ -922,6 +922,245 @@ static int wgrad_p3_blocks(const mpgan_conv_geom* g) {
   return (int)(tiles < WP3_BLOCKS ? tiles : WP3_BLOCKS);
 }
 
+// ---------------------------------------------------------------------------
+// 2-D patch form of the weight gradient for the generator's narrow layers (<= 64 dense and <= 32 gathered
+// channels, 3x3 taps; round 3): the U-Net's 16 -> 16 and 32 -> 32 stride-1 units, its stride-2 down convs
+// (16 -> 32, 32 -> 64; each twice: unit0 and the strided residual conv) and ConvTranspose2d(64 -> 16).
+//   R[cd][t][cg] = sum over coarse pixels m of dense[m][cd] * gath[m * S - 1 + k_t][cg]      (S = 1 | 2)
+// The K-stepped pipeline above tiles such a 16 x 144 result as 32 x 128, re-stages every gathered pixel once per
+// tap and leaves one slab per K split (16 -> 16 at 128^2: 47 us + an 11 us reducer over 11 MB of slabs for
+// 1.2 GFLOP).  Here persistent blocks walk 8 x TX tiles of coarse pixels: the dense tile and the gathered patch
+// (producer's BatchNorm + PReLU applied on the way in, zero outside = the padding) are staged ONCE per tile --
+// the next tile's loads are in flight under the current contraction -- and v_mfma_f32_16x16x4_f32 contracts over
+// PIXELS (A[cd][px] from the dense tile, B[px][cg] from the patch shifted by the tap).  Work units (tap, 16-wide
+// dense block) are dealt round-robin to the four waves; accumulators live across the block's tiles, so a block
+// leaves ONE slab (and one bias row: column sums of the dense operand, accumulated by the loading threads) for
+// the fixed-order reducer: <= 512 slabs whatever the image size.
+// LDS pitches are chosen so that the four pixel groups of a wave read four different 16-bank quarters:
+// S * pitch = 16 or 48 (mod 64) floats.
+// ---------------------------------------------------------------------------
+constexpr int WP2_TY = 8;
+template <int CD, int CG, int S, int TX>
+struct WP2 {
+  static constexpr int TP = WP2_TY * TX;                       // coarse pixels per tile
+  static constexpr int PY = (WP2_TY - 1) * S + 3, PX = (TX - 1) * S + 3;
+  static constexpr int PROWS = PY * PX;
+  static constexpr int PGP = S == 1 ? (CG == 16 ? 16 : (CG == 32 ? 48 : 80)) : (CG == 16 ? 24 : 40);
+  static constexpr int PDP = CD == 16 ? 16 : (CD == 32 ? 48 : 80);
+  static constexpr int CA = CD / 16, CB = CG / 16;
+  static constexpr int NUNITS = 9 * CA, NU = (NUNITS + 3) / 4;
+  static constexpr int GQ = CG / 4, DQ = CD / 4;               // float4 per pixel
+  static constexpr int NPCH = (PROWS * GQ + 255) / 256, NDCH = (TP * DQ) / 256;
+  static constexpr int SMEM = (PROWS * PGP + TP * PDP) * 4;
+  static_assert((TP * DQ) % 256 == 0 && 256 % DQ == 0 && 256 % GQ == 0, "thread -> channel-quad mapping must be fixed");
+};
+struct WP2Grid { int tiles_y, tiles_x, ntiles; };
+
+template <int CD, int CG, int S, int TX, bool HAS_PRO>
+__global__ __launch_bounds__(256, 2) void wgrad_patch2d_kernel(const WgradParams p, const WP2Grid tg) {
+  using K = WP2<CD, CG, S, TX>;
+  extern __shared__ __attribute__((aligned(16))) float lds2[];
+  float* patch = lds2;                                          // [patch pixel][PGP]
+  float* dyt = lds2 + K::PROWS * K::PGP;                        // [tile pixel][PDP]
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, g = lane >> 4;
+  f32x4 acc[K::NU][K::CB];
+#pragma unroll
+  for (int u = 0; u < K::NU; ++u)
+#pragma unroll
+    for (int b = 0; b < K::CB; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[u][b][i] = 0.f;
+  // this wave's units: (tap, dense block) -> LDS offsets (wave-uniform)
+  int aoff[K::NU], boff[K::NU];
+#pragma unroll
+  for (int u = 0; u < K::NU; ++u) {
+    const int idx = wid + 4 * u;
+    const int tap = idx / K::CA, ca = idx - tap * K::CA;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    aoff[u] = 16 * ca;
+    boff[u] = (ky * K::PX + kx) * K::PGP;
+  }
+  // gathered patch: this thread's chunks (tile-independent decode); dense tile: its chunks
+  const int gq = tid % K::GQ, dq = tid % K::DQ;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  float slope = 1.f;
+  if constexpr (HAS_PRO) {
+    sc = *reinterpret_cast<const float4*>(p.pro.scale + 4 * gq);
+    sh = *reinterpret_cast<const float4*>(p.pro.shift + 4 * gq);
+    slope = pro_slope(p.pro);
+  }
+  const int act = p.pro.act;
+  int pyx[K::NPCH];
+#pragma unroll
+  for (int i = 0; i < K::NPCH; ++i) {
+    const int pr = (tid + 256 * i) / K::GQ;
+    pyx[i] = pr < K::PROWS ? (((pr / K::PX) << 16) | (pr % K::PX)) : -1;
+  }
+  float4 pv[K::NPCH], dv[K::NDCH];
+  unsigned pok = 0;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);               // column sums of this thread's dense chunks (bias gradient)
+  const int Gy = p.Gy, Gx = p.Gx, My = p.My, Mx = p.Mx, ldg = p.ldg, ldd = p.ldd;
+  auto load_tile = [&](unsigned tt) {
+    const unsigned tx = tt % (unsigned)tg.tiles_x;
+    unsigned t = tt / (unsigned)tg.tiles_x;
+    const unsigned ty = t % (unsigned)tg.tiles_y;
+    const int n = (int)(t / (unsigned)tg.tiles_y);
+    const int my0 = (int)ty * WP2_TY, mx0 = (int)tx * TX;
+    const int y0 = my0 * S - 1, x0 = mx0 * S - 1;
+    const float* __restrict__ gbase = p.gath + (long)n * Gy * Gx * ldg + 4 * gq;
+    pok = 0;
+#pragma unroll
+    for (int i = 0; i < K::NPCH; ++i) {
+      const int iy = y0 + (pyx[i] >> 16), ix = x0 + (pyx[i] & 0xffff);
+      const bool ok = pyx[i] >= 0 && (unsigned)iy < (unsigned)Gy && (unsigned)ix < (unsigned)Gx;
+      pv[i] = ok ? *reinterpret_cast<const float4*>(gbase + ((long)iy * Gx + ix) * ldg) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pok |= (ok ? 1u : 0u) << i;
+    }
+    const float* __restrict__ dbase = p.dense + (long)n * My * Mx * ldd + 4 * dq;
+#pragma unroll
+    for (int i = 0; i < K::NDCH; ++i) {
+      const int q = (tid + 256 * i) / K::DQ;
+      const int my = my0 + q / TX, mx = mx0 + q % TX;
+      dv[i] = (my < My && mx < Mx) ? *reinterpret_cast<const float4*>(dbase + ((long)my * Mx + mx) * ldd)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < K::NPCH; ++i) {
+      float4 v = pv[i];
+      if constexpr (HAS_PRO) {
+        if ((pok >> i) & 1u) {                                   // padding stays zero: act(0 * scale + shift) != 0
+          v.x = act_apply(fmaf(v.x, sc.x, sh.x), act, slope);
+          v.y = act_apply(fmaf(v.y, sc.y, sh.y), act, slope);
+          v.z = act_apply(fmaf(v.z, sc.z, sh.z), act, slope);
+          v.w = act_apply(fmaf(v.w, sc.w, sh.w), act, slope);
+        }
+      }
+      if (pyx[i] >= 0)
+        *reinterpret_cast<float4*>(patch + ((pyx[i] >> 16) * K::PX + (pyx[i] & 0xffff)) * K::PGP + 4 * gq) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < K::NDCH; ++i) {
+      const int q = (tid + 256 * i) / K::DQ;
+      *reinterpret_cast<float4*>(dyt + q * K::PDP + 4 * dq) = dv[i];
+      bsum.x += dv[i].x; bsum.y += dv[i].y; bsum.z += dv[i].z; bsum.w += dv[i].w;
+    }
+  };
+
+  const unsigned ntiles = (unsigned)tg.ntiles;
+  const unsigned per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const unsigned w0 = xcd_remap(blockIdx.x, gridDim.x) * per;
+  const unsigned wend = w0 + per < ntiles ? w0 + per : ntiles;
+  if (w0 < wend) load_tile(w0);
+  for (unsigned tt = w0; tt < wend; ++tt) {
+    __syncthreads();                                            // the previous tile's fragment reads are done
+    store_tile();
+    __syncthreads();
+    if (tt + 1 < wend) load_tile(tt + 1);                       // in flight under this tile's contraction
+    // ---- contraction over the tile's pixels, four at a time: k = pixel 4 j + g ----
+#pragma unroll 2
+    for (int j = 0; j < K::TP / 4; ++j) {
+      const int q = 4 * j + g;
+      const float* arow = dyt + q * K::PDP + ln;                 // A[row = cd][k] of dense block 0
+      const float* brow = patch + ((q / TX) * S * K::PX + (q % TX) * S) * K::PGP + ln;   // B[k][col = cg] at tap (0, 0)
+#pragma unroll
+      for (int u = 0; u < K::NU; ++u) {
+        if (wid + 4 * u < K::NUNITS) {                          // wave-uniform
+          const float a = arow[aoff[u]];
+#pragma unroll
+          for (int b = 0; b < K::CB; ++b)
+            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[boff[u] + 16 * b], acc[u][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- D[row = cd = 16 ca + 4 g + i][col = cg = 16 b + ln] -> partial[block][cd][tap * CG + cg] ----
+  float* out = p.partial + (long)blockIdx.x * CD * 9 * CG;
+#pragma unroll
+  for (int u = 0; u < K::NU; ++u) {
+    const int idx = wid + 4 * u;
+    if (idx < K::NUNITS) {
+      const int tap = idx / K::CA, ca = idx - tap * K::CA;
+#pragma unroll
+      for (int b = 0; b < K::CB; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[(16 * ca + 4 * g + i) * (9 * CG) + tap * CG + 16 * b + ln] = acc[u][b][i];
+    }
+  }
+  if (p.bias_partial) {                                         // fold the threads' column sums in a fixed order
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(lds2);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < K::DQ) {
+      float4 t = red[tid];
+      for (int r = tid + K::DQ; r < 256; r += K::DQ) {
+        const float4 v = red[r];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      *reinterpret_cast<float4*>(p.bias_partial + (long)blockIdx.x * CD + 4 * tid) = t;
+    }
+  }
+}
+
+// Which instance (if any) serves this conv: 0 none, else an index into the dispatch below.
+struct WP2Plan { int inst, blocks, tiles_y, tiles_x, ntiles, Cd, Cg; };
+static WP2Plan wgrad_p2_plan(const mpgan_conv_geom* g) {
+  WP2Plan pl{};
+  static const bool off = getenv("MPGAN_DBG_NO_WPATCH2D") != nullptr;
+  if (off || g->k[0] != 1 || g->k[1] != 3 || g->k[2] != 3 || g->in_dhw[0] != 1 || g->out_dhw[0] != 1) return pl;
+  if (g->pad[1] != 1 || g->pad[2] != 1 || g->stride[1] != g->stride[2] || g->stride[1] < 1 || g->stride[1] > 2) return pl;
+  const int S = g->stride[1];
+  int Cd, Cg, My, Mx;
+  if (!g->transposed) {
+    Cd = g->cout; Cg = g->cin; My = g->out_dhw[1]; Mx = g->out_dhw[2];
+    // forward-type mapping needs out = ceil(in / S) with pad 1, k 3 (true for every even extent)
+    if (My != (g->in_dhw[1] + 2 - 3) / S + 1 || Mx != (g->in_dhw[2] + 2 - 3) / S + 1) return pl;
+  } else {
+    if (S != 2 || g->out_dhw[1] != 2 * g->in_dhw[1] || g->out_dhw[2] != 2 * g->in_dhw[2]) return pl;
+    Cd = g->cin; Cg = g->cout; My = g->in_dhw[1]; Mx = g->in_dhw[2];
+  }
+  int inst = 0, tx = 16;
+  if (S == 1 && Cd == 16 && Cg == 16) inst = 1;
+  else if (S == 1 && Cd == 32 && Cg == 32) inst = 2;
+  else if (S == 2 && Cd == 32 && Cg == 16) inst = 3;
+  else if (S == 2 && Cd == 64 && Cg == 32) { inst = 4; tx = 8; }
+  else if (S == 2 && Cd == 64 && Cg == 16) { inst = 5; tx = 8; }
+  if (!inst || My < 4 || Mx < 4) return pl;
+  pl.tiles_y = (My + WP2_TY - 1) / WP2_TY;
+  pl.tiles_x = (Mx + tx - 1) / tx;
+  const long nt = (long)g->n * pl.tiles_y * pl.tiles_x;
+  if (nt >= (1L << 31)) return pl;
+  pl.ntiles = (int)nt;
+  pl.blocks = (int)(nt < 512 ? nt : 512);                      // two resident blocks per CU, each walking its range of tiles
+  pl.inst = inst; pl.Cd = Cd; pl.Cg = Cg;
+  return pl;
+}
+
+template <int CD, int CG, int S, int TX>
+static int launch_wgrad_p2(const WgradParams& p, const WP2Plan& pl, hipStream_t st) {
+  using K = WP2<CD, CG, S, TX>;
+  const WP2Grid tg{pl.tiles_y, pl.tiles_x, pl.ntiles};
+  auto k1 = wgrad_patch2d_kernel<CD, CG, S, TX, true>;
+  auto k0 = wgrad_patch2d_kernel<CD, CG, S, TX, false>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
+    hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
+    if (e1 != hipSuccess || e0 != hipSuccess) {
+      set_error("wgrad_patch2d: hipFuncSetAttribute: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e0));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  if (p.pro.scale) hipLaunchKernelGGL(k1, dim3(pl.blocks), dim3(256), K::SMEM, st, p, tg);
+  else hipLaunchKernelGGL(k0, dim3(pl.blocks), dim3(256), K::SMEM, st, p, tg);
+  return check_launch("wgrad_patch2d");
+}
+
 struct ThinWgradPlan { int blocks; long chunk; bool ok; };
 static ThinWgradPlan plan_thin_wgrad(int Cd, int Cg, int T, long M, bool has_pro, long lds_cap = 64 * 1024) {
   ThinWgradPlan t;
@@ -1078,6 +1317,13 @@ extern "C" int64_t mpgan_conv_wgrad_workspace(const mpgan_conv_geom* g) {
     const int64_t pneed = (int64_t)wgrad_p3_blocks(g) * (16 * 432 + 16) * (int64_t)sizeof(float);
     if (pneed > need) need = pneed;
   }
+  {                                              // 2-D patch form: one [Cd][9 * Cg] slab + Cd bias sums per persistent block
+    const WP2Plan p2 = wgrad_p2_plan(g);
+    if (p2.inst) {
+      const int64_t pneed = (int64_t)p2.blocks * (p2.Cd * 9 * p2.Cg + p2.Cd) * (int64_t)sizeof(float);
+      if (pneed > need) need = pneed;
+    }
+  }
   return need;
 }
 
@@ -1144,6 +1390,30 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((16 * 16 * 27 + 31) / 32 + bbp), dim3(256), 0, st0, p.partial, dw, nb, 16, 16,
                        27, beta, p.bias_partial, nb, dbias, bbp);
     return check_launch("wgrad_patch3d_reduce");
+  }
+  {
+    const WP2Plan p2 = wgrad_p2_plan(g);
+    if (p2.inst && p.ldd % 4 == 0 && p.ldg % 4 == 0 && p.pro.n_stride == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dense) | reinterpret_cast<uintptr_t>(p.gath)) & 15) == 0 &&
+        (!p.pro.scale || ((reinterpret_cast<uintptr_t>(p.pro.scale) | reinterpret_cast<uintptr_t>(p.pro.shift)) & 15) == 0)) {
+      const int64_t pslab = (int64_t)p2.blocks * Cd * 9 * Cg;
+      MPGAN_CHECK_ARG(workspace_bytes >= (pslab + (int64_t)p2.blocks * Cd) * (int64_t)sizeof(float),
+                      "conv_backward_weight: workspace too small for the 2-D patch form");
+      p.bias_partial = dbias ? p.partial + pslab : nullptr;
+      int rcp;
+      switch (p2.inst) {
+        case 1: rcp = launch_wgrad_p2<16, 16, 1, 16>(p, p2, st0); break;
+        case 2: rcp = launch_wgrad_p2<32, 32, 1, 16>(p, p2, st0); break;
+        case 3: rcp = launch_wgrad_p2<32, 16, 2, 16>(p, p2, st0); break;
+        case 4: rcp = launch_wgrad_p2<64, 32, 2, 8>(p, p2, st0); break;
+        default: rcp = launch_wgrad_p2<64, 16, 2, 8>(p, p2, st0); break;
+      }
+      if (rcp) return rcp;
+      const int bbp = dbias ? (Cd + 31) / 32 : 0;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Cd * Cg * 9 + 31) / 32 + bbp), dim3(256), 0, st0, p.partial, dw, p2.blocks,
+                         Cd, Cg, 9, beta, p.bias_partial, p2.blocks, dbias, bbp);
+      return check_launch("wgrad_patch2d_reduce");
+    }
   }
   {
     ThinWgradPlan tp = plan_thin_wgrad(Cd, Cg, T, M, p.pro.scale != nullptr);

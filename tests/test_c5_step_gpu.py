@@ -9,8 +9,8 @@ one-ulp flips that BatchNorm's backward amplifies: tests/test_bf16_gpu.py measur
 are arranged to be well-conditioned:
   * the generator's gradient is compared TEACHER-FORCED at the hand-off: the upstream gradient dL/dy our bf16
     discriminator + L1 loss produced is fed to the fp32 oracle generator's backward, and every parameter gradient
-    must then agree at fp32 level (flat relative L2 2e-2, per tensor with the fp64-free kink bound of
-    test_networks_gpu.py) -- this pins the g_x -> GeneratorPlan.backward wiring, the 3-D patch kernels
+    must then agree at fp32 level (flat relative L2 2e-2; per tensor no further from an fp64 run of the same
+    backward than torch's own fp32 run is, times 3) -- this pins the g_x -> GeneratorPlan.backward wiring, the 3-D patch kernels
     (gather_patch3d_c16 / wgrad_patch3d_c16 at a size where persistent blocks walk several tiles, with ragged
     tiles) and all statistics rows;
   * dL/dy itself and the discriminator's gradients are held against the emulation by the sanity bound of
@@ -80,7 +80,9 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
     torch.cuda.synchronize()
 
     # ---------------- G step on the oracle side ----------------
+    import copy
     rg, rd = ref.generator, ref.discriminator
+    rg64 = copy.deepcopy(rg).double()
     y_ref = rg(t1)
     assert (captured["y"].cpu() - y_ref).abs().mean().item() < 1e-4              # fp32 generator: north_star's L1 bound
     assert (captured["y"].cpu() - y_ref).abs().max().item() < 2e-3
@@ -99,28 +101,39 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
     e_gy, cost_gy = _rel(gy, gy_emul), _rel(gy_emul, gy_f32)
     print(f"dL/dy: ours vs bf16 emulation {e_gy:.4f}; emulation vs fp32 oracle (precision cost) {cost_gy:.4f}")
     assert e_gy <= cost_gy + 2e-2, (e_gy, cost_gy)
-    # teacher-forced: OUR upstream gradient through the oracle generator's backward
+    # teacher-forced: OUR upstream gradient through the oracle generator's backward -- in fp32 and, as the
+    # yardstick, in fp64 (BatchNorm over the 9^3 x 2 values of the deepest level and PReLU-kink flips make single
+    # tensors of ANY fp32 backward differ by percents): err(ours, f64) <= 3 err(oracle f32, f64) + 2e-3
     y_ref.backward(gy)
+    y64 = rg64(t1.double())
+    y64.backward(gy.double())
     gg = tap.grads[id(ours.generator)]
-    rp = dict(rg.named_parameters())
+    rp, p64 = dict(rg.named_parameters()), dict(rg64.named_parameters())
     gmax = max(p.grad.abs().max().item() for p in rp.values())
-    errs = {}
+    errs, bad = {}, []
     for name, p in rp.items():
         if name.endswith("conv.bias") and (name[:-len("conv.bias")] + "adn.N.weight") in rp:
             assert gg[name].abs().max().item() <= 1e-4 * gmax + 1e-6, name      # true gradient: zero
             continue
         if p.numel() == 1:
             continue
-        errs[name] = _rel(gg[name], p.grad)
+        e_ours, e_32 = _rel(gg[name], p64[name].grad), _rel(p.grad, p64[name].grad)
+        errs[name] = (e_ours, e_32)
+        if e_ours > 3 * e_32 + 2e-3:
+            bad.append((name, e_ours, e_32))
     flat_o = torch.cat([gg[k].reshape(-1) for k in rp])
     flat_r = torch.cat([p.grad.reshape(-1) for p in rp.values()])
-    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
-    print("G gradient, teacher-forced at dL/dy: flat rel-L2", _rel(flat_o, flat_r), "worst tensors", worst)
+    flat_64 = torch.cat([p64[k].grad.reshape(-1) for k in rp])
+    worst = sorted(errs.items(), key=lambda kv: -kv[1][0])[:4]
+    print("G gradient, teacher-forced at dL/dy: flat rel-L2 vs f32", _rel(flat_o, flat_r), "vs f64", _rel(flat_o, flat_64),
+          "(oracle f32 vs f64:", _rel(flat_r, flat_64), ") worst tensors (ours, oracle f32)", worst)
+    assert not bad, sorted(bad, key=lambda r: -r[1])[:6]
     assert _rel(flat_o, flat_r) <= 2e-2
-    assert worst[0][1] <= 5e-2, worst            # a PReLU-kink flip spreads over its layer
-    slopes = {k: (gg[k].item(), p.grad.item()) for k, p in rp.items() if p.numel() == 1}
-    smax = max(abs(w) for _, w in slopes.values())
-    assert max(abs(g - w) for g, w in slopes.values()) <= 5e-2 * smax
+    assert _rel(flat_o, flat_64) <= 3 * _rel(flat_r, flat_64) + 2e-3
+    slopes = {k: (gg[k].item(), p.grad.item(), p64[k].grad.item()) for k, p in rp.items() if p.numel() == 1}
+    smax = max(abs(w64) for _, _, w64 in slopes.values())
+    for k, (gv, w32, w64) in slopes.items():
+        assert abs(gv - w64) <= 3 * abs(w32 - w64) + 2e-3 * smax, (k, gv, w32, w64)
 
     # ---------------- D step: same generator weights on both sides ----------------
     with torch.no_grad():

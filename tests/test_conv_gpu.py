@@ -16,6 +16,8 @@ CONV_CASES = [
     (2, 16, 16, 3, 1, 1, (20, 24), 3),     # G down0.unit1
     (2, 16, 32, 3, 2, 1, (20, 24), 2),     # G down1.unit0
     (2, 32, 64, 3, 2, 1, (12, 16), 2),
+    (2, 32, 32, 3, 1, 1, (24, 20), 2),     # G down1.unit1 (2-D patch weight gradient, 32 x 32 channels)
+    (2, 16, 32, 3, 2, 1, (21, 27), 2),     # odd extents under stride 2
     (2, 64, 128, 3, 1, 1, (9, 7), 2),      # G bottom.unit0
     (2, 128, 128, 3, 1, 1, (8, 8), 2),     # G bottom.unit1
     (2, 64, 128, 1, 1, 0, (8, 8), 2),      # G bottom.residual (1x1)
@@ -629,3 +631,58 @@ def test_patch3d_prologue_residual_statistics_and_slices(spatial, n, p):
     dx = acc0.cuda()
     ops.conv_backward_data(g, to_cl(dy), ops.pack_weight(w.cuda(), for_dgrad=True), dx, resid=dx)
     assert_close(from_cl(dx, 3), dx_ref + acc0.permute(0, 4, 1, 2, 3), what="backward data + residual")
+
+
+@pytest.mark.parametrize("cd,cg,s,spatial,n,transposed", [
+    (16, 16, 1, (136, 200), 3, False),      # 17 x 13 x 3 = 663 tiles over 512 persistent blocks: two tiles per block
+    (32, 32, 1, (72, 144), 4, False),       # 9 x 9 x 4 = 324 tiles
+    (32, 16, 2, (140, 260), 2, False),      # stride 2: 70 x 130 coarse pixels, ragged tiles
+    (64, 32, 2, (66, 150), 3, False),       # 8-wide tiles: 5 x 10 x 3
+    (64, 16, 2, (40, 52), 3, True),         # ConvTranspose2d(64 -> 16): dense = x (coarse grid), gathered = dy
+])
+def test_patch2d_weight_gradient_prologue_slices_and_many_tiles(cd, cg, s, spatial, n, transposed):
+    """The 2-D patch form of the weight gradient (wgrad_patch2d_kernel) at sizes where a persistent block walks
+    several tiles: prologue (producer BatchNorm + PReLU with a device slope, zero padding of the ACTIVATED tensor)
+    on the gathered operand, both operands as channel slices of wider buffers, fused bias gradient, accumulate."""
+    from mpgan_amd import ops
+    gen = torch.Generator().manual_seed(500 + cd + cg + s)
+    if not transposed:
+        cin, cout = cg, cd
+        g = _geom(2, n, cin, cout, 3, s, 1, spatial)
+        z = torch.rand(n, cin, *spatial, generator=gen) * 2 - 1
+        sc, sh = torch.rand(cin, generator=gen) + 0.5, torch.rand(cin, generator=gen) - 0.5
+        alpha = 0.3
+        a = z * sc[None, :, None, None] + sh[None, :, None, None]
+        a = torch.where(a > 0, a, alpha * a).requires_grad_(True)
+        w = ((torch.rand(cout, cin, 3, 3, generator=gen) - 0.5) / (cin * 9) ** 0.5).requires_grad_(True)
+        b = (torch.rand(cout, generator=gen) - 0.5).requires_grad_(True)
+        y = F.conv2d(a, w, b, stride=s, padding=1)
+        gy = torch.rand(y.shape, generator=gen) * 2 - 1
+        y.backward(gy)
+        zbuf = torch.full((n, 1, *spatial, cin + 8), float("nan"), device="cuda")
+        zbuf[..., 4:4 + cin] = to_cl(z)
+        gybuf = torch.full((n, *g.out_dhw, cout + 4), float("nan"), device="cuda")
+        gybuf[..., :cout] = to_cl(gy)
+        pro = ops.Prologue(sc.cuda(), sh.cuda(), 0, ops.ACT_LEAKY, 1.0, torch.tensor([alpha], device="cuda"))
+        dw = torch.ones_like(w.detach()).cuda()
+        db = torch.ones(cout, device="cuda")
+        ws = torch.empty(ops.conv_wgrad_workspace(g) // 4, device="cuda")
+        ops.conv_backward_weight(g, zbuf[..., 4:4 + cin], gybuf[..., :cout], dw, ws, pro=pro, beta=1.0, dbias=db)
+        assert_close(dw.cpu() - 1.0, w.grad, what="wgrad (2-D patch form)")
+        assert_close(db.cpu() - 1.0, b.grad, what="bias grad (2-D patch form)")
+        ops.conv_backward_weight(g, zbuf[..., 4:4 + cin], gybuf[..., :cout], dw, ws, pro=pro, beta=0.0)
+        assert_close(dw.cpu(), w.grad, what="wgrad (2-D patch form), overwrite, no bias")
+    else:
+        cin, cout = cd, cg
+        g = _geom(2, n, cin, cout, 3, 2, 1, spatial, transposed=True)
+        x = (torch.rand(n, cin, *spatial, generator=gen) * 2 - 1).requires_grad_(True)
+        w = ((torch.rand(cin, cout, 3, 3, generator=gen) - 0.5) / (cin * 9) ** 0.5).requires_grad_(True)
+        y = F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1)
+        gy = torch.rand(y.shape, generator=gen) * 2 - 1
+        y.backward(gy)
+        xbuf = torch.full((n, 1, *spatial, cin + 32), float("nan"), device="cuda")      # x = a slice of the concat buffer
+        xbuf[..., :cin] = to_cl(x.detach())
+        dw = torch.full_like(w.detach(), float("nan")).cuda()
+        ws = torch.empty(ops.conv_wgrad_workspace(g) // 4, device="cuda")
+        ops.conv_backward_weight(g, xbuf[..., :cin], to_cl(gy), dw, ws)
+        assert_close(dw.cpu(), w.grad, what="convT wgrad (2-D patch form)")

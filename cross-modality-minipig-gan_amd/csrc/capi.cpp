@@ -28,3 +28,43 @@ extern "C" int mpgan_zero_bytes(void* ptr, int64_t bytes, void* stream) {
   }
   return MPGAN_OK;
 }
+
+// Development aid (include/mpgan_hip.h): in a `make STAMPS=1` build every following gather-conv launch records
+// its blocks' phase time stamps into `buf`; the product build has no stamps and says so.
+#ifdef MPGAN_STAMPS
+namespace mpgan {
+StampCtx& stamp_ctx() {
+  static StampCtx c{nullptr, 0, 0, 0};
+  return c;
+}
+}  // namespace mpgan
+#endif
+extern "C" int mpgan_debug_stamps(void* buf, int64_t launches, int64_t blocks_per_launch) {
+#ifdef MPGAN_STAMPS
+  mpgan::StampCtx& c = mpgan::stamp_ctx();
+  c.base = static_cast<unsigned long long*>(buf);
+  c.launches = buf ? launches : 0;
+  c.blocks = blocks_per_launch;
+  c.next = 0;
+  return MPGAN_OK;
+#else
+  (void)buf; (void)launches; (void)blocks_per_launch;
+  mpgan::set_error("debug_stamps: this library was built without -DMPGAN_STAMPS (make STAMPS=1)");
+  return MPGAN_ERR_UNSUPPORTED;
+#endif
+}
+// Launches stamped since the last mpgan_debug_stamps call (-1 in the product build).
+extern "C" int64_t mpgan_debug_stamps_used(void) {
+#ifdef MPGAN_STAMPS
+  return mpgan::stamp_ctx().next;
+#else
+  return -1;
+#endif
+}
+// Rate of the stamps' clock in kHz (hipDeviceAttributeWallClockRate of the current device).
+extern "C" int32_t mpgan_debug_clock_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return -1;
+  return khz;
+}

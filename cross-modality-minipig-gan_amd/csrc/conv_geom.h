@@ -54,6 +54,7 @@ struct GatherConv {
   NormFold fold;         // consumer side: fold the producer's accumulators into the prologue's scale / shift
   BwdStats bwd;          // see above (part == null: off)
   int in_bf16, out_bf16; // thin (VALU) kernels of the bf16 path: `in` / `out` point at bf16 data (weights stay fp32)
+  MPGAN_STAMP_FIELD      // development builds only (mpgan_common.h)
   Phase ph[8];
 };
 

@@ -559,6 +559,8 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
   const int lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
+  MPGAN_STAMP(p, 0);
+  MPGAN_STAMP_VALUE(p, 6, 1);                 // kernel kind: K-stepped pipeline
   const BlockId bid = conv_block_id(p);
   const Phase ph = p.ph[bid.phase];
   const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
@@ -816,6 +818,7 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
     issue_loads(SX);        // tile 1 stays in flight into the first K-step
   }
   __syncthreads();
+  MPGAN_STAMP(p, 1);        // prologue done: first tile in LDS
 
   // One K-step: MFMAs on LDS buffer cb; under group 0 load tile kt+2 into `Sn`, under
   // group 3 write tile kt+1 (held by `Sp`) to the other buffer.  Loads past the last tile
@@ -881,7 +884,10 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
         __syncthreads();
       }
     }
+    MPGAN_STAMP(p, 2);      // K loop done
+    MPGAN_STAMP(p, 3);
     conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot, stats_row, FAST && m0 + BM > Mtot);
+    MPGAN_STAMP(p, 7);
   } else {
     // every group walks nk_per K-steps' worth of barriers; a group whose range is shorter idles at them
     for (int kt = 0; kt < nk_per; kt += 2) {
@@ -892,6 +898,7 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
         __syncthreads();
       }
     }
+    MPGAN_STAMP(p, 2);      // K loop done
     // fold the groups' sums into group 0 through LDS: [register][thread] floats, conflict-free
     float* red = lds_all;
     for (int g = 1; g < KS; ++g) {
@@ -914,7 +921,9 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
       }
       __syncthreads();
     }
+    MPGAN_STAMP(p, 3);      // in-block split-K fold done
     conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds_all, m0, n0, Mtot, stats_row, FAST && m0 + BM > Mtot, tid, kg == 0);
+    MPGAN_STAMP(p, 7);
   }
 }
 
@@ -2054,6 +2063,10 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   const int total = PH * PW * CQ;
   const FastDiv fPW = MERGE ? pl.fPWm : pl.fPW[0], fNx = MERGE ? pl.fKx : pl.fNx[0], fCout = pl.fCout;
   const Phase& ph0 = p.ph[0];
+  MPGAN_STAMP(p, 0);
+  MPGAN_STAMP_VALUE(p, 6, 2);                 // kernel kind: persistent patch
+  unsigned long long st_contract = 0, st_tail = 0, st_tiles = 0;
+  (void)st_contract; (void)st_tail; (void)st_tiles;
 
   // ---- weights: once per block ----
   {
@@ -2080,6 +2093,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
       }
     }
   }
+  MPGAN_STAMP(p, 1);                          // weights staged (their stores issued)
   if (folding) {   // BatchNorm of the producer, finalised here instead of by a launch of its own (norm_fold.h)
     fold_stats_block(p.fold, CIN, reinterpret_cast<long long*>(fold_sh + CIN), fold_sc, fold_sh, tid, 256, blockIdx.x == 0);
     if constexpr (PRO != 0) {
@@ -2176,7 +2190,9 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
     store_patch();
   }
   __syncthreads();
+  MPGAN_STAMP(p, 2);                          // first patch in LDS
   for (; t < ntiles; t += (int)gridDim.x) {
+    const unsigned long long st_a = MPGAN_STAMP_NOW();
     const int tn = t + (int)gridDim.x;
     int n, my0, mx0;
     decode(t, n, my0, mx0);
@@ -2316,6 +2332,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
         st[(wid * 2 + 1) * 32 + lane] = 0.f;
       }
     }
+    const unsigned long long st_b = MPGAN_STAMP_NOW();
     __syncthreads();                                  // every wave is done with the patch; statistics slots are complete
     if (want_stats && tid < Cout) {
       for (int phase = 0; phase < nph; ++phase) {
@@ -2338,7 +2355,14 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
     }
     if (tn < ntiles) store_patch();
     __syncthreads();
+    st_contract += st_b - st_a;
+    st_tail += MPGAN_STAMP_NOW() - st_b;
+    st_tiles += 1;
   }
+  MPGAN_STAMP_VALUE(p, 3, st_contract);       // sum over this block's tiles: contraction + epilogue stores issued
+  MPGAN_STAMP_VALUE(p, 4, st_tail);           // ... barrier, statistics rows, next patch's arrival + LDS stores, barrier
+  MPGAN_STAMP_VALUE(p, 5, st_tiles);
+  MPGAN_STAMP(p, 7);
   if (p.stats_acc && tid < Cout) {                   // one set of atomics per block, whatever its number of tiles
     long long* rep = p.stats_acc + (long)(blockIdx.x % (unsigned)p.acc_rep) * ACC_WORDS * Cout;
     acc_add(rep, Cout, 0, tid, tot_a);
@@ -2898,7 +2922,24 @@ static int launch_patch3d(const GatherConv& p, hipStream_t st) {
   return check_launch("gather_patch3d_c16");
 }
 
+#ifdef MPGAN_STAMPS
+static int launch_gather_impl(const GatherConv& p, hipStream_t st);
+static int launch_gather(const GatherConv& p0, hipStream_t st) {
+  GatherConv p = p0;
+  StampCtx& c = stamp_ctx();
+  p.stamps = nullptr;
+  p.stamp_blocks = 0;
+  if (c.base && c.next < c.launches) {
+    p.stamps = c.base + c.next * c.blocks * MPGAN_STAMP_SLOTS;
+    p.stamp_blocks = (int)c.blocks;
+    c.next += 1;
+  }
+  return launch_gather_impl(p, st);
+}
+static int launch_gather_impl(const GatherConv& p, hipStream_t st) {
+#else
 static int launch_gather(const GatherConv& p, hipStream_t st) {
+#endif
   const long maxM = max_phase_pixels(p);
   if (maxM == 0) return MPGAN_OK;
   MPGAN_CHECK_ARG((long)p.N * p.Do * p.Ho * p.Wo < (1L << 31) && (long)p.N * p.Di * p.Hi * p.Wi < (1L << 31) &&

@@ -608,6 +608,81 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// The same reduction for SMALL results (the generator's narrow layers: 16 x 144 ... 64 x 288 outputs, hundreds
+// of slabs): with 32 elements per block only total/32 (72 for a 16 -> 16 layer) blocks exist and every thread
+// walks 64 slabs.  Here a block takes 8 consecutive elements (one 32-byte sector per slab) x 32 split lanes:
+// four times the blocks, a quarter of the loads per thread, all of them independent.  Lane sums, then the 32
+// lanes, are added in a fixed order.  The trailing `bias_blocks` blocks do the fused bias gradient as above.
+__global__ __launch_bounds__(256) void wgrad_reduce_narrow_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                  int nsplit, int Cd, int Cg, int T, float beta,
+                                                                  const float* __restrict__ bp, int bsplit,
+                                                                  float* __restrict__ db, int bias_blocks) {
+  __shared__ float sh[32][9];
+  const int e = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const int main_blocks = (int)gridDim.x - bias_blocks;
+  if ((int)blockIdx.x >= main_blocks) {
+    const int c = ((int)blockIdx.x - main_blocks) * 8 + e;
+    float s = 0.f;
+    if (c < Cd)
+      for (int k = sl; k < bsplit; k += 32) s += bp[(long)k * Cd + c];
+    sh[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && c < Cd) {
+      float t = sh[0][e];
+#pragma unroll
+      for (int k = 1; k < 32; ++k) t += sh[k][e];
+      db[c] = beta != 0.f ? beta * db[c] + t : t;
+    }
+    return;
+  }
+  const long total = (long)Cd * Cg * T;
+  const long NC = (long)T * Cg;
+  const long i = (long)blockIdx.x * 8 + e;
+  float s = 0.f;
+  if (i < total) {
+    const float* src = partial + i;
+    int k = sl;
+    for (; k + 32 * 7 < nsplit; k += 32 * 8) {               // eight independent loads in flight
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + 32 * u) * total];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nsplit; k += 32) s += src[(long)k * total];
+  }
+  sh[sl][e] = s;
+  __syncthreads();
+  if (sl == 0 && i < total) {
+    float t = sh[0][e];
+#pragma unroll
+    for (int k = 1; k < 32; ++k) t += sh[k][e];
+    const long cd = i / NC;
+    const long rem = i - cd * NC;
+    const int tt = (int)(rem / Cg);
+    const int cg = (int)(rem - (long)tt * Cg);
+    const long o = (cd * Cg + cg) * T + tt;
+    dw[o] = beta != 0.f ? beta * dw[o] + t : t;
+  }
+}
+
+// One entry for both reducers: the narrow form when the wide one would leave most CUs idle.
+static inline void launch_wgrad_reduce(hipStream_t st, const float* partial, float* dw, int nsplit, int Cd, int Cg, int T,
+                                       float beta, const float* bp, int bsplit, float* db) {
+  const long total = (long)Cd * Cg * T;
+  if (total <= 32L * 512 && nsplit >= 64) {
+    const int blocks = (int)((total + 7) / 8), bb = db ? (Cd + 7) / 8 : 0;
+    hipLaunchKernelGGL(wgrad_reduce_narrow_kernel, dim3(blocks + bb), dim3(256), 0, st, partial, dw, nsplit, Cd, Cg, T, beta,
+                       bp, bsplit, db, bb);
+    return;
+  }
+  int blocks = (int)((total + 31) / 32);
+  if (blocks > 8192) blocks = 8192;
+  const int bb = db ? (Cd + 31) / 32 : 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + bb), dim3(256), 0, st, partial, dw, nsplit, Cd, Cg, T, beta, bp,
+                     bsplit, db, bb);
+}
+
 // db[c] += sum_split bias_partial[split][c]  (one wave per channel, fixed order)
 __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bp, int nsplit, int Cd,
                                                                 float* __restrict__ db, float beta) {
@@ -1123,19 +1198,23 @@ static WP2Plan wgrad_p2_plan(const mpgan_conv_geom* g) {
     if (S != 2 || g->out_dhw[1] != 2 * g->in_dhw[1] || g->out_dhw[2] != 2 * g->in_dhw[2]) return pl;
     Cd = g->cin; Cg = g->cout; My = g->in_dhw[1]; Mx = g->in_dhw[2];
   }
-  int inst = 0, tx = 16;
-  if (S == 1 && Cd == 16 && Cg == 16) inst = 1;
-  else if (S == 1 && Cd == 32 && Cg == 32) inst = 2;
-  else if (S == 2 && Cd == 32 && Cg == 16) inst = 3;
-  else if (S == 2 && Cd == 64 && Cg == 32) { inst = 4; tx = 8; }
-  else if (S == 2 && Cd == 64 && Cg == 16) { inst = 5; tx = 8; }
+  // Blocks are capped so that the slabs (Cd x 9 x Cg floats per block) stay within ~4.7 MB: the reducer's time is
+  // their traffic, and every block must still walk several tiles for the prefetch to pay.  32 -> 64 channels
+  // (72 KB slabs: 64 blocks) is left to the K-stepped kernel.
+  int inst = 0, tx = 16, cap = 512;
+  if (S == 1 && Cd == 16 && Cg == 16) { inst = 1; cap = 512; }
+  else if (S == 1 && Cd == 32 && Cg == 32) { inst = 2; cap = 128; }
+  else if (S == 2 && Cd == 32 && Cg == 16) { inst = 3; cap = 256; }
+  else if (S == 2 && Cd == 64 && Cg == 16) { inst = 5; tx = 8; cap = 128; }
+  static const int cap_env = getenv("MPGAN_DBG_WPATCH2D_BLOCKS") ? atoi(getenv("MPGAN_DBG_WPATCH2D_BLOCKS")) : 0;
+  if (cap_env > 0) cap = cap_env;
   if (!inst || My < 4 || Mx < 4) return pl;
   pl.tiles_y = (My + WP2_TY - 1) / WP2_TY;
   pl.tiles_x = (Mx + tx - 1) / tx;
   const long nt = (long)g->n * pl.tiles_y * pl.tiles_x;
   if (nt >= (1L << 31)) return pl;
   pl.ntiles = (int)nt;
-  pl.blocks = (int)(nt < 512 ? nt : 512);                      // two resident blocks per CU, each walking its range of tiles
+  pl.blocks = (int)(nt < cap ? nt : cap);                      // persistent blocks, each walking its range of tiles
   pl.inst = inst; pl.Cd = Cd; pl.Cg = Cg;
   return pl;
 }
@@ -1386,9 +1465,7 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
     else hipLaunchKernelGGL(wgrad_patch3d_c16_kernel<false>, dim3(nb), dim3(256), 0, st0, p, tg);
     int rcp = check_launch("wgrad_patch3d_c16");
     if (rcp) return rcp;
-    const int bbp = dbias ? 1 : 0;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((16 * 16 * 27 + 31) / 32 + bbp), dim3(256), 0, st0, p.partial, dw, nb, 16, 16,
-                       27, beta, p.bias_partial, nb, dbias, bbp);
+    launch_wgrad_reduce(st0, p.partial, dw, nb, 16, 16, 27, beta, p.bias_partial, nb, dbias);
     return check_launch("wgrad_patch3d_reduce");
   }
   {
@@ -1405,13 +1482,10 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
         case 1: rcp = launch_wgrad_p2<16, 16, 1, 16>(p, p2, st0); break;
         case 2: rcp = launch_wgrad_p2<32, 32, 1, 16>(p, p2, st0); break;
         case 3: rcp = launch_wgrad_p2<32, 16, 2, 16>(p, p2, st0); break;
-        case 4: rcp = launch_wgrad_p2<64, 32, 2, 8>(p, p2, st0); break;
         default: rcp = launch_wgrad_p2<64, 16, 2, 8>(p, p2, st0); break;
       }
       if (rcp) return rcp;
-      const int bbp = dbias ? (Cd + 31) / 32 : 0;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Cd * Cg * 9 + 31) / 32 + bbp), dim3(256), 0, st0, p.partial, dw, p2.blocks,
-                         Cd, Cg, 9, beta, p.bias_partial, p2.blocks, dbias, bbp);
+      launch_wgrad_reduce(st0, p.partial, dw, p2.blocks, Cd, Cg, 9, beta, p.bias_partial, p2.blocks, dbias);
       return check_launch("wgrad_patch2d_reduce");
     }
   }
@@ -1438,11 +1512,7 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
 #undef THIN_LAUNCH
       int rc0 = check_launch("thin_wgrad");
       if (rc0) return rc0;
-      const long total0 = (long)Cd * Cg * T;
-      int blocks0 = (int)((total0 + 31) / 32);
-      const int bb0 = dbias ? (Cd + 31) / 32 : 0;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks0 + bb0), dim3(256), 0, st0, p.partial, dw, tp.blocks, Cd, Cg,
-                         T, beta, p.bias_partial, tp.blocks, dbias, bb0);
+      launch_wgrad_reduce(st0, p.partial, dw, tp.blocks, Cd, Cg, T, beta, p.bias_partial, tp.blocks, dbias);
       return check_launch("thin_wgrad_reduce");
     }
   }
@@ -1470,12 +1540,7 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
   else if (vg) rc = dispatch_wgrad<true, false>(p, pl, st);
   else rc = dispatch_wgrad<true, true>(p, pl, st);
   if (rc) return rc;
-  const long total = (long)Cd * Cg * T;
-  int blocks = (int)((total + 31) / 32);
-  if (blocks > 8192) blocks = 8192;
-  const int bb = dbias ? (Cd + 31) / 32 : 0;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + bb), dim3(256), 0, st, p.partial, dw, pl.nsplit * pl.kw, Cd, Cg,
-                     T, beta, p.bias_partial, pl.nsplit, dbias, bb);
+  launch_wgrad_reduce(st, p.partial, dw, pl.nsplit * pl.kw, Cd, Cg, T, beta, p.bias_partial, pl.nsplit, dbias);
   return check_launch("wgrad_reduce");
 }
 

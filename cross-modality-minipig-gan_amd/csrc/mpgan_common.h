@@ -124,6 +124,35 @@ __device__ __forceinline__ void fdivmod(unsigned n, const FastDiv& f, unsigned& 
   r = n - q * f.d;
 }
 
+// ---- in-kernel phase stamps (development builds only: `make STAMPS=1` -> libmpgan_hip_stamps.so) ----------
+// With -DMPGAN_STAMPS every gather-conv launch gets a slice [blocks][MPGAN_STAMP_SLOTS] of a caller-supplied
+// device buffer (mpgan_debug_stamps) and thread 0 of each block records the 100 MHz constant clock
+// (s_memrealtime: the same time base on every CU) at its phase boundaries: what the in-kernel fixed cost of the
+// generator's short kernels consists of is then MEASURED (tools/kernel_phases.py), not inferred from what-if
+// builds.  In the product build the macros expand to nothing and GatherConv has no such field.
+constexpr int MPGAN_STAMP_SLOTS = 8;
+#ifdef MPGAN_STAMPS
+struct StampCtx { unsigned long long* base; long launches, blocks; long next; };
+StampCtx& stamp_ctx();                      // host side (capi.cpp)
+#define MPGAN_STAMP_FIELD unsigned long long* stamps; int stamp_blocks;
+#define MPGAN_STAMP(p, slot)                                                                         \
+  do {                                                                                               \
+    if ((p).stamps && threadIdx.x == 0 && (int)blockIdx.x < (p).stamp_blocks)                        \
+      (p).stamps[(long)blockIdx.x * MPGAN_STAMP_SLOTS + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define MPGAN_STAMP_VALUE(p, slot, v)                                                                \
+  do {                                                                                               \
+    if ((p).stamps && threadIdx.x == 0 && (int)blockIdx.x < (p).stamp_blocks)                        \
+      (p).stamps[(long)blockIdx.x * MPGAN_STAMP_SLOTS + (slot)] = (unsigned long long)(v);          \
+  } while (0)
+#define MPGAN_STAMP_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define MPGAN_STAMP_FIELD
+#define MPGAN_STAMP(p, slot) ((void)0)
+#define MPGAN_STAMP_VALUE(p, slot, v) ((void)0)
+#define MPGAN_STAMP_NOW() 0ull
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -713,7 +713,7 @@ def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod,
     prog.add("norm_finalize", lib().mpgan_norm_finalize_strided, partials.data_ptr(), 1, rows, c, W, n * P, 0,
              _p(norm_mod.weight), _p(norm_mod.bias), float(norm_mod.eps), float(norm_mod.momentum), _p(rm), _p(rv),
              _p(nbt), nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
-             keep=(norm_mod.weight, norm_mod.bias, rm, rv, nbt, nb, partials))
+             keep=(norm_mod.weight, norm_mod.bias, rm, rv, nbt, nb, partials), desc=f"C{c} rows{rows}")
 
 
 def emit_eval_norms(prog, eval_norms, dev):
@@ -742,7 +742,7 @@ def emit_norm_act_add(prog, z, pz, r, pr, out, tanh=False, fold=None):
     if fold is None:
         prog.add("norm_act_add", lib().mpgan_norm_act_add, z.data_ptr(), ldz, C.byref(pzc) if pzc else None, _p(r),
                  _ld(r), C.byref(prc) if prc else None, n, P, z.shape[-1], int(tanh), out.data_ptr(), _ld(out),
-                 keep=(z, pzc, pz, r, prc, pr, out))
+                 keep=(z, pzc, pz, r, prc, pr, out), desc=f"C{z.shape[-1]} n{n} P{P}")
         return
     prog.add("norm_act_add_fold", lib().mpgan_norm_act_add_fold, z.data_ptr(), ldz, C.byref(pzc), C.byref(fold), _p(r),
              _ld(r), C.byref(prc) if prc else None, n, P, z.shape[-1], int(tanh), out.data_ptr(), _ld(out),
@@ -769,16 +769,17 @@ def emit_norm_bwd(prog, g, z, nb: NormBuf, pro: Prologue, dz, partials, dgamma, 
                  _p(dgamma), _p(dbeta), _p(dslope), nb.c1.data_ptr(), nb.c2.data_ptr(), keep=(dgamma, dbeta, dslope))
         prog.add("norm_bwd_apply", L.mpgan_norm_bwd_apply, g.data_ptr(), _ld(g), z.data_ptr(), ldz, C.byref(pc),
                  nb.mean.data_ptr(), nb.invstd.data_ptr(), nb.c1.data_ptr(), nb.c2.data_ptr(), pe_ref, n, P, c,
-                 dz.data_ptr(), _ld(dz), keep=(dz, g, z, pc, pro, nb, partials))
+                 dz.data_ptr(), _ld(dz), keep=(dz, g, z, pc, pro, nb, partials), desc=f"C{c} n{n} P{P}")
         return
     prog.add("norm_bwd_reduce", L.mpgan_norm_bwd_reduce, g.data_ptr(), _ld(g), z.data_ptr(), ldz, C.byref(pc),
              nb.mean.data_ptr(), nb.invstd.data_ptr(), pe_ref, n, P, c, partials.data_ptr(),
-             keep=(g, z, pc, pro, nb, partials, pe, peer))
+             keep=(g, z, pc, pro, nb, partials, pe, peer), desc=f"C{c} n{n} P{P}")
     prog.add("norm_bwd_finalize", L.mpgan_norm_bwd_finalize, partials.data_ptr(), n, chunks, c, P, int(nb.instance),
-             _p(dgamma), _p(dbeta), _p(dslope), nb.c1.data_ptr(), nb.c2.data_ptr(), keep=(dgamma, dbeta, dslope))
+             _p(dgamma), _p(dbeta), _p(dslope), nb.c1.data_ptr(), nb.c2.data_ptr(), keep=(dgamma, dbeta, dslope),
+             desc=f"C{c} rows{n * chunks}")
     prog.add("norm_bwd_apply", L.mpgan_norm_bwd_apply, g.data_ptr(), _ld(g), z.data_ptr(), ldz, C.byref(pc),
              nb.mean.data_ptr(), nb.invstd.data_ptr(), nb.c1.data_ptr(), nb.c2.data_ptr(), pe_ref, n, P, c,
-             dz.data_ptr(), _ld(dz), keep=(dz,))
+             dz.data_ptr(), _ld(dz), keep=(dz,), desc=f"C{c} n{n} P{P}")
 
 
 def _t3(v, dims, fill):

@@ -459,7 +459,10 @@ def test_parameter_writes_after_a_forward_reach_the_packed_weights():
                 if net is ref:
                     g_ref = g_first
                 else:
-                    assert_close(g_first, g_ref, rtol=2e-3, what="head weight gradient on the second step")
+                    # (a gradient left over from the first step would double it; the two sides' weights differ by
+                    #  Adam's +-lr sign noise on near-zero gradients after step one, hence L2 and not elementwise)
+                    rel = ((g_first.double() - g_ref.double()).norm() / g_ref.double().norm()).item()
+                    assert rel <= 2e-2, ("head weight gradient on the second step", rel)
             opt.step()
     with torch.no_grad():
         p_r, p_o = ref(xc), ours(x).cpu()

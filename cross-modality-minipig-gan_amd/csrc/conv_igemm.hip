@@ -61,6 +61,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
     rowpix[tid] = pix;
   }
   __syncthreads();
+  MPGAN_STAMP(p, 4);    // epilogue: row -> pixel map ready
   if (p.ksplit > 1) {   // split-K: raw partial sums, reduced (with bias) by splitk_reduce_kernel
     float* part = p.kpartial + (long)ksplit_id * ((long)p.N * p.Do * p.Ho * p.Wo) * Cout;
     if (active)
@@ -148,6 +149,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
       }
     }
   }
+  MPGAN_STAMP(p, 5);    // epilogue: output stores issued
   if (bw) {
     // the two half-waves (shuffle), then the WM waves sharing a column range (LDS, fixed order): no atomics
     constexpr int WMB = 4 / WN;
@@ -2018,7 +2020,10 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int CQ = CIN / 4;
   constexpr int LU = CIN == 16 ? 9 : 12;      // patch chunks per thread: the WHOLE patch of a tile in one round (host checks)
-  constexpr int WU = 4;
+  // weight chunks per thread and trip: ALL of a 3x3 layer's weights in one round of loads (32 -> 32: 2304 chunks = 9
+  // per thread; with 4 per trip the block spent three dependent round trips -- 8.6 us measured by the phase stamps,
+  // 37 % of its life -- before its first MFMA)
+  constexpr int WU = 12;
   // LDS pitches (floats per pixel / per weight row), chosen by the host so that the fragments' ds_read_b128 are
   // conflict-free: CIN + 8 for the 16x16x4 form (CIN + 4 cost 61 % of the LDS cycles in bank conflicts there,
   // rocprofv3 SQ_LDS_BANK_CONFLICT), CIN + 4 for the 32x32x2 form.
@@ -2068,14 +2073,16 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   unsigned long long st_contract = 0, st_tail = 0, st_tiles = 0;
   (void)st_contract; (void)st_tail; (void)st_tiles;
 
-  // ---- weights: once per block ----
-  {
+  // ---- weights: once per block.  Staged BEHIND the first patch's loads (stage_weights() is called once they
+  //      are in flight): the block's two cold round trips -- weights, first patch -- overlap instead of adding up ----
+  auto stage_weights = [&]() {
     const int wtotal = sntaps * Cout * CQ;
     const int Ktot = p.Kz * p.Ky * p.Kx * CIN;
     for (int base = 0; base < wtotal; base += 256 * WU) {
       float4 wv[WU];
 #pragma unroll
       for (int u = 0; u < WU; ++u) {
+        if (base + u * 256 >= wtotal) break;               // block-uniform: no loads for slots past the weights
         const int idx = base + u * 256 + tid;
         const unsigned row = idx < wtotal ? (unsigned)idx / (unsigned)CQ : 0u;
         unsigned t, co, jy, jx;
@@ -2088,12 +2095,12 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
       }
 #pragma unroll
       for (int u = 0; u < WU; ++u) {
+        if (base + u * 256 >= wtotal) break;
         const int idx = base + u * 256 + tid;
         if (idx < wtotal) *reinterpret_cast<float4*>(wl + (idx / CQ) * PCW + 4 * cq) = wv[u];
       }
     }
-  }
-  MPGAN_STAMP(p, 1);                          // weights staged (their stores issued)
+  };
   if (folding) {   // BatchNorm of the producer, finalised here instead of by a launch of its own (norm_fold.h)
     fold_stats_block(p.fold, CIN, reinterpret_cast<long long*>(fold_sh + CIN), fold_sc, fold_sh, tid, 256, blockIdx.x == 0);
     if constexpr (PRO != 0) {
@@ -2121,7 +2128,6 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   const float* zero4 = reinterpret_cast<const float*>(pl.zero_page);   // 16 bytes of zeros in global memory
   float4 pv[LU];
   unsigned pok = 0;
-  int ln = 0;                                         // sample of the tile held in pv (per-sample prologue vectors)
   auto decode = [&](int t, int& n, int& my0, int& mx0) {
     unsigned q, tx, ty, nn;
     fdivmod((unsigned)t, pl.fTx, q, tx);
@@ -2130,12 +2136,18 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
     mx0 = (int)tx * PT_W;
     n = (int)nn;
   };
+  float4 scn = sc, shn = sh;                          // prologue vectors of the tile held in pv (loaded WITH its patch)
   auto load_patch = [&](int t) {
     int n, my0, mx0;
     decode(t, n, my0, mx0);
-    ln = n;
     const int y0 = my0 * isy + ylo, x0 = mx0 * isx + xlo;
     const float* __restrict__ gin = p.in + (long)n * Hi * Wi * ldi + 4 * cq;
+    if constexpr (PRO != 0) {
+      if (!folding) {
+        scn = *reinterpret_cast<const float4*>(p.pro.scale + (long)n * p.pro.n_stride + 4 * cq);
+        shn = *reinterpret_cast<const float4*>(p.pro.shift + (long)n * p.pro.n_stride + 4 * cq);
+      }
+    }
     pok = 0;
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
@@ -2150,10 +2162,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   };
   auto store_patch = [&]() {
     if constexpr (PRO != 0) {
-      if (!folding) {
-        sc = *reinterpret_cast<const float4*>(p.pro.scale + (long)ln * p.pro.n_stride + 4 * cq);
-        sh = *reinterpret_cast<const float4*>(p.pro.shift + (long)ln * p.pro.n_stride + 4 * cq);
-      }
+      if (!folding) { sc = scn; sh = shn; }
     }
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
@@ -2185,10 +2194,10 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
     for (int i = 0; i < rounds * pl.stagger; ++i) __builtin_amdgcn_s_sleep(1);
   }
   int t = (int)blockIdx.x;
-  if (t < ntiles) {
-    load_patch(t);
-    store_patch();
-  }
+  if (t < ntiles) load_patch(t);              // in flight while the weights are fetched and staged
+  stage_weights();
+  MPGAN_STAMP(p, 1);                          // weights staged (their stores issued)
+  if (t < ntiles) store_patch();
   __syncthreads();
   MPGAN_STAMP(p, 2);                          // first patch in LDS
   for (; t < ntiles; t += (int)gridDim.x) {

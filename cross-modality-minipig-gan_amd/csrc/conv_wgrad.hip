@@ -15,6 +15,7 @@
 // ds_read_b32 with no transposition.
 #include "mpgan_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace mpgan {
 
@@ -1047,15 +1048,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch2d_kernel(const WgradParams
     for (int b = 0; b < K::CB; ++b)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[u][b][i] = 0.f;
-  // this wave's units: (tap, dense block) -> LDS offsets (wave-uniform)
-  int aoff[K::NU], boff[K::NU];
+  // This wave's units: idx = wid + 4 u -> (tap = idx / CA, dense block ca = idx % CA).  4 % CA == 0, so ca = wid % CA
+  // is the SAME for all of a wave's units: one A read per pixel step serves them all.  Per-lane LDS bases (floats):
+  // lane (ln, g) reads A[row = cd = 16 ca + ln][k = pixel 4 j + g] and B[k][col = cg = 16 b + ln] at the tap's shift.
+  static_assert(4 % K::CA == 0, "a wave's units must share their dense block");
+  const int nvalid = (K::NUNITS - wid + 3) / 4;                 // units this wave really owns (NU or NU - 1)
+  int a_base = g * K::PDP + ln + 16 * (wid % K::CA);
+  int b_base[K::NU];
 #pragma unroll
   for (int u = 0; u < K::NU; ++u) {
     const int idx = wid + 4 * u;
-    const int tap = idx / K::CA, ca = idx - tap * K::CA;
+    const int tap = (idx < K::NUNITS ? idx : wid) / K::CA;      // a unit past the end re-reads a valid one (never run)
     const int ky = tap / 3, kx = tap - 3 * ky;
-    aoff[u] = 16 * ca;
-    boff[u] = (ky * K::PX + kx) * K::PGP;
+    b_base[u] = (ky * K::PX + kx) * K::PGP + g * S * K::PGP + ln;
   }
   // gathered patch: this thread's chunks (tile-independent decode); dense tile: its chunks
   const int gq = tid % K::GQ, dq = tid % K::DQ;
@@ -1135,22 +1140,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch2d_kernel(const WgradParams
     store_tile();
     __syncthreads();
     if (tt + 1 < wend) load_tile(tt + 1);                       // in flight under this tile's contraction
-    // ---- contraction over the tile's pixels, four at a time: k = pixel 4 j + g ----
-#pragma unroll 2
-    for (int j = 0; j < K::TP / 4; ++j) {
-      const int q = 4 * j + g;
-      const float* arow = dyt + q * K::PDP + ln;                 // A[row = cd][k] of dense block 0
-      const float* brow = patch + ((q / TX) * S * K::PX + (q % TX) * S) * K::PGP + ln;   // B[k][col = cg] at tap (0, 0)
+    // ---- contraction over the tile's pixels, four at a time: k = pixel 4 j + g.  Fully unrolled and branch-free:
+    //      pixel step j sits at row j / (TX / 4), columns 4 (j % (TX / 4)) + g of the tile, so every LDS address is
+    //      "per-lane base + compile-time offset" and the reads of later steps are issued under the MFMAs of earlier
+    //      ones (a wave-uniform test per unit inside this loop put every MFMA into a basic block of its own, behind
+    //      its own two LDS round trips: 36 us for the 16 -> 16 layer instead of 15).  A wave owns NU or NU - 1 units.
+    auto contract = [&](auto nv_tag) {
+      constexpr int NV = decltype(nv_tag)::value;
 #pragma unroll
-      for (int u = 0; u < K::NU; ++u) {
-        if (wid + 4 * u < K::NUNITS) {                          // wave-uniform
-          const float a = arow[aoff[u]];
+      for (int j = 0; j < K::TP / 4; ++j) {
+        constexpr int JR = TX / 4;
+        const int poff = ((j / JR) * S * K::PX + (j % JR) * 4 * S) * K::PGP;      // compile-time after unrolling
+        const float a = dyt[a_base + 4 * j * K::PDP];
+#pragma unroll
+        for (int u = 0; u < NV; ++u)
 #pragma unroll
           for (int b = 0; b < K::CB; ++b)
-            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[boff[u] + 16 * b], acc[u][b], 0, 0, 0);
-        }
+            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, patch[b_base[u] + poff + 16 * b], acc[u][b], 0, 0, 0);
       }
-    }
+    };
+    if (nvalid == K::NU) contract(std::integral_constant<int, K::NU>{});
+    else contract(std::integral_constant<int, (K::NU > 1 ? K::NU - 1 : 1)>{});
   }
   // ---- D[row = cd = 16 ca + 4 g + i][col = cg = 16 b + ln] -> partial[block][cd][tap * CG + cg] ----
   float* out = p.partial + (long)blockIdx.x * CD * 9 * CG;

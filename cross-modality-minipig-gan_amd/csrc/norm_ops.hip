@@ -11,9 +11,19 @@
 
 namespace mpgan {
 
-static inline int stats_chunks_host(long pixels_per_sample) {
-  // >= 256 rows per chunk: these passes are latency-bound per block, so they want ~4 blocks per CU
-  long c = pixels_per_sample / 256;
+static inline int stats_chunks_host(long pixels_per_sample, int C = 0) {
+  // These passes are latency-bound per block: a chunk is FOUR passes of the block's R = 256 / (C / 4) rows, so every
+  // thread issues four independent row loads and a 128-channel map at 32^2 still makes 512 blocks (256 rows per
+  // chunk whatever C left it with 64 blocks walking 32 dependent passes each: 28 us for a 2 MB tensor).
+  long rows = 256;
+  if (C >= 4 && C % 4 == 0) {
+    long R = 256 / (C / 4);
+    if (R < 1) R = 1;
+    rows = 4 * R;
+    if (rows > 256) rows = 256;
+    if (rows < 16) rows = 16;
+  }
+  long c = pixels_per_sample / rows;
   if (c < 1) c = 1;
   if (c > 256) c = 256;
   return (int)c;
@@ -49,6 +59,36 @@ struct ReduceGeom {
   int chunks;
 };
 
+// Fixed-order sum over the R row slots of red[R][W] (W = NQ * C values per row) into out[W].  With W <= 128 all
+// 256 threads take part: G = 256 / W groups each fold rows gq, gq + G, ..., then the G group sums are added in
+// order (a 16-channel layer had 48 threads walking 64 rows one after another: the tail of every block).
+__device__ __forceinline__ void fold_rows(float* red, int R, int W, float* __restrict__ out) {
+  const int tid = threadIdx.x;
+  const int G = 256 / W;
+  if (G >= 2 && R >= 2 * G) {
+    const int i = tid % W, gq = tid / W;
+    float s = 0.f;
+    if (gq < G)
+      for (int rr = gq; rr < R; rr += G) s += red[rr * W + i];
+    __syncthreads();                       // every row slot has been read
+    if (gq < G) red[gq * W + i] = s;
+    __syncthreads();
+    if (tid < W) {
+      float t = red[tid];
+      for (int k = 1; k < G; ++k) t += red[k * W + tid];
+      out[tid] = t;
+      red[tid] = t;                        // (only this thread reads column tid: the result may stay in row slot 0)
+    }
+    return;
+  }
+  for (int i = tid; i < W; i += 256) {
+    float s = 0.f;
+    for (int rr = 0; rr < R; ++rr) s += red[rr * W + i];
+    out[i] = s;
+    red[i] = s;
+  }
+}
+
 template <int V, int NQ, class F>
 __device__ __forceinline__ void chunk_reduce(const ReduceGeom& g, float* partials, F f) {
   extern __shared__ float red[];  // [R][NQ][C]
@@ -71,13 +111,7 @@ __device__ __forceinline__ void chunk_reduce(const ReduceGeom& g, float* partial
       for (int e = 0; e < V; ++e) red[(r * NQ + a) * g.C + q * V + e] = acc[a][e];
   }
   __syncthreads();
-  // fixed-order sum over the R rows
-  float* out = partials + ((long)n * g.chunks + chunk) * NQ * g.C;
-  for (int i = tid; i < NQ * g.C; i += blockDim.x) {
-    float s = 0.f;
-    for (int rr = 0; rr < g.R; ++rr) s += red[rr * NQ * g.C + i];
-    out[i] = s;
-  }
+  fold_rows(red, g.R, NQ * g.C, partials + ((long)n * g.chunks + chunk) * NQ * g.C);
 }
 
 template <int V>
@@ -130,29 +164,40 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
       psc[e] = pr.coef ? pr.scale[c + e] : 0.f;
       psh[e] = pr.coef ? pr.shift[c + e] : 0.f;
     }
-    for (long pix = beg + r; pix < end; pix += g.R) {
-      const long row = (long)n * g.P + pix;
-      float zv[V], gv[V], zp[V];
-      Vec<V>::load(z + row * ldz + c, zv);
-      Vec<V>::load(gr + row * ldg + c, gv);
-      if (pr.coef) Vec<V>::load(pr.z + row * pr.ld + c, zp);
+    // four rows per trip, their loads issued together (the sums still run in pixel order)
+    for (long pix0 = beg + r; pix0 < end; pix0 += 4L * g.R) {
+      float zv[4][V], gv[4][V], zp[4][V];
+      bool ok[4];
 #pragma unroll
-      for (int e = 0; e < V; ++e) {
-        const float y = zv[e] * sc[e] + sh[e];
-        const float zh = (zv[e] - mu[e]) * is[e];
-        float ga = gv[e], gy_extra = 0.f;
-        if (pr.coef) {
-          const float yp = zp[e] * psc[e] + psh[e];
-          const float ap = (leaky && yp < 0.f) ? yp * slope : yp;
-          const float a = (leaky && y < 0.f) ? y * slope : y;
-          ga -= ca * sgn(ap - a);
-          gy_extra = -cy * sgn(yp - y);
+      for (int u = 0; u < 4; ++u) {
+        const long pix = pix0 + (long)u * g.R;
+        ok[u] = pix < end;
+        const long row = (long)n * g.P + (ok[u] ? pix : pix0);
+        Vec<V>::load(z + row * ldz + c, zv[u]);
+        Vec<V>::load(gr + row * ldg + c, gv[u]);
+        if (pr.coef) Vec<V>::load(pr.z + row * pr.ld + c, zp[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float y = zv[u][e] * sc[e] + sh[e];
+          const float zh = (zv[u][e] - mu[e]) * is[e];
+          float ga = gv[u][e], gy_extra = 0.f;
+          if (pr.coef) {
+            const float yp = zp[u][e] * psc[e] + psh[e];
+            const float ap = (leaky && yp < 0.f) ? yp * slope : yp;
+            const float a = (leaky && y < 0.f) ? y * slope : y;
+            ga -= ca * sgn(ap - a);
+            gy_extra = -cy * sgn(yp - y);
+          }
+          const bool neg = leaky && y < 0.f;
+          const float gy = (neg ? ga * slope : ga) + gy_extra;
+          acc[0][e] += gy;
+          acc[1][e] += gy * zh;
+          acc[2][e] += neg ? ga * y : 0.f;
         }
-        const bool neg = leaky && y < 0.f;
-        const float gy = (neg ? ga * slope : ga) + gy_extra;
-        acc[0][e] += gy;
-        acc[1][e] += gy * zh;
-        acc[2][e] += neg ? ga * y : 0.f;
       }
     }
 #pragma unroll
@@ -161,11 +206,16 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
       for (int e = 0; e < V; ++e) red[(r * 3 + a) * g.C + c + e] = acc[a][e];
   }
   __syncthreads();
-  float* out = partials + ((long)n * g.chunks + chunk) * 3 * g.C;
-  for (int i = tid; i < 3 * g.C; i += blockDim.x) {
-    float sm = 0.f;
-    for (int rr = 0; rr < g.R; ++rr) sm += red[rr * 3 * g.C + i];
-    out[i] = sm;
+  const long rowi = (long)n * g.chunks + chunk;
+  fold_rows(red, g.R, 3 * g.C, partials + rowi * 3 * g.C);
+  // PReLU-slope gradient: this row's third sums added over the CHANNELS, one scalar per row behind all the rows --
+  // the finalize then adds rows scalars instead of rows x C values in its one slope block (C = 128: 28 us -> 4)
+  __syncthreads();
+  if (tid < 64) {
+    float t = 0.f;
+    for (int j = tid; j < g.C; j += 64) t += red[2 * g.C + j];
+    t = wave_sum(t);
+    if (tid == 0) partials[(long)gridDim.x * gridDim.y * 3 * g.C + rowi] = t;
   }
   (void)cz;
 }
@@ -292,46 +342,23 @@ __global__ __launch_bounds__(256) void partials_compact_kernel(const float* __re
   if (w == 0 && c < W) compact[(long)g * W + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
-// PReLU-slope gradient: the sum of the third partial over every row and channel, by ONE block, formed directly
-// from the rows (a few thousand values for the U-Net's layers) -- no per-channel hand-off, hence no second launch.
-// Rows are [3][C]; with C % 4 == 0 the third section is read as float4 (16-byte aligned: 3*C*4*r + 2*C*4), so a
-// 1024-row x 16-channel layer is 16 independent loads per thread instead of 64.
+// PReLU-slope gradient: the sum of the third partial over every row and channel, by ONE block.  norm_bwd_reduce
+// leaves each row's sum over the channels as one scalar behind the rows (partials[rows * 3 * C + row]), so this
+// is a sum of `rows` floats -- no per-channel hand-off, hence no second launch.
 __device__ __forceinline__ void slope_grad_block(const float* __restrict__ partials, int rows, int C, float* dslope) {
   __shared__ double red[256];
+  const float* __restrict__ sc = partials + (long)rows * 3 * C;
   double s = 0.0;
   const int t = (int)threadIdx.x;
-  if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(partials) & 15) == 0) {
-    const int cq = C >> 2;                                 // float4 per row
-    const long total = (long)rows * cq;
-    for (long i = t; i < total; i += 256 * 8) {
-      float4 v[8];
+  for (int i = t; i < rows; i += 256 * 8) {
+    float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const long e = i + 256L * u;
-        if (e < total) {
-          const long r = e / cq;
-          const int q = (int)(e - r * cq);
-          v[u] = *reinterpret_cast<const float4*>(partials + r * 3 * C + 2 * C + 4 * q);
-        } else {
-          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
+    for (int u = 0; u < 8; ++u) {
+      const int e = i + 256 * u;
+      v[u] = e < rows ? sc[e] : 0.f;
     }
-  } else {
-    const long total = (long)rows * C;
-    for (long i = t; i < total; i += 256 * 8) {
-      float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const long e = i + 256L * u;
-        const long r = e / C;
-        v[u] = e < total ? partials[r * 3 * C + 2 * C + (e - r * C)] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += (double)v[u];
-    }
+    for (int u = 0; u < 8; ++u) s += (double)v[u];
   }
   red[t] = s;
   __syncthreads();
@@ -483,23 +510,36 @@ __global__ __launch_bounds__(256) void norm_act_add_kernel(const float* __restri
     rsc[e] = pr.scale ? pr.scale[n * pr.n_stride + c + e] : 1.f;
     rsh[e] = pr.scale ? pr.shift[n * pr.n_stride + c + e] : 0.f;
   }
-  for (long pix = (long)blockIdx.x * R + rr; pix < P; pix += (long)gridDim.x * R) {
-    const long row = (long)n * P + pix;
-    float v[V], o[V];
-    Vec<V>::load(z + row * ldz + c, v);
+  // four rows per trip with their loads issued together: these passes are latency-bound per thread
+  const long stride = (long)gridDim.x * R;
+  for (long pix0 = (long)blockIdx.x * R + rr; pix0 < P; pix0 += 4 * stride) {
+    float v[4][V], rv[4][V];
+    bool ok[4];
 #pragma unroll
-    for (int e = 0; e < V; ++e) o[e] = pz.scale ? act_apply(v[e] * zsc[e] + zsh[e], pz.act, sz) : v[e];
-    if (r) {
-      float rv[V];
-      Vec<V>::load(r + row * ldr + c, rv);
-#pragma unroll
-      for (int e = 0; e < V; ++e) o[e] += pr.scale ? act_apply(rv[e] * rsc[e] + rsh[e], pr.act, sr) : rv[e];
+    for (int u = 0; u < 4; ++u) {
+      const long pix = pix0 + u * stride;
+      ok[u] = pix < P;
+      const long row = (long)n * P + (ok[u] ? pix : pix0);
+      Vec<V>::load(z + row * ldz + c, v[u]);
+      if (r) Vec<V>::load(r + row * ldr + c, rv[u]);
     }
-    if (tanh_out) {
 #pragma unroll
-      for (int e = 0; e < V; ++e) o[e] = tanhf(o[e]);
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      const long row = (long)n * P + pix0 + u * stride;
+      float o[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] = pz.scale ? act_apply(v[u][e] * zsc[e] + zsh[e], pz.act, sz) : v[u][e];
+      if (r) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] += pr.scale ? act_apply(rv[u][e] * rsc[e] + rsh[e], pr.act, sr) : rv[u][e];
+      }
+      if (tanh_out) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = tanhf(o[e]);
+      }
+      Vec<V>::store(out + row * ldo + c, o);
     }
-    Vec<V>::store(out + row * ldo + c, o);
   }
   (void)rows;
 }
@@ -531,29 +571,44 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* gr, in
     psc[e] = pr.coef ? pr.scale[c + e] : 0.f;
     psh[e] = pr.coef ? pr.shift[c + e] : 0.f;
   }
-  for (long pix = (long)blockIdx.x * R + r; pix < P; pix += (long)gridDim.x * R) {
-    const long row = (long)n * P + pix;
-    float zv[V], gv[V], zp[V], o[V];
-    Vec<V>::load(z + row * ldz + c, zv);
-    Vec<V>::load(gr + row * ldg + c, gv);
-    if (pr.coef) Vec<V>::load(pr.z + row * pr.ld + c, zp);
+  // four rows per trip, all their loads in front of the first store (gr and dz may alias: a row is read in full
+  // before it is written, and no thread touches another thread's rows)
+  const long stride = (long)gridDim.x * R;
+  for (long pix0 = (long)blockIdx.x * R + r; pix0 < P; pix0 += 4 * stride) {
+    float zv[4][V], gv[4][V], zp[4][V];
+    bool ok[4];
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      const float y = zv[e] * sc[e] + sh[e];
-      const float zh = (zv[e] - mu[e]) * is[e];
-      float ga = gv[e], gy_extra = 0.f, dz_extra = 0.f;
-      if (pr.coef) {
-        const float yp = zp[e] * psc[e] + psh[e];
-        const float ap = (leaky && yp < 0.f) ? yp * slope : yp;
-        const float a = (leaky && y < 0.f) ? y * slope : y;
-        ga -= ca * sgn(ap - a);
-        gy_extra = -cy * sgn(yp - y);
-        dz_extra = -cz * sgn(zp[e] - zv[e]);
-      }
-      const float gy = ((leaky && y < 0.f) ? ga * slope : ga) + gy_extra;
-      o[e] = sc[e] * (gy - k1[e] - zh * k2[e]) + dz_extra;
+    for (int u = 0; u < 4; ++u) {
+      const long pix = pix0 + u * stride;
+      ok[u] = pix < P;
+      const long row = (long)n * P + (ok[u] ? pix : pix0);
+      Vec<V>::load(z + row * ldz + c, zv[u]);
+      Vec<V>::load(gr + row * ldg + c, gv[u]);
+      if (pr.coef) Vec<V>::load(pr.z + row * pr.ld + c, zp[u]);
     }
-    Vec<V>::store(dz + row * lddz + c, o);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      const long row = (long)n * P + pix0 + u * stride;
+      float o[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float y = zv[u][e] * sc[e] + sh[e];
+        const float zh = (zv[u][e] - mu[e]) * is[e];
+        float ga = gv[u][e], gy_extra = 0.f, dz_extra = 0.f;
+        if (pr.coef) {
+          const float yp = zp[u][e] * psc[e] + psh[e];
+          const float ap = (leaky && yp < 0.f) ? yp * slope : yp;
+          const float a = (leaky && y < 0.f) ? y * slope : y;
+          ga -= ca * sgn(ap - a);
+          gy_extra = -cy * sgn(yp - y);
+          dz_extra = -cz * sgn(zp[u][e] - zv[u][e]);
+        }
+        const float gy = ((leaky && y < 0.f) ? ga * slope : ga) + gy_extra;
+        o[e] = sc[e] * (gy - k1[e] - zh * k2[e]) + dz_extra;
+      }
+      Vec<V>::store(dz + row * lddz + c, o);
+    }
   }
   (void)rows;
 }
@@ -633,7 +688,7 @@ static int make_reduce_geom(ReduceGeom& g, int C, long P, bool vec, const char* 
   MPGAN_UNSUPPORTED(g.CG > 256, "%s: C=%d too wide", what, C);
   g.R = 256 / g.CG;
   g.P = P;
-  g.chunks = stats_chunks_host(P);
+  g.chunks = stats_chunks_host(P, C);
   return MPGAN_OK;
 }
 
@@ -648,7 +703,7 @@ static inline int ew_blocks(long total) {
 
 using namespace mpgan;
 
-extern "C" int32_t mpgan_stats_chunks(int64_t pixels_per_sample, int32_t) { return stats_chunks_host(pixels_per_sample); }
+extern "C" int32_t mpgan_stats_chunks(int64_t pixels_per_sample, int32_t c) { return stats_chunks_host(pixels_per_sample, c); }
 
 extern "C" int mpgan_channel_stats(const float* z, int32_t ldz, int32_t n, int64_t P, int32_t c, float* partials,
                                    void* stream) {
@@ -717,7 +772,7 @@ extern "C" int mpgan_norm_act_add(const float* z, int32_t ldz, const mpgan_prolo
   const int CGa = vec ? c / 4 : c;
   MPGAN_UNSUPPORTED(CGa > 256, "norm_act_add: C=%d too wide", c);
   const int Ra = 256 / CGa;
-  long gxa = (P + Ra - 1) / Ra;
+  long gxa = (P + 4L * Ra - 1) / (4L * Ra);          // four rows per thread (the kernel batches their loads)
   const long capa = 4096 / n > 1 ? 4096 / n : 1;
   if (gxa > capa) gxa = capa;
   dim3 grida((unsigned)gxa, (unsigned)n);
@@ -749,7 +804,7 @@ extern "C" int mpgan_norm_act_add_fold(const float* z, int32_t ldz, const mpgan_
   a.n_stride = 0;
   const int CGa = vec ? c / 4 : c;
   const int Ra = 256 / CGa;
-  long gxa = (P + Ra - 1) / Ra;
+  long gxa = (P + 4L * Ra - 1) / (4L * Ra);          // four rows per thread (the kernel batches their loads)
   const long capa = 4096 / n > 1 ? 4096 / n : 1;
   if (gxa > capa) gxa = capa;
   dim3 grida((unsigned)gxa, (unsigned)n);
@@ -794,9 +849,6 @@ extern "C" int mpgan_norm_bwd_finalize(const float* partials, int32_t n, int32_t
   // per-channel slope terms go to the tail of the partials buffer (>= c floats past the partial rows)
   // (Measured and dropped: one 1024-thread block finalizing every channel plus the slope sum: 23-31 us
   //  against 10 -- one CU's address unit serialises its 16 waves' one-line-per-lane row reads.)
-  MPGAN_UNSUPPORTED(dslope && (long)n * chunks * c > (1L << 18),
-                    "norm_bwd_finalize: slope gradient over %ld partials (sized for the generator's layers)",
-                    (long)n * chunks * c);
   const long rows = (long)n * chunks;
   if (!instance && rows >= 512 && rows < (1L << 31)) {   // many rows: a block per channel (see the kernel)
     hipLaunchKernelGGL(norm_bwd_finalize_wide_kernel, dim3(c + (dslope ? 1 : 0)), dim3(256), 0, (hipStream_t)stream,
@@ -823,7 +875,7 @@ extern "C" int mpgan_norm_bwd_apply(const float* g, int32_t ldg, const float* z,
   const int CGa = vec ? c / 4 : c;
   MPGAN_UNSUPPORTED(CGa > 256, "norm_bwd_apply: C=%d too wide", c);
   const int Ra = 256 / CGa;
-  long gxa = (P + Ra - 1) / Ra;
+  long gxa = (P + 4L * Ra - 1) / (4L * Ra);          // four rows per thread (the kernel batches their loads)
   const long capa = 4096 / n > 1 ? 4096 / n : 1;
   if (gxa > capa) gxa = capa;
   dim3 grida((unsigned)gxa, (unsigned)n);

@@ -758,7 +758,7 @@ def emit_norm_bwd(prog, g, z, nb: NormBuf, pro: Prologue, dz, partials, dgamma, 
     assert g.shape == z.shape and dz.shape == z.shape
     c = z.shape[-1]
     chunks = ops.stats_chunks(P, c)
-    assert partials.numel() >= n * chunks * 3 * c + c
+    assert partials.numel() >= n * chunks * (3 * c + 1) + c          # [3][C] rows + one slope scalar per row
     L = lib()
     pc = pro.c()
     pe = peer.c() if peer is not None else None
@@ -806,7 +806,7 @@ class Scratch:
         self.ws = None
 
     def want_partials(self, n, P, c):
-        self.partials_need = max(self.partials_need, (n * ops.stats_chunks(P, c) + 32) * 3 * c + c)
+        self.partials_need = max(self.partials_need, (n * ops.stats_chunks(P, c) + 32) * (3 * c + 1) + c)
 
     def want_ws(self, g: ConvGeom):
         self.ws_need = max(self.ws_need, ops.conv_wgrad_workspace(g) // 4)

@@ -314,8 +314,8 @@ def norm_bwd_reduce(g, z, p: Prologue, mean, invstd, partials, peer: Optional[Pe
     if g.shape != z.shape:
         raise ValueError("norm_bwd_reduce: shape mismatch")
     c = z.shape[-1]
-    if partials.numel() < n * stats_chunks(P, c) * 3 * c + c:
-        raise ValueError("norm_bwd_reduce: partials too small (need n*chunks*3*c + c floats)")
+    if partials.numel() < n * stats_chunks(P, c) * (3 * c + 1):
+        raise ValueError("norm_bwd_reduce: partials too small (need n*chunks*(3*c + 1) floats)")
     check(lib().mpgan_norm_bwd_reduce(g.data_ptr(), ldg, z.data_ptr(), ldz, _pro(p), mean.data_ptr(),
                                       invstd.data_ptr(), _peer(peer), n, P, c, partials.data_ptr(), _stream()),
           "norm_bwd_reduce")

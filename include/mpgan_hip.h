@@ -228,9 +228,11 @@ int mpgan_norm_act_add(const float* z, int32_t ldz, const mpgan_prologue* pz,
                        float* out, int32_t ldo, void* stream);
 
 /* Backward of a = act(z*scale+shift), given g = dL/da:
- *   reduce  : partials [n][chunks][3][C] of (sum gy, sum gy*zhat, sum g*min(y,0));
- *             the buffer must hold C more floats after those rows (finalize scratch)
- *   finalize: dgamma += , dbeta += , dslope += ; coef c1 = sum gy / M, c2 = sum gy*zhat / M
+ *   reduce  : partials [n][chunks][3][C] of (sum gy, sum gy*zhat, sum g*min(y,0)), followed by one float per
+ *             row (n*chunks of them): that row's third sums added over the channels (the PReLU-slope gradient's
+ *             terms) -- the buffer holds n*chunks*(3*C + 1) floats, chunks = mpgan_stats_chunks(P, C)
+ *   finalize: dgamma += , dbeta += , dslope += (dslope != null needs the per-row scalars a reduce pass left;
+ *             rows written by mpgan_conv_backward_data_stats carry none); coef c1 = sum gy / M, c2 = sum gy*zhat / M
  *   apply   : dz = scale*(gy - c1 - zhat*c2)
  * g may carry a fused pointwise factor: g_eff = g * (1 - t^2) (tanh backward)
  * when tanh_y != null. */

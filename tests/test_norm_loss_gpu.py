@@ -67,7 +67,7 @@ def test_norm_prelu_forward_backward(c, spatial, n, instance):
 
     P = d * h * w
     chunks = ops.stats_chunks(P, c)
-    partials = torch.empty(n * chunks * 3 * c + c, device="cuda")
+    partials = torch.empty(n * chunks * (3 * c + 1), device="cuda")    # [3][C] rows + one slope scalar per row
     g_cl = to_cl(g)
     ops.norm_bwd_reduce(g_cl, z_cl, pro, mean, invstd, partials)
     dgamma, dbeta = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")

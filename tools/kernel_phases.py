@@ -7,7 +7,8 @@ records the 100 MHz device clock at its phase boundaries (csrc/mpgan_common.h: M
 prints, in microseconds,
     span     first block's start -> last block's end (what rocprofv3 reports as the kernel, minus dispatch)
     ramp     95th-percentile block start after the first one (dispatch ramp, or the second round of blocks)
-    K-stepped kernel:   prologue (first tile's loads -> LDS) | K loop | in-block split-K fold | epilogue
+    K-stepped kernel:   prologue (first tile's loads -> LDS) | K loop | in-block split-K fold | epilogue = row->pixel
+                        map + output stores issued + statistics rows
     persistent patch:   weight staging | first patch | sum of contractions (+ stores issued) | sum of tile
                         tails (barrier, statistics rows, next patch's arrival + LDS stores) | tiles per block
     gap      this launch's last end -> the next stamped launch's first start (seam + any unstamped kernels
@@ -96,7 +97,8 @@ def main():
         b = blk[done]
         if kind == 1:
             r.update(prologue=med(b[:, 1] - b[:, 0]), kloop=med(b[:, 2] - b[:, 1]), fold=med(b[:, 3] - b[:, 2]),
-                     epilogue=med(b[:, 7] - b[:, 3]), block=med(b[:, 7] - b[:, 0]))
+                     epilogue=med(b[:, 7] - b[:, 3]), ep_map=med(b[:, 4] - b[:, 3]), ep_store=med(b[:, 5] - b[:, 4]),
+                     ep_stats=med(b[:, 7] - b[:, 5]), block=med(b[:, 7] - b[:, 0]))
         elif kind == 2:
             r.update(wstage=med(b[:, 1] - b[:, 0]), patch0=med(b[:, 2] - b[:, 1]), contract=med(b[:, 3]), tails=med(b[:, 4]),
                      tiles=float(np.median(b[:, 5])), block=med(b[:, 7] - b[:, 0]))
@@ -107,7 +109,7 @@ def main():
     per = nl // 6
     print(f"{a.what}: {nl} stamped launches ({per} per U-Net), clock {khz} kHz; microseconds, medians over blocks"
           + ("" if a.all else ", mean over the six U-Nets"))
-    hdr = f"{'launch':58s} {'blocks':>6s} {'span':>6s} {'ramp':>5s} | {'phases':60s} | {'gap':>5s}"
+    hdr = f"{'launch':58s} {'blocks':>6s} {'span':>6s} {'ramp':>5s} | {'phases':92s} | {'gap':>5s}"
     print(hdr)
     groups = [[rows[i]] for i in range(nl)] if a.all else [[rows[u * per + j] for u in range(6)] for j in range(per)]
     tot_span = tot_gap = 0.0
@@ -117,8 +119,9 @@ def main():
         name, desc, kern = r0["key"]
         label = f"{'fwd' if name == 'conv_forward' else 'dgrad'} {desc} {kern.replace('gather_', '').replace('_kernel', '')}"[:58]
         if r0["kind"] == 1:
-            ph = (f"prologue {mean('prologue'):5.1f}  K loop {mean('kloop'):5.1f}  fold {mean('fold'):4.1f}  "
-                  f"epilogue {mean('epilogue'):5.1f}  (block {mean('block'):5.1f})")
+            ph = (f"prologue {mean('prologue'):4.1f}  K loop {mean('kloop'):5.1f}  fold {mean('fold'):3.1f}  "
+                  f"epilogue {mean('epilogue'):4.1f} = map {mean('ep_map'):3.1f} + stores {mean('ep_store'):3.1f} + stats {mean('ep_stats'):3.1f}  "
+                  f"(block {mean('block'):5.1f})")
         elif r0["kind"] == 2:
             ph = (f"weights {mean('wstage'):4.1f}  patch0 {mean('patch0'):4.1f}  contract {mean('contract'):5.1f}  "
                   f"tails {mean('tails'):5.1f}  tiles {mean('tiles'):3.0f}  (block {mean('block'):5.1f})")
@@ -129,7 +132,7 @@ def main():
             tot_span += span
         if gap == gap:
             tot_gap += gap
-        print(f"{label:58s} {mean('blocks') if r0['kind'] else float('nan'):6.0f} {span:6.1f} {mean('ramp') if r0['kind'] else float('nan'):5.1f} | {ph:60s} | {gap:5.1f}")
+        print(f"{label:58s} {mean('blocks') if r0['kind'] else float('nan'):6.0f} {span:6.1f} {mean('ramp') if r0['kind'] else float('nan'):5.1f} | {ph:92s} | {gap:5.1f}")
     scale = 1 if a.all else 6
     print(f"sum of spans {tot_span * scale / 1e3:.3f} ms, sum of gaps {tot_gap * scale / 1e3:.3f} ms per pass")
 

@@ -92,6 +92,41 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
   }
   // fused norm-backward sums of the produced gradient (BwdStats): per-column vectors and running sums
   const bool bw = p.bwd.part != nullptr;
+  // Output path A (the usual one): every 32 x 32 accumulator tile goes through a wave-private LDS transpose and leaves
+  // as 16-byte stores -- a lane holds ONE channel of 16 rows, so direct stores are 4 bytes per lane and 16 store
+  // instructions per tile; the phase stamps show 3-6.5 us of every K-stepped launch in issuing them (all blocks end
+  // their K loops together and the scalar stores queue up).  Path B (below): the element-wise walk, kept for the
+  // BwdStats form (its sums need each element beside its z) and for unaligned / odd-width outputs.
+  const bool vec_out = !bw && (Cout % 4 == 0) && (ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(gout) & 15) == 0) &&
+                       (!gres || ((ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(gres) & 15) == 0));
+  if (vec_out) {
+    constexpr int TP = 36;                                 // pitch of the transpose tile: conflict-free both ways
+    float* wt = lds + 2048 + wid * 32 * TP;                // clear of rowpix (ints 0..511) and the statistics area (1024..)
+    if (active) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) wt[((r & 3) + 8 * (r >> 2) + 4 * lh) * TP + li] = acc[tm][tn][r] + bv[tn];
+          const int c4 = lane & 7, co = n0 + (wn * TN + tn) * 32 + 4 * c4;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int row = (lane >> 3) + 8 * k;
+            const int pix = rowpix[(wm * TM + tm) * 32 + row];
+            float4 v = *reinterpret_cast<const float4*>(wt + row * TP + 4 * c4);
+            if (pix >= 0 && co < Cout) {
+              if (gres) {
+                const float4 rr = *reinterpret_cast<const float4*>(gres + (long)pix * ldr + co);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+              }
+              if (tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+              *reinterpret_cast<float4*>(gout + (long)pix * ldo + co) = v;
+            }
+          }
+        }
+    }
+  }
   float bsc[TN], bsh[TN], bmu[TN], bis[TN], b1[TN], b2[TN], b3[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -105,7 +140,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
   const bool bleaky = p.bwd.leaky != 0;
   const float bslope = p.bwd.slope;
   // row-major walk: the 64-bit pixel offset is formed once per row, not once per element
-  if (active)
+  if (active && !vec_out)
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     // BwdStats: the tile's z values are fetched in ONE batch in front of the stores (loads between the stores could
@@ -815,9 +850,9 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   if (nk > 0) {
-    issue_loads(SX);        // tile 0
-    store_tile(0, SX);
-    issue_loads(SX);        // tile 1 stays in flight into the first K-step
+    issue_loads(SY);        // tile 0
+    issue_loads(SX);        // tile 1, issued beside it: the block's cold round trips overlap (the phase stamps put the
+    store_tile(0, SY);      // prologue at 4-7 us of a 15-60 us launch); tile 1 stays in flight into the first K-step
   }
   __syncthreads();
   MPGAN_STAMP(p, 1);        // prologue done: first tile in LDS
@@ -2023,7 +2058,9 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   // weight chunks per thread and trip: ALL of a 3x3 layer's weights in one round of loads (32 -> 32: 2304 chunks = 9
   // per thread; with 4 per trip the block spent three dependent round trips -- 8.6 us measured by the phase stamps,
   // 37 % of its life -- before its first MFMA)
-  constexpr int WU = 12;
+  // -- and branch-free: slots past the weights re-read row 0 (an L1 hit) instead of testing (a test per slot puts
+  // every load into a basic block of its own behind its own wait: 18 us).  3x3 taps, Cout <= 16 (NARROW) or <= 32.
+  constexpr int WU = NARROW ? (CIN == 16 ? 3 : (CIN == 32 ? 5 : 9)) : (CIN == 16 ? 5 : 9);
   // LDS pitches (floats per pixel / per weight row), chosen by the host so that the fragments' ds_read_b128 are
   // conflict-free: CIN + 8 for the 16x16x4 form (CIN + 4 cost 61 % of the LDS cycles in bank conflicts there,
   // rocprofv3 SQ_LDS_BANK_CONFLICT), CIN + 4 for the 32x32x2 form.
@@ -2082,7 +2119,6 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
       float4 wv[WU];
 #pragma unroll
       for (int u = 0; u < WU; ++u) {
-        if (base + u * 256 >= wtotal) break;               // block-uniform: no loads for slots past the weights
         const int idx = base + u * 256 + tid;
         const unsigned row = idx < wtotal ? (unsigned)idx / (unsigned)CQ : 0u;
         unsigned t, co, jy, jx;
@@ -2095,7 +2131,6 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
       }
 #pragma unroll
       for (int u = 0; u < WU; ++u) {
-        if (base + u * 256 >= wtotal) break;
         const int idx = base + u * 256 + tid;
         if (idx < wtotal) *reinterpret_cast<float4*>(wl + (idx / CQ) * PCW + 4 * cq) = wv[u];
       }
@@ -2223,6 +2258,24 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          // residual operand of the epilogue (backward-data accumulating into a gradient): fetched BEFORE the
+          // contraction -- loaded beside the stores, each store waited out its own round trip (+4-7 us per tile)
+          float rres[16];
+          if (gres) {
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+              const int my = my0 + 2 * wid + rh, oy = my * osy + ph.oy;
+              const bool rowok = my < My && oy < p.Ho && li < Cout;
+              const int rowbase = ((n * p.Ho + oy) * p.Wo + ph.ox);
+#pragma unroll
+              for (int rq = 0; rq < 8; ++rq) {
+                const int mx = mx0 + 4 * lh + (rq & 3) + 8 * (rq >> 2);
+                const int ox = mx * osx;
+                const bool ok = rowok && mx < Mx && ox + ph.ox < p.Wo;
+                rres[rh * 8 + rq] = ok ? gres[(rowbase + ox) * ldr + li] : 0.f;
+              }
+            }
+          }
           {
             const int tyl = 2 * wid + (li >> 4), txl = li & 15;
             const float* Arow = patch + ((tyl * isy - ylo) * PW + (txl * isx - xlo)) * PCA + 4 * lh;
@@ -2263,7 +2316,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
                 float v = acc[r] + bv;
                 sm += v;
                 sq += v * v;
-                if (gres) v += gres[pix * ldr + co];
+                if (gres) v += rres[r];
                 if (tanh_out) v = tanhf(v);
                 if (!(pl.dbg & 1)) gout[pix * ldo + co] = v;
               }
@@ -2276,6 +2329,22 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
         } else {
           const int l16 = lane & 15, kq = lane >> 4;
           f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+          float rres[8];                                  // residual operand, fetched before the contraction (see above)
+          if (gres) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              const int my = my0 + 2 * wid + mt, oy = my * osy + ph.oy;
+              const bool rowok = my < My && oy < p.Ho && l16 < Cout;
+              const int rowbase = (n * p.Ho + oy) * p.Wo + ph.ox;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int mx = mx0 + 4 * kq + r;
+                const int ox = mx * osx;
+                const bool ok = rowok && mx < Mx && ox + ph.ox < p.Wo;
+                rres[mt * 4 + r] = ok ? gres[(rowbase + ox) * ldr + l16] : 0.f;
+              }
+            }
+          }
           {
             const float* A0row = patch + (((2 * wid) * isy - ylo) * PW + (l16 * isx - xlo)) * PCA + 4 * kq;
             const float* A1row = A0row + isy * PW * PCA;
@@ -2319,7 +2388,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
                 float v = (mt == 0 ? acc0[r] : acc1[r]) + bv;
                 sm += v;
                 sq += v * v;
-                if (gres) v += gres[pix * ldr + co];
+                if (gres) v += rres[mt * 4 + r];
                 if (tanh_out) v = tanhf(v);
                 if (!(pl.dbg & 1)) gout[pix * ldo + co] = v;
               }
@@ -2752,68 +2821,104 @@ __global__ __launch_bounds__(256, 2) void gather_patch3d_c16_kernel(const Gather
   float* st = wl + 27 * 16 * P3_PW;                             // [4 waves][2][16]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const Phase& ph = p.ph[0];
-  // persistent blocks: the 27 taps' weights are staged once, then the block walks tiles (XCD-contiguous ranges)
+  // Persistent blocks: the 27 taps' weights are staged once, then the block walks tiles (XCD-contiguous ranges).
+  // All staging is "issue every load of the round, then store": a bounds test around each load had put every chunk
+  // into a basic block of its own behind its own memory round trip (seven per tile); and the NEXT tile's patch is
+  // fetched into registers under the current tile's contraction.
+  constexpr int NPCH = (P3_PROWS * 4 + 255) / 256;               // 7 patch chunks per thread
+  constexpr int NWCH = (27 * 16 * 4 + 255) / 256;                // 7 weight chunks per thread
+  const int c4 = tid & 3;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  float slope = 1.f;
+  if constexpr (HAS_PRO) {
+    sc = *reinterpret_cast<const float4*>(p.pro.scale + 4 * c4);
+    sh = *reinterpret_cast<const float4*>(p.pro.shift + 4 * c4);
+    slope = pro_slope(p.pro);
+  }
+  const int act = p.pro.act;
+  int pzyx[NPCH];                                                // (pz << 16) | (py << 8) | px of this thread's chunks, -1 past the patch
+#pragma unroll
+  for (int i = 0; i < NPCH; ++i) {
+    const int pr = (tid + 256 * i) >> 2;
+    const int pz = pr / (P3_PY * P3_PX), rem = pr - pz * (P3_PY * P3_PX);
+    const int py = rem / P3_PX, px = rem - py * P3_PX;
+    pzyx[i] = pr < P3_PROWS ? ((pz << 16) | (py << 8) | px) : -1;
+  }
+  const int mnz = ph.dz0 + (p.dstep[0] < 0 ? 2 * p.dstep[0] : 0), mny = ph.dy0 + (p.dstep[1] < 0 ? 2 * p.dstep[1] : 0),
+            mnx = ph.dx0 + (p.dstep[2] < 0 ? 2 * p.dstep[2] : 0);
+  float4 pv[NPCH];
+  unsigned pok = 0;
+  auto decode = [&](unsigned t, int& n, int& oz0, int& oy0, int& ox0) {
+    const int tx = t % tg.tiles_x; t /= tg.tiles_x;
+    const int ty = t % tg.tiles_y; t /= tg.tiles_y;
+    const int tz = t % tg.tiles_z;
+    n = (int)(t / tg.tiles_z);
+    oz0 = tz * P3_TZ; oy0 = ty * P3_TY; ox0 = tx * P3_TX;
+  };
+  auto load_patch = [&](unsigned t) {
+    int n, oz0, oy0, ox0;
+    decode(t, n, oz0, oy0, ox0);
+    const int pz0 = oz0 + mnz, py0 = oy0 + mny, px0 = ox0 + mnx;
+    const float* __restrict__ gin = p.in + 4 * c4;
+    pok = 0;
+#pragma unroll
+    for (int i = 0; i < NPCH; ++i) {
+      const int iz = pz0 + (pzyx[i] >> 16), iy = py0 + ((pzyx[i] >> 8) & 255), ix = px0 + (pzyx[i] & 255);
+      const bool ok = pzyx[i] >= 0 && (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi &&
+                      (unsigned)ix < (unsigned)p.Wi;
+      const long off = ok ? ((((long)n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * p.ldi : 0;   // out of range: a valid address, masked below
+      pv[i] = *reinterpret_cast<const float4*>(gin + off);
+      pok |= (ok ? 1u : 0u) << i;
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPCH; ++i) {
+      float4 v = pv[i];
+      if constexpr (HAS_PRO) {
+        v.x = act_apply(fmaf(v.x, sc.x, sh.x), act, slope);
+        v.y = act_apply(fmaf(v.y, sc.y, sh.y), act, slope);
+        v.z = act_apply(fmaf(v.z, sc.z, sh.z), act, slope);
+        v.w = act_apply(fmaf(v.w, sc.w, sh.w), act, slope);
+      }
+      const bool ok = (pok >> i) & 1u;                           // the conv's zero padding is a zero of the ACTIVATED tensor
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if (pzyx[i] >= 0) {
+        const int pr = ((pzyx[i] >> 16) * P3_PY + ((pzyx[i] >> 8) & 255)) * P3_PX + (pzyx[i] & 255);
+        *reinterpret_cast<float4*>(patch + pr * P3_PA + 4 * c4) = v;
+      }
+    }
+  };
+  const unsigned ntiles = (unsigned)(p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x);
+  const unsigned per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const unsigned w0 = xcd_remap(blockIdx.x, gridDim.x) * per;
+  const unsigned wend = w0 + per < ntiles ? w0 + per : ntiles;
+  if (w0 < wend) load_patch(w0);                               // in flight while the weights are fetched
   {
     const float* __restrict__ gw = p.wp;                       // packed [Cout = 16][27][Cin = 16]
+    float4 wv[NWCH];
 #pragma unroll
-    for (int i = 0; i < (27 * 16 * 4 + 255) / 256; ++i) {
+    for (int i = 0; i < NWCH; ++i) {
+      const int e = tid + 256 * i;
+      wv[i] = *reinterpret_cast<const float4*>(gw + (long)(e < 27 * 16 * 4 ? e : 0) * 4);   // row * 16 + 4 * k4 == 4 * e
+    }
+#pragma unroll
+    for (int i = 0; i < NWCH; ++i) {
       const int e = tid + 256 * i;
       if (e < 27 * 16 * 4) {
         const int k4 = e & 3, row = e >> 2;                    // row = co * 27 + tap
         const int co = row / 27, tap = row - co * 27;
-        *reinterpret_cast<float4*>(wl + (tap * 16 + co) * P3_PW + 4 * k4) = *reinterpret_cast<const float4*>(gw + (long)row * 16 + 4 * k4);
+        *reinterpret_cast<float4*>(wl + (tap * 16 + co) * P3_PW + 4 * k4) = wv[i];
       }
     }
   }
-  const unsigned ntiles = (unsigned)(p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x);
-  const unsigned per = (ntiles + gridDim.x - 1) / gridDim.x;
-  const unsigned w0 = xcd_remap(blockIdx.x, gridDim.x) * per;
-  for (unsigned tt = w0; tt < w0 + per && tt < ntiles; ++tt) {
-  unsigned t = tt;
-  const int stats_row = (int)t;
-  const int tx = t % tg.tiles_x; t /= tg.tiles_x;
-  const int ty = t % tg.tiles_y; t /= tg.tiles_y;
-  const int tz = t % tg.tiles_z;
-  const int n = t / tg.tiles_z;
-  const int oz0 = tz * P3_TZ, oy0 = ty * P3_TY, ox0 = tx * P3_TX;
-  const int mnz = ph.dz0 + (p.dstep[0] < 0 ? 2 * p.dstep[0] : 0), mny = ph.dy0 + (p.dstep[1] < 0 ? 2 * p.dstep[1] : 0),
-            mnx = ph.dx0 + (p.dstep[2] < 0 ? 2 * p.dstep[2] : 0);
-  const int pz0 = oz0 + mnz, py0 = oy0 + mny, px0 = ox0 + mnx;
-  // ---- stage the patch (prologue applied once per element) and the weights ----
-  {
-    const float* __restrict__ gin = p.in;
-    const int c4 = tid & 3;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    float slope = 1.f;
-    if constexpr (HAS_PRO) {
-      sc = *reinterpret_cast<const float4*>(p.pro.scale + 4 * c4);
-      sh = *reinterpret_cast<const float4*>(p.pro.shift + 4 * c4);
-      slope = pro_slope(p.pro);
-    }
-    const int act = p.pro.act;
-#pragma unroll
-    for (int i = 0; i < (P3_PROWS * 4 + 255) / 256; ++i) {
-      const int e = tid + 256 * i;
-      const int pr = e >> 2;
-      if (pr < P3_PROWS) {
-        const int pz = pr / (P3_PY * P3_PX), rem = pr - pz * (P3_PY * P3_PX);
-        const int py = rem / P3_PX, px = rem - py * P3_PX;
-        const int iz = pz0 + pz, iy = py0 + py, ix = px0 + px;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
-          v = *reinterpret_cast<const float4*>(gin + ((((long)n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * p.ldi + 4 * c4);
-          if constexpr (HAS_PRO) {
-            v.x = act_apply(fmaf(v.x, sc.x, sh.x), act, slope);
-            v.y = act_apply(fmaf(v.y, sc.y, sh.y), act, slope);
-            v.z = act_apply(fmaf(v.z, sc.z, sh.z), act, slope);
-            v.w = act_apply(fmaf(v.w, sc.w, sh.w), act, slope);
-          }
-        }
-        *reinterpret_cast<float4*>(patch + pr * P3_PA + 4 * c4) = v;
-      }
-    }
-  }
+  for (unsigned tt = w0; tt < wend; ++tt) {
+  const int stats_row = (int)tt;
+  int n, oz0, oy0, ox0;
+  decode(tt, n, oz0, oy0, ox0);
+  store_patch();
   __syncthreads();
+  if (tt + 1 < wend) load_patch(tt + 1);                       // under this tile's contraction and output stores
   // ---- contraction: wave = 32 pixels (two 16-row blocks) x 16 channels ----
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int ln = lane & 15, g = lane >> 4;

@@ -919,45 +919,68 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch3d_c16_kernel(const WgradPa
   const unsigned ntiles = (unsigned)(p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x);
   const unsigned per = (ntiles + gridDim.x - 1) / gridDim.x;
   const unsigned w0 = xcd_remap(blockIdx.x, gridDim.x) * per;
-  for (unsigned tt = w0; tt < w0 + per && tt < ntiles; ++tt) {
-    unsigned t = tt;
+  const unsigned wend = w0 + per < ntiles ? w0 + per : ntiles;
+  // Staging is "issue every load of the tile, then store" (a bounds test around each load put each chunk behind its
+  // own memory round trip), and the NEXT tile's operands are fetched into registers under the current contraction.
+  constexpr int NPCH = (WP3_PROWS * 4 + 255) / 256;              // 7 patch chunks per thread
+  int pzyx[NPCH];
+#pragma unroll
+  for (int i = 0; i < NPCH; ++i) {
+    const int pr = (tid + 256 * i) >> 2;
+    const int pz = pr / (WP3_PY * WP3_PX), rem = pr - pz * (WP3_PY * WP3_PX);
+    const int py = rem / WP3_PX, px = rem - py * WP3_PX;
+    pzyx[i] = pr < WP3_PROWS ? ((pz << 16) | (py << 8) | px) : -1;
+  }
+  float4 pv[NPCH], dv[2];
+  unsigned pok = 0;
+  auto load_tile = [&](unsigned t) {
     const int tx = t % tg.tiles_x; t /= tg.tiles_x;
     const int ty = t % tg.tiles_y; t /= tg.tiles_y;
     const int tz = t % tg.tiles_z;
     const int n = t / tg.tiles_z;
     const int oz0 = tz * WP3_TZ, oy0 = ty * WP3_TY, ox0 = tx * WP3_TX;
-    __syncthreads();                                            // the previous tile's reads are done
+    pok = 0;
 #pragma unroll
-    for (int i = 0; i < (WP3_PROWS * 4 + 255) / 256; ++i) {
-      const int e = tid + 256 * i, pr = e >> 2;
-      if (pr < WP3_PROWS) {
-        const int pz = pr / (WP3_PY * WP3_PX), rem = pr - pz * (WP3_PY * WP3_PX);
-        const int py = rem / WP3_PX, px = rem - py * WP3_PX;
-        const int iz = oz0 - p.pz + pz, iy = oy0 - p.py + py, ix = ox0 - p.px + px;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)iz < (unsigned)p.Gz && (unsigned)iy < (unsigned)p.Gy && (unsigned)ix < (unsigned)p.Gx) {
-          v = *reinterpret_cast<const float4*>(p.gath + ((((long)n * p.Gz + iz) * p.Gy + iy) * p.Gx + ix) * p.ldg + 4 * c4);
-          if constexpr (HAS_PRO) {
-            v.x = act_apply(fmaf(v.x, sc.x, sh.x), act, slope);
-            v.y = act_apply(fmaf(v.y, sc.y, sh.y), act, slope);
-            v.z = act_apply(fmaf(v.z, sc.z, sh.z), act, slope);
-            v.w = act_apply(fmaf(v.w, sc.w, sh.w), act, slope);
-          }
-        }
+    for (int i = 0; i < NPCH; ++i) {
+      const int iz = oz0 - p.pz + (pzyx[i] >> 16), iy = oy0 - p.py + ((pzyx[i] >> 8) & 255), ix = ox0 - p.px + (pzyx[i] & 255);
+      const bool ok = pzyx[i] >= 0 && (unsigned)iz < (unsigned)p.Gz && (unsigned)iy < (unsigned)p.Gy && (unsigned)ix < (unsigned)p.Gx;
+      const long off = ok ? ((((long)n * p.Gz + iz) * p.Gy + iy) * p.Gx + ix) * p.ldg : 0;
+      pv[i] = *reinterpret_cast<const float4*>(p.gath + off + 4 * c4);
+      pok |= (ok ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = (tid + 256 * i) >> 2;                        // tile pixel 0..127
+      const int oz = oz0 + (q >> 6), oy = oy0 + ((q >> 3) & 7), ox = ox0 + (q & 7);
+      const bool ok = oz < p.Mz && oy < p.My && ox < p.Mx;
+      const long off = ok ? ((((long)n * p.Mz + oz) * p.My + oy) * p.Mx + ox) * p.ldd : 0;
+      const float4 v = *reinterpret_cast<const float4*>(p.dense + off + 4 * c4);
+      dv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPCH; ++i) {
+      float4 v = pv[i];
+      if constexpr (HAS_PRO) {
+        v.x = act_apply(fmaf(v.x, sc.x, sh.x), act, slope);
+        v.y = act_apply(fmaf(v.y, sc.y, sh.y), act, slope);
+        v.z = act_apply(fmaf(v.z, sc.z, sh.z), act, slope);
+        v.w = act_apply(fmaf(v.w, sc.w, sh.w), act, slope);
+      }
+      const bool ok = (pok >> i) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if (pzyx[i] >= 0) {
+        const int pr = ((pzyx[i] >> 16) * WP3_PY + ((pzyx[i] >> 8) & 255)) * WP3_PX + (pzyx[i] & 255);
         *reinterpret_cast<float4*>(patch + pr * 16 + 4 * c4) = v;
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + 256 * i, q = e >> 2;                  // tile pixel 0..127
-      const int oz = oz0 + (q >> 6), oy = oy0 + ((q >> 3) & 7), ox = ox0 + (q & 7);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (oz < p.Mz && oy < p.My && ox < p.Mx)
-        v = *reinterpret_cast<const float4*>(p.dense + ((((long)n * p.Mz + oz) * p.My + oy) * p.Mx + ox) * p.ldd + 4 * c4);
-      *reinterpret_cast<float4*>(dyt + q * 16 + 4 * c4) = v;
-    }
-    __syncthreads();
-    // ---- contraction over the tile's 128 pixels, four at a time: k = pixel 4 j + g ----
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(dyt + ((tid + 256 * i) >> 2) * 16 + 4 * c4) = dv[i];
+  };
+  // contraction over the tile's 128 pixels, four at a time (k = pixel 4 j + g): branch-free bodies, one per wave kind
+  auto contract = [&](auto bias_tag) {
+    constexpr bool BIAS = decltype(bias_tag)::value;
 #pragma unroll 4
     for (int j = 0; j < 32; ++j) {
       const int q = 4 * j + g;
@@ -966,9 +989,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch3d_c16_kernel(const WgradPa
       const float* brow = patch + pb * 16 + ln;                  // B[k][col = ci = ln] at tap (0, 0, 0)
 #pragma unroll
       for (int k = 0; k < 6; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[toff[k]], acc[k], 0, 0, 0);
-      if (last_wave) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(a, 1.0f, accb, 0, 0, 0);       // taps 3, 7, .. 23: six
-      else acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[toff[6]], acc[6], 0, 0, 0);    // taps w + 24 <= 26
+      if constexpr (BIAS) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(a, 1.0f, accb, 0, 0, 0);   // taps 3, 7, .. 23: six
+      else acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[toff[6]], acc[6], 0, 0, 0);        // taps w + 24 <= 26
     }
+  };
+  if (w0 < wend) load_tile(w0);
+  for (unsigned tt = w0; tt < wend; ++tt) {
+    __syncthreads();                                            // the previous tile's reads are done
+    store_tile();
+    __syncthreads();
+    if (tt + 1 < wend) load_tile(tt + 1);
+    if (last_wave) contract(std::true_type{});
+    else contract(std::false_type{});
   }
   // ---- D[row = co = 4 g + i][col = ci = ln] -> partial[block][co][tap * 16 + ci]; bias partial [block][co] ----
   float* out = p.partial + (long)blockIdx.x * 16 * 432;

@@ -103,7 +103,8 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
     assert e_gy <= cost_gy + 2e-2, (e_gy, cost_gy)
     # teacher-forced: OUR upstream gradient through the oracle generator's backward -- in fp32 and, as the
     # yardstick, in fp64 (BatchNorm over the 9^3 x 2 values of the deepest level and PReLU-kink flips make single
-    # tensors of ANY fp32 backward differ by percents): err(ours, f64) <= 3 err(oracle f32, f64) + 2e-3
+    # tensors of ANY fp32 backward differ by percents): err(ours, f64) <= 3 err(oracle f32, f64) + eps,
+    # eps = 1e-2 for every tensor and 2e-3 for at least 90 % of them
     y_ref.backward(gy)
     y64 = rg64(t1.double())
     y64.backward(gy.double())
@@ -119,8 +120,10 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
             continue
         e_ours, e_32 = _rel(gg[name], p64[name].grad), _rel(p.grad, p64[name].grad)
         errs[name] = (e_ours, e_32)
-        if e_ours > 3 * e_32 + 2e-3:
+        if e_ours > 3 * e_32 + 1e-2:             # eps: one PReLU-kink flip (tests/test_fullsize_gpu.py: YARD_EPS)
             bad.append((name, e_ours, e_32))
+    tight = sum(a <= 3 * b + 2e-3 for a, b in errs.values())
+    assert tight >= 0.9 * len(errs), (tight, len(errs))
     flat_o = torch.cat([gg[k].reshape(-1) for k in rp])
     flat_r = torch.cat([p.grad.reshape(-1) for p in rp.values()])
     flat_64 = torch.cat([p64[k].grad.reshape(-1) for k in rp])

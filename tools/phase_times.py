@@ -60,9 +60,21 @@ def main():
             e[0] += d["ms"]; e[1] += d["calls"]
         for nm, (ms, calls) in sorted(byname.items(), key=lambda kv: -kv[1][0]):
             print(f"{ms / a.steps:8.3f} ms/step {calls // a.steps:4d} calls {ms / calls * 1e3:8.1f} us/call  {nm}")
-        print("--- top calls")
-        for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:40]:
-            print(f"{d['ms'] / a.steps:8.3f} ms/step {d['calls'] // a.steps:4d} calls {d['ms'] / d['calls'] * 1e3:8.1f} us/call  {k}")
+        print("--- top calls (conv launches: algorithmic GB/s = gathered + dense operand once over the launch time, and TFLOP/s)")
+        hbm_bound_ms = 0.0
+        for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:60]:
+            gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["bytes"] else 0.0
+            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["flops"] else 0.0
+            extra = f"  {gbs:7.0f} GB/s {tf:6.1f} TF/s" if d["bytes"] else ""
+            print(f"{d['ms'] / a.steps:8.3f} ms/step {d['calls'] // a.steps:4d} calls {d['ms'] / d['calls'] * 1e3:8.1f} us/call  {k}{extra}")
+        # what bf16 storage of these tensors could save at most: a launch's time can only follow its bytes where it
+        # already runs near the HBM roof; take time * min(1, GB/s / 4000) as its bandwidth-bound share and halve that
+        for k, d in summ.items():
+            if d["bytes"]:
+                gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                hbm_bound_ms += d["ms"] / a.steps * min(1.0, gbs / 4000.0) * 0.5
+        print(f"upper bound of what halving the conv operands' bytes (bf16 storage) could save in this phase: "
+              f"{hbm_bound_ms:.2f} ms per step (launch time x min(1, algorithmic GB/s / 4000) / 2, summed)")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,12 @@
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r3e
+mkdir -p $O
+cd $R
+echo "[1] tests"; timeout -k 10 1000 python -m pytest tests/test_conv_gpu.py tests/test_networks_gpu.py tests/test_fullsize_gpu.py tests/test_c5_step_gpu.py tests/test_variant_b_gpu.py -m gpu -q --tb=short > $O/tests.log 2>&1; echo "tests rc=$?" | tee -a $O/tests.log
+tail -8 $O/tests.log
+echo "[2b] stamps"; timeout -k 10 200 python tools/kernel_phases.py --what fwd > $O/kp_fwd.txt 2>&1; echo rc=$?
+timeout -k 10 200 python tools/kernel_phases.py --what bwd > $O/kp_bwd.txt 2>&1; echo rc=$?
+echo "[3] bench"; timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+echo "[2] phases"; timeout -k 10 200 python tools/phase_times.py --steps 5 --probe gbwd > $O/ph_gbwd.txt 2>&1; echo rc=$?
+echo done

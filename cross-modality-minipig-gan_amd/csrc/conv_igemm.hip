@@ -34,7 +34,7 @@ constexpr int PITCH = BK + 4;
 template <int BN, int TM, int TN, int WN>
 __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& ph, f32x16 (&acc)[TM][TN], float* lds,
                                               long m0, int n0, long Mtot, int stats_row, bool zero_rows = false,
-                                              int tid = threadIdx.x, bool active = true) {
+                                              int tid = threadIdx.x, bool active = true, const float* bias_pre = nullptr) {
   // `tid` is the thread's index inside its 256-thread K group; only the group with `active` holds the tile's
   // sums and writes anything (the in-block split-K form of the pipelined kernel calls this from every group so
   // that the barriers below are reached by all waves).
@@ -88,7 +88,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     cov[tn] = n0 + (wn * TN + tn) * 32 + li;
-    bv[tn] = (p.bias && cov[tn] < Cout) ? p.bias[cov[tn]] : 0.f;
+    bv[tn] = bias_pre ? bias_pre[tn] : ((p.bias && cov[tn] < Cout) ? p.bias[cov[tn]] : 0.f);   // bias_pre: fetched before the K loop
   }
   // fused norm-backward sums of the produced gradient (BwdStats): per-column vectors and running sums
   const bool bw = p.bwd.part != nullptr;
@@ -848,6 +848,12 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bias_pre[TN];       // the epilogue's bias values: in flight under the whole K loop
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int co = n0 + (wn * TN + tn) * 32 + li;
+    bias_pre[tn] = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+  }
 
   if (nk > 0) {
     issue_loads(SY);        // tile 0
@@ -923,7 +929,7 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
     }
     MPGAN_STAMP(p, 2);      // K loop done
     MPGAN_STAMP(p, 3);
-    conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot, stats_row, FAST && m0 + BM > Mtot);
+    conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds, m0, n0, Mtot, stats_row, FAST && m0 + BM > Mtot, threadIdx.x, true, bias_pre);
     MPGAN_STAMP(p, 7);
   } else {
     // every group walks nk_per K-steps' worth of barriers; a group whose range is shorter idles at them
@@ -959,7 +965,7 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
       __syncthreads();
     }
     MPGAN_STAMP(p, 3);      // in-block split-K fold done
-    conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds_all, m0, n0, Mtot, stats_row, FAST && m0 + BM > Mtot, tid, kg == 0);
+    conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds_all, m0, n0, Mtot, stats_row, FAST && m0 + BM > Mtot, tid, kg == 0, bias_pre);
     MPGAN_STAMP(p, 7);
   }
 }
@@ -1733,6 +1739,8 @@ struct PatchLaunch {
   const void* zero_page; // persistent form: >= 16 bytes of zeros in global memory (padding reads it)
   FastDiv fTx, fTy;      // persistent form: tile index -> (sample, tile row, tile column)
   int stagger;           // persistent form: sleep (x 64 clocks) per dispatch round before a block starts (see the kernel)
+  int tw_off;            // persistent form: LDS float offset of the output transpose staging (4 waves x 16 px x pitch), or -1:
+                         //   the epilogue then leaves through it as 16-byte stores (vector output path)
   int dbg;               // MPGAN_DBG_PATCH_SKIP bits (what-if timing builds): 1 no output stores, 2 no MFMAs, 4 no patch loads, 8 no LDS patch stores
 };
 
@@ -2107,8 +2115,8 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   const Phase& ph0 = p.ph[0];
   MPGAN_STAMP(p, 0);
   MPGAN_STAMP_VALUE(p, 6, 2);                 // kernel kind: persistent patch
-  unsigned long long st_contract = 0, st_tail = 0, st_tiles = 0;
-  (void)st_contract; (void)st_tail; (void)st_tiles;
+  unsigned long long st_contract = 0, st_tail = 0, st_tiles = 0, st_mfma = 0;
+  (void)st_contract; (void)st_tail; (void)st_tiles; (void)st_mfma;
 
   // ---- weights: once per block.  Staged BEHIND the first patch's loads (stage_weights() is called once they
   //      are in flight): the block's two cold round trips -- weights, first patch -- overlap instead of adding up ----
@@ -2220,6 +2228,10 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   float* gout = p.out;
   const int ldo = p.ldo, ldr = p.ldr, tanh_out = p.tanh_out;
   const int osy = p.ostride[1], osx = p.ostride[2];
+  // this lane's output channel is the same for every tile and phase: its bias is fetched ONCE, up front (loaded
+  // behind each tile's MFMA loops it was an exposed L2 round trip per tile)
+  const int bias_co = NARROW ? (lane & 15) : (lane & 31);
+  const float bias_v = (p.bias && bias_co < Cout) ? p.bias[bias_co] : 0.f;
 
   // De-phase the blocks that share a CU (dispatch deals the first 256 blocks one per CU, then the next 256, ...):
   // identical blocks started together stay in lockstep -- all staging, then all contracting -- and leave the matrix
@@ -2251,6 +2263,8 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
       float sm = 0.f, sq = 0.f;
       int scol = 0;
       bool swrite = false;
+      const unsigned long long st_ph = MPGAN_STAMP_NOW();
+      (void)st_ph;
       if (live) {
         // (32-bit element offsets in the epilogues below: the host admits only outputs below 2^31 elements)
         if constexpr (!NARROW) {
@@ -2298,28 +2312,46 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
               }
             }
           }
+          st_mfma += MPGAN_STAMP_NOW() - st_ph;
           const int co = li;
-          const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+          const float bv = bias_v;
           // register r of lane (li, lh) is m-row 2*wid + (r >> 3), m-column 4*lh + (r & 3) + 8*((r >> 2) & 1)
 #pragma unroll
           for (int rh = 0; rh < 2; ++rh) {
             const int my = my0 + 2 * wid + rh, oy = my * osy + ph.oy;
             const bool rowok = my < My && oy < p.Ho && co < Cout;
             const int rowbase = ((n * p.Ho + oy) * p.Wo + ph.ox) ;
+            float* tw = lds + pl.tw_off + wid * (16 * 40);     // this wave's transpose staging: [16 px][40]
 #pragma unroll
             for (int rq = 0; rq < 8; ++rq) {
               const int r = rh * 8 + rq;
-              const int mx = mx0 + 4 * lh + (rq & 3) + 8 * (rq >> 2);
+              const int pxl = 4 * lh + (rq & 3) + 8 * (rq >> 2);
+              const int mx = mx0 + pxl;
               const int ox = mx * osx;
-              if (rowok && mx < Mx && ox + ph.ox < p.Wo) {
-                const int pix = rowbase + ox;
-                float v = acc[r] + bv;
+              const bool ok = rowok && mx < Mx && ox + ph.ox < p.Wo;
+              float v = acc[r] + bv;
+              if (ok) {
                 sm += v;
                 sq += v * v;
-                if (gres) v += rres[r];
-                if (tanh_out) v = tanhf(v);
-                if (!(pl.dbg & 1)) gout[pix * ldo + co] = v;
               }
+              if (gres) v += rres[r];
+              if (tanh_out) v = tanhf(v);
+              if (pl.tw_off >= 0) tw[pxl * 40 + li] = v;       // vector path: through LDS, stored below
+              else if (ok && !(pl.dbg & 1)) gout[(rowbase + ox) * ldo + co] = v;
+            }
+            if (pl.tw_off >= 0) {
+              // a lane held ONE channel of 16 pixels (16 four-byte stores per tile: 2.8 us of epilogue per tile against
+              // 1.6 us of MFMA loops, measured by the phase stamps); now lane (px, c4) stores 16 bytes
+              __builtin_amdgcn_wave_barrier();
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
+                const int pxl = (lane >> 3) + 8 * k, c4 = lane & 7;
+                const float4 o = *reinterpret_cast<const float4*>(tw + pxl * 40 + 4 * c4);
+                const int mx = mx0 + pxl, ox = mx * osx;
+                if (my < My && oy < p.Ho && mx < Mx && ox + ph.ox < p.Wo && 4 * c4 < Cout && !(pl.dbg & 1))
+                  *reinterpret_cast<float4*>(gout + (rowbase + ox) * ldo + 4 * c4) = o;
+              }
+              __builtin_amdgcn_wave_barrier();
             }
           }
           sm += __shfl_xor(sm, 32, 64);
@@ -2372,26 +2404,39 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
               }
             }
           }
+          st_mfma += MPGAN_STAMP_NOW() - st_ph;
           const int co = l16;
-          const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+          const float bv = bias_v;
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
             const int my = my0 + 2 * wid + mt, oy = my * osy + ph.oy;
             const bool rowok = my < My && oy < p.Ho && co < Cout;
             const int rowbase = (n * p.Ho + oy) * p.Wo + ph.ox;
+            float* tw = lds + pl.tw_off + wid * (16 * 20);     // this wave's transpose staging: [16 px][20]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int mx = mx0 + 4 * kq + r;
+              const int pxl = 4 * kq + r;
+              const int mx = mx0 + pxl;
               const int ox = mx * osx;
-              if (rowok && mx < Mx && ox + ph.ox < p.Wo) {
-                const int pix = rowbase + ox;
-                float v = (mt == 0 ? acc0[r] : acc1[r]) + bv;
+              const bool ok = rowok && mx < Mx && ox + ph.ox < p.Wo;
+              float v = (mt == 0 ? acc0[r] : acc1[r]) + bv;
+              if (ok) {
                 sm += v;
                 sq += v * v;
-                if (gres) v += rres[mt * 4 + r];
-                if (tanh_out) v = tanhf(v);
-                if (!(pl.dbg & 1)) gout[pix * ldo + co] = v;
               }
+              if (gres) v += rres[mt * 4 + r];
+              if (tanh_out) v = tanhf(v);
+              if (pl.tw_off >= 0) tw[pxl * 20 + l16] = v;
+              else if (ok && !(pl.dbg & 1)) gout[(rowbase + ox) * ldo + co] = v;
+            }
+            if (pl.tw_off >= 0) {                              // lane (px = lane / 4, c4 = lane % 4) stores 16 bytes (see above)
+              __builtin_amdgcn_wave_barrier();
+              const int pxl = lane >> 2, c4 = lane & 3;
+              const float4 o = *reinterpret_cast<const float4*>(tw + pxl * 20 + 4 * c4);
+              const int mx = mx0 + pxl, ox = mx * osx;
+              if (my < My && oy < p.Ho && mx < Mx && ox + ph.ox < p.Wo && 4 * c4 < Cout && !(pl.dbg & 1))
+                *reinterpret_cast<float4*>(gout + (rowbase + ox) * ldo + 4 * c4) = o;
+              __builtin_amdgcn_wave_barrier();
             }
           }
           sm += __shfl_xor(sm, 16, 64);
@@ -2440,6 +2485,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   MPGAN_STAMP_VALUE(p, 3, st_contract);       // sum over this block's tiles: contraction + epilogue stores issued
   MPGAN_STAMP_VALUE(p, 4, st_tail);           // ... barrier, statistics rows, next patch's arrival + LDS stores, barrier
   MPGAN_STAMP_VALUE(p, 5, st_tiles);
+  MPGAN_STAMP_VALUE(p, 8, st_mfma);           // ... of which: residual prefetch + fragment reads + MFMAs (thread 0's wave)
   MPGAN_STAMP(p, 7);
   if (p.stats_acc && tid < Cout) {                   // one set of atomics per block, whatever its number of tiles
     long long* rep = p.stats_acc + (long)(blockIdx.x % (unsigned)p.acc_rep) * ACC_WORDS * Cout;
@@ -2629,7 +2675,16 @@ static bool patch_persist_plan(const GatherConv& p, const PatchLaunch& pl, Patch
     out->zero_page = zp;
   }
   const int nph = pl.merged ? p.nphase : 1;
-  const long bytes = ((long)out->w_floats + out->patch_floats + nph * 256 + 2 * p.Cin + 8 * p.Cin + 4) * 4;   // + fold scratch
+  long floats = (long)out->w_floats + out->patch_floats + nph * 256 + 2 * p.Cin + 8 * p.Cin + 4;   // + fold scratch
+  floats = (floats + 3) & ~3L;
+  // vector output path: one tile row of a wave (16 pixels x Cout) goes through LDS and leaves as 16-byte stores
+  const bool vec_out = (p.Cout % 4 == 0) && (p.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+  out->tw_off = -1;
+  if (vec_out) {
+    out->tw_off = (int)floats;
+    floats += 4 * 16 * (narrow ? 20 : 40);
+  }
+  const long bytes = floats * 4;
   if (bytes > 150 * 1024) return false;
   *smem = (int)bytes;
   *ntiles = pl.tiles_x * pl.tiles_y * p.N;

@@ -130,7 +130,7 @@ __device__ __forceinline__ void fdivmod(unsigned n, const FastDiv& f, unsigned& 
 // (s_memrealtime: the same time base on every CU) at its phase boundaries: what the in-kernel fixed cost of the
 // generator's short kernels consists of is then MEASURED (tools/kernel_phases.py), not inferred from what-if
 // builds.  In the product build the macros expand to nothing and GatherConv has no such field.
-constexpr int MPGAN_STAMP_SLOTS = 8;
+constexpr int MPGAN_STAMP_SLOTS = 12;
 #ifdef MPGAN_STAMPS
 struct StampCtx { unsigned long long* base; long launches, blocks; long next; };
 StampCtx& stamp_ctx();                      // host side (capi.cpp)

@@ -477,7 +477,7 @@ int mpgan_norm_bwd_apply_bf16(const void* g, int32_t g_f32, int32_t ldg, const v
 /* ---- development aids (no counterpart in the reference) ----------------------------------------------------
  * In-kernel phase stamps: a library built with `make STAMPS=1` records, for each of the next `launches`
  * gather-conv launches, the 100 MHz device clock at every block's phase boundaries into
- * buf[launch][blocks_per_launch][8] (uint64; blocks beyond the cap do not stamp).  The product build returns
+ * buf[launch][blocks_per_launch][12] (uint64; blocks beyond the cap do not stamp).  The product build returns
  * MPGAN_ERR_UNSUPPORTED.  mpgan_debug_stamps(NULL, 0, 0) switches stamping off. */
 int mpgan_debug_stamps(void* buf, int64_t launches, int64_t blocks_per_launch);
 int64_t mpgan_debug_stamps_used(void);

@@ -9,8 +9,9 @@ prints, in microseconds,
     ramp     95th-percentile block start after the first one (dispatch ramp, or the second round of blocks)
     K-stepped kernel:   prologue (first tile's loads -> LDS) | K loop | in-block split-K fold | epilogue = row->pixel
                         map + output stores issued + statistics rows
-    persistent patch:   weight staging | first patch | sum of contractions (+ stores issued) | sum of tile
-                        tails (barrier, statistics rows, next patch's arrival + LDS stores) | tiles per block
+    persistent patch:   weight staging | first patch | sum over the block's tiles of contraction + epilogue (of
+                        which: residual prefetch + fragment reads + MFMAs) | sum of tile tails (barrier, statistics
+                        rows, next patch's arrival + LDS stores) | tiles per block
     gap      this launch's last end -> the next stamped launch's first start (seam + any unstamped kernels
              between: BatchNorm finalize, the residual-sum pass)
 as medians over the blocks, averaged over the six U-Nets of the cascade.
@@ -30,7 +31,7 @@ os.environ.setdefault("MPGAN_SINGLE_STREAM", "1")
 import numpy as np      # noqa: E402
 import torch            # noqa: E402
 
-SLOTS, CAP = 8, 1024
+SLOTS, CAP = 12, 1024
 
 
 def main():
@@ -101,7 +102,7 @@ def main():
                      ep_stats=med(b[:, 7] - b[:, 5]), block=med(b[:, 7] - b[:, 0]))
         elif kind == 2:
             r.update(wstage=med(b[:, 1] - b[:, 0]), patch0=med(b[:, 2] - b[:, 1]), contract=med(b[:, 3]), tails=med(b[:, 4]),
-                     tiles=float(np.median(b[:, 5])), block=med(b[:, 7] - b[:, 0]))
+                     mfma=med(b[:, 8]), tiles=float(np.median(b[:, 5])), block=med(b[:, 7] - b[:, 0]))
         rows.append(r)
     for i, r in enumerate(rows):
         nxt = rows[i + 1]["start"] if i + 1 < nl else np.nan
@@ -123,8 +124,8 @@ def main():
                   f"epilogue {mean('epilogue'):4.1f} = map {mean('ep_map'):3.1f} + stores {mean('ep_store'):3.1f} + stats {mean('ep_stats'):3.1f}  "
                   f"(block {mean('block'):5.1f})")
         elif r0["kind"] == 2:
-            ph = (f"weights {mean('wstage'):4.1f}  patch0 {mean('patch0'):4.1f}  contract {mean('contract'):5.1f}  "
-                  f"tails {mean('tails'):5.1f}  tiles {mean('tiles'):3.0f}  (block {mean('block'):5.1f})")
+            ph = (f"weights {mean('wstage'):4.1f}  patch0 {mean('patch0'):4.1f}  contract {mean('contract'):5.1f} "
+                  f"(MFMA loops {mean('mfma'):4.1f})  tails {mean('tails'):4.1f}  tiles {mean('tiles'):3.0f}  (block {mean('block'):5.1f})")
         else:
             ph = "(no stamps in this kernel)"
         span, gap = mean("span"), mean("gap")

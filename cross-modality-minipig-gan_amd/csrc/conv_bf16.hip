@@ -420,9 +420,26 @@ static int hb_check(const GatherConv& p, const char* what) {
 // ---------------------------------------------------------------------------
 constexpr int HP_TZ = 4, HP_TY = 8, HP_TX = 8;                 // output pixels per tile: 256
 constexpr int HP_PY = HP_TY + 2, HP_PX = HP_TX + 2;
-constexpr int HP_PROWS = (HP_TZ + 2) * HP_PY * HP_PX;          // 600 patch rows of 128 B
-constexpr int HP_PATCH = HP_PROWS * HB_ROWB;                   // 76,800 B
+// LDS rows of the patch: row(z, y, x) = z * HP_PZ + y * HP_PX + x with the plane pitch padded from 100 to 104 rows
+// (= 8 mod 16).  A ds_read_b128 is served in four groups of 16 lanes, conflict-free when the 16 rows of a group are
+// distinct mod 16 (row parity = which half of the 64 banks, (row >> 1) & 7 = the XOR swizzle of the 16-byte chunk).
+// With tile rows in q = (z, y, x) order a group held four x-quads of four different y lines, 10 rows apart: up to
+// three lanes on one bank quarter (SQ_LDS_BANK_CONFLICT: 30 % of the conv2 backward-data launch's cycles, round 3).
+// Now a wave's 32 rows are 2 z x 2 y x 8 x and a lane group = all 8 x of both z planes at one y: rows b + x + 8 z.
+constexpr int HP_PZ = 104;
+constexpr int HP_PROWS = (HP_TZ + 2) * HP_PZ;                  // 624 patch rows of 128 B (24 of them padding)
+constexpr int HP_PATCH = HP_PROWS * HB_ROWB;                   // 79,872 B
 constexpr int HP_PPIECES = (HP_PROWS * 8 + 511) / 512;         // LDS-DMA instructions per thread for one patch: 10
+
+// Tile row (MFMA row li of wave sub-tile s = wm * 2 + tm) -> tile pixel (z, y, x), see above.  The lane groups of
+// ds_read_b128 are {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (+32 for the upper half-wave).
+__device__ __forceinline__ void hp_row_pixel(int s, int li, int& z, int& y, int& x) {
+  const bool g1 = (li >= 4 && li <= 11) || (li >= 16 && li <= 19) || li >= 28;
+  const int k = g1 ? (li < 12 ? li - 4 : (li < 20 ? li - 8 : li - 16)) : (li < 4 ? li : (li < 16 ? li - 8 : li - 12));
+  x = k & 7;
+  z = 2 * (s >> 2) + (k >> 3);
+  y = 2 * (s & 3) + (g1 ? 1 : 0);
+}
 
 template <int BN>
 struct HpTile {
@@ -472,11 +489,12 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
   const int pck = (tid & 7) ^ (((tid >> 3) >> 1) & 7);      // source chunk: (row >> 1) & 7 with row = (q >> 3); 64 i drops out
 #pragma unroll
   for (int i = 0; i < HP_PPIECES; ++i) {
-    const int pr = (tid >> 3) + 64 * i;
-    const int pz = pr / (HP_PY * HP_PX), rem = pr - pz * (HP_PY * HP_PX);
+    const int pr = (tid >> 3) + 64 * i;                       // LDS row (planes padded to HP_PZ rows: rem >= 100 is padding)
+    const int pz = pr / HP_PZ, rem = pr - pz * HP_PZ;
     const int py = rem / HP_PX, px = rem - py * HP_PX;
     const int iz = pz0 + pz, iy = py0 + py, ix = px0 + px;
-    const bool ok = pr < HP_PROWS && (unsigned)iz < (unsigned)Di && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+    const bool ok = pr < HP_PROWS && rem < HP_PY * HP_PX && (unsigned)iz < (unsigned)Di && (unsigned)iy < (unsigned)Hi &&
+                    (unsigned)ix < (unsigned)Wi;
     ppB[i] = ok ? (unsigned)((((n * Di + iz) * Hi + iy) * Wi + ix)) * (unsigned)ldi * 2u : 0xFFFFFFFFu;
   }
   const int r0 = tid >> 3, cc = tid & 7;
@@ -532,8 +550,9 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
   int abase[TM];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
-    const int q = wm * 64 + tm * 32 + li;
-    abase[tm] = ((q >> 6) * HP_PY + ((q >> 3) & 7)) * HP_PX + (q & 7);
+    int z, y, x;
+    hp_row_pixel(wm * 2 + tm, li, z, y, x);
+    abase[tm] = z * HP_PZ + y * HP_PX + x;
   }
   // B fragments as in the K-stepped kernel
   const int sw = (li >> 1) & 7;
@@ -568,7 +587,7 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) fb[set][tn] = lds_read_b128(Bs + tn * 32 * HB_ROWB + foff[s]);
     };
-    int delta = (tzo * HP_PY + tyo) * HP_PX + txo;
+    int delta = tzo * HP_PZ + tyo * HP_PX + txo;
     read_frags(delta, 0, 0, 0);
     for (int tap = 0; tap < 27; ++tap) {
       const int nstage = cstage == 2 ? 0 : cstage + 1;
@@ -579,7 +598,7 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
         if (nx == 3) { nx = 0; ny += 1; }
         if (ny == 3) { ny = 0; carry_y = 1; }
         const int sx = p.dstep[2] < 0 ? -1 : 1, sy = p.dstep[1] < 0 ? -1 : 1, sz = p.dstep[0] < 0 ? -1 : 1;
-        ndelta += sx * (nx - kx_) + sy * (ny - ky_) * HP_PX + sz * carry_y * (HP_PY * HP_PX);
+        ndelta += sx * (nx - kx_) + sy * (ny - ky_) * HP_PX + sz * carry_y * HP_PZ;
         kx_ = nx; ky_ = ny;
       }
 #pragma unroll
@@ -613,8 +632,10 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
   // ---- epilogue (as the K-stepped kernel's): fp32 image -> statistics -> bf16 rows ----
   float* img = reinterpret_cast<float*>(lds);
   int* rowpix = reinterpret_cast<int*>(lds + T::ROWPIX);
-  if (tid < HB_BM) {
-    const int oz = oz0 + (tid >> 6), oy = oy0 + ((tid >> 3) & 7), ox = ox0 + (tid & 7);
+  if (tid < HB_BM) {                                  // image row tid = sub-tile (tid >> 5), MFMA row (tid & 31)
+    int z, y, x;
+    hp_row_pixel(tid >> 5, tid & 31, z, y, x);
+    const int oz = oz0 + z, oy = oy0 + y, ox = ox0 + x;
     rowpix[tid] = (oz < ph.Mz && oy < ph.My && ox < ph.Mx) ? ((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox : -1;
   }
 #pragma unroll

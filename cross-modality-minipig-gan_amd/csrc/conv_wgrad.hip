@@ -1327,6 +1327,10 @@ static WgradPlan plan_wgrad(int Cd, int NC, long M) {
   long ns = want < maxsplit ? want : maxsplit;
   if (ns < 1) ns = 1;
   if (ns > 256) ns = 256;
+  // Short blocks (the generator's 32^2 level: 8 K-steps each) must not spill a few blocks into a second round of the
+  // 512 resident ones: 9 column tiles x 64 splits = 576 blocks ran as one full round + 64 stragglers (128 -> 128
+  // at 32^2: 82 us for a 31 us contraction).  Between one and two rounds, take one.
+  if (tiles * ns > 512 && tiles * ns < 1024 && tiles <= 512) ns = 512 / tiles;
   long chunk = (M + ns - 1) / ns;
   chunk = (chunk + WBK - 1) / WBK * WBK;
   ns = (M + chunk - 1) / chunk;

@@ -14,7 +14,7 @@ are arranged to be well-conditioned:
     (gather_patch3d_c16 / wgrad_patch3d_c16 at a size where persistent blocks walk several tiles, with ragged
     tiles) and all statistics rows;
   * dL/dy itself and the discriminator's gradients are held against the emulation by the sanity bound of
-    test_bf16_gpu.py (no further from the emulation than the emulation is from pure fp32, + 2e-2), the head
+    test_bf16_gpu.py (within twice the emulation's own distance to pure fp32, + 2e-2), the head
     (no cancellation yet) to 1e-2."""
 import pytest
 import torch
@@ -100,7 +100,7 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
     gy = captured["gy"].cpu()
     e_gy, cost_gy = _rel(gy, gy_emul), _rel(gy_emul, gy_f32)
     print(f"dL/dy: ours vs bf16 emulation {e_gy:.4f}; emulation vs fp32 oracle (precision cost) {cost_gy:.4f}")
-    assert e_gy <= cost_gy + 2e-2, (e_gy, cost_gy)
+    assert e_gy <= 2 * cost_gy + 2e-2, (e_gy, cost_gy)
     # teacher-forced: OUR upstream gradient through the oracle generator's backward -- in fp32 and, as the
     # yardstick, in fp64 (BatchNorm over the 9^3 x 2 values of the deepest level and PReLU-kink flips make single
     # tensors of ANY fp32 backward differ by percents): err(ours, f64) <= 3 err(oracle f32, f64) + eps,
@@ -164,7 +164,8 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
     print("bf16 emulation vs fp32 oracle (precision cost):", {k: round(e, 4) for k, e in cost.items()})
     for name, e in errs.items():
         tight = name.startswith("model_linear") or name == "model_conv.10.weight"
-        assert e <= (1e-2 if tight else cost[name] + 2e-2), (name, e, cost[name])
+        # (ours vs the emulation is one more draw of the perturbation whose size `cost` measures: within twice it)
+        assert e <= (1e-2 if tight else 2 * cost[name] + 2e-2), (name, e, cost[name])
 
     # ---------------- BatchNorm bookkeeping: G saw 2 forwards, D 3 ----------------
     sd_g, sd_d = ours.generator.state_dict(), ours.discriminator.state_dict()

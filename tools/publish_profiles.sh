@@ -1,24 +1,40 @@
 #!/bin/bash
-# Copy the summaries of the newest tools/collect_profiles.sh run (gpurun_out/r02/) into profiles/ (tracked).
+# Copy the summaries of the newest tools/collect_profiles.sh run (gpurun_out/r03/) into profiles/ (tracked).
 set -eo pipefail
 cd "$(dirname "$0")/.."
-P=gpurun_out/r02
+P=gpurun_out/r03
+T=r03
 newest() { ls -t $1 | head -1; }
-cp $P/bench_default.log profiles/r02_bench_default.log
-cp "$(newest "$P/stats_default/runc/*_kernel_stats.csv")" profiles/r02_bench_default_kernel_stats.csv
-cp "$(newest "$P/stats_single/runc/*_kernel_stats.csv")" profiles/r02_bench_single_stream_kernel_stats.csv
-cp "$(newest "$P/stats_gfwd/runc/*_kernel_stats.csv")" profiles/r02_gfwd_kernel_stats.csv
-cp "$(newest "$P/stats_c5_bf16/runc/*_kernel_stats.csv")" profiles/r02_c5_bf16_kernel_stats.csv
-cp "$(newest "$P/stats_c5_f32/runc/*_kernel_stats.csv")" profiles/r02_c5_f32_kernel_stats.csv
-cat $P/bench_c5_bf16.err $P/bench_c5_bf16.json > profiles/r02_bench_c5_bf16.log
-cat $P/bench_c5_f32.err $P/bench_c5_f32.json > profiles/r02_bench_c5_f32.log
-cp $P/layer_bench.txt profiles/r02_layer_bench.txt
-cp $P/layer_bench_bf16.txt profiles/r02_layer_bench_bf16.txt
-cp $P/phase_times.txt profiles/r02_phase_times.txt
-cp $P/variant_b_bs7.txt profiles/r02_variant_b_bs7.txt
-python3 tools/make_traffic.py "$(newest "$P/pmc_fetch/runc/*_counter_collection.csv")" "$(newest "$P/pmc_write/runc/*_counter_collection.csv")" profiles/traffic.json | head -4
-python3 tools/make_traffic.py "$(newest "$P/pmc_gfwd_fetch/runc/*_counter_collection.csv")" "$(newest "$P/pmc_gfwd_write/runc/*_counter_collection.csv")" profiles/r02_gfwd_traffic.json | head -3
-python3 tools/make_sq_summary.py "$(newest "$P/pmc_sq/runc/*_counter_collection.csv")" profiles/r02_pmc_dconv_sq_counters.csv
-if ls $P/pmc_c5_fetch/runc/*_counter_collection.csv > /dev/null 2>&1; then
+have() { ls $1 > /dev/null 2>&1; }
+if have "$P/bench_default.log"; then cp $P/bench_default.log profiles/${T}_bench_default.log; fi
+for tag in default single gfwd gbwd c5_bf16 vb; do
+  if have "$P/stats_$tag/runc/*_kernel_stats.csv"; then
+    name=$tag
+    [[ $tag == default ]] && name=bench_default
+    [[ $tag == single ]] && name=bench_single_stream
+    [[ $tag == vb ]] && name=variant_b
+    cp "$(newest "$P/stats_$tag/runc/*_kernel_stats.csv")" profiles/${T}_${name}_kernel_stats.csv
+  fi
+done
+for f in phase_times phase_times_gbwd_calls kernel_phases_gfwd kernel_phases_gbwd layer_bench layer_bench_bf16 variant_b_bs7 variant_b_families c5_gfwd_calls c5_gbwd_calls; do
+  if have "$P/$f.txt"; then grep -v "amdgpu.ids\|RuntimeWarning\|mean = lambda" $P/$f.txt > profiles/${T}_$f.txt; fi
+done
+if have "$P/bench_c5_bf16.json"; then cat $P/bench_c5_bf16.err $P/bench_c5_bf16.json > profiles/${T}_bench_c5_bf16.log; fi
+if have "$P/pmc_fetch/runc/*_counter_collection.csv"; then
+  python3 tools/make_traffic.py "$(newest "$P/pmc_fetch/runc/*_counter_collection.csv")" "$(newest "$P/pmc_write/runc/*_counter_collection.csv")" profiles/traffic.json | head -4
+fi
+if have "$P/pmc_gfwd_fetch/runc/*_counter_collection.csv"; then
+  python3 tools/make_traffic.py "$(newest "$P/pmc_gfwd_fetch/runc/*_counter_collection.csv")" "$(newest "$P/pmc_gfwd_write/runc/*_counter_collection.csv")" profiles/${T}_gfwd_traffic.json | head -3
+fi
+for tag in sq sq_g sq_bf16; do
+  if have "$P/pmc_$tag/runc/*_counter_collection.csv"; then
+    out=pmc_dconv_sq_counters
+    [[ $tag == sq_g ]] && out=pmc_generator_sq_counters
+    [[ $tag == sq_bf16 ]] && out=pmc_bf16_sq_counters
+    python3 tools/make_sq_summary.py "$(newest "$P/pmc_$tag/runc/*_counter_collection.csv")" profiles/${T}_$out.csv
+  fi
+done
+if have "$P/pmc_c5_fetch/runc/*_counter_collection.csv"; then
   python3 tools/make_traffic.py "$(newest "$P/pmc_c5_fetch/runc/*_counter_collection.csv")" "$(newest "$P/pmc_c5_write/runc/*_counter_collection.csv")" profiles/traffic_c5_bf16.json conv_bf16.hip | head -6
 fi
+ls profiles | grep $T

@@ -95,6 +95,11 @@ _ALWAYS_PACK = bool(os.environ.get("MPGAN_DBG_ALWAYS_PACK"))
 # same-address atomics make a 1-channel layer 8x slower (convt_quad: 28 -> 225 us).  Off unless MPGAN_ACC_STATS=1.
 _ACC_STATS = bool(os.environ.get("MPGAN_ACC_STATS"))
 _FUSE_DOWN = not os.environ.get("MPGAN_DBG_NO_FUSE_DOWN")   # ResidualUnit: first conv + residual conv as one launch
+# The discriminator's weight gradients run on the caller's stream, one after the other with the backward-data
+# launches (lane 0).  Both families are matrix-bound: side by side on two streams each only gets half the chip --
+# A/B on one box, 20-step benches: 55.25 / 55.27 ms (second stream) vs 55.18 / 55.35 ms (one stream) -- and the
+# per-launch figures the bench line reports are then contention-free.  MPGAN_D_WGRAD_SIDE=1 puts them back on lane 1.
+_D_WGRAD_LANE = 1 if os.environ.get("MPGAN_D_WGRAD_SIDE") else 0
 
 
 def same_geom(a, b) -> bool:
@@ -1354,7 +1359,7 @@ class DiscPlan:
             pro_in = lrelu(nbs[i - 1]) if i > 0 else None
             if want_param_grads:
                 emit_conv_wgrad(b, geoms[i], src, gas[i], gv(convs[i].weight), ws, pro=pro_in,
-                                dbias=gv(convs[i].bias), lane=1)
+                                dbias=gv(convs[i].bias), lane=_D_WGRAD_LANE)
             if i > 0:
                 # the gradient w.r.t. a_{i-1} = LeakyReLU(BN(z_{i-1})): the epilogue of this launch also forms the
                 # norm-backward sums of layer i-1, so that layer needs no reduce pass over g and z

@@ -147,8 +147,8 @@ def test_full_gd_step_at_c3_matches_oracle():
       * the discriminator's raw gradients: the 952,576-input head to 2e-3 against the fp32 oracle, every other
         tensor by the same fp64 yardstick (the fp64 oracle's D step, generator overwritten likewise);
       * BatchNorm running statistics and batch counters of both networks (G: 2 forwards, D: 3);
-      * the same step with the stream overlap switched off is bit-identical (side-stream G forward in
-        the D step, weight gradients beside the backward-data chain)."""
+      * the same step with the second stream switched off is bit-identical (the generator's weight gradients
+        beside its backward-data chain)."""
     from mpgan_amd import engine
     from mpgan_amd.gan import GAN
     from oracle import refmodel as R
@@ -168,7 +168,8 @@ def test_full_gd_step_at_c3_matches_oracle():
         ours.generator.load_state_dict(ref_sd_g)
         ours.discriminator.load_state_dict(ref_sd_d)
         ours.train()
-        ours.overlap_streams = not single_stream
+        # (the optional D-step overlap of G's forward on a high-priority stream -- off by default -- is covered at a
+        #  small size by tests/test_networks_gpu.py; here the second stream carries the generator's weight gradients)
         tap = _GradTap()
         ours.ddp = tap
         saved = engine._SINGLE_STREAM

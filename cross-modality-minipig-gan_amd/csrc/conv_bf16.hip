@@ -17,6 +17,7 @@
 #include "mpgan_common.h"
 #include "conv_geom.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace mpgan {
 
@@ -409,6 +410,477 @@ static int hb_check(const GatherConv& p, const char* what) {
 }
 
 // ---------------------------------------------------------------------------
+// Wide form of the K-stepped kernel (round 3): 128 x 64 per wave instead of 64 x 64.
+// What bounds the 256 x 128 tile above is the L2 -> LDS fill (66 GB/s per CU when the pieces are whole
+// 128-byte lines served by the XCD's L2) at 87 FLOP per staged byte, plus 3.4-6.1 vector instructions per MFMA for the
+// pieces' 64-bit source addresses and zero-page selects (profiles/r03_pmc_bf16_sq_counters.csv: matrix pipe busy
+// 34-43 %).  Here:
+//   * eight waves as WM x WN = 2 x 4 (256 x 256 tile, layers with >= 256 produced channels: 128 FLOP per staged byte)
+//     or 4 x 2 (512 x 128: 102), each wave 128 x 64: six ds_read_b128 per eight MFMAs instead of four per four;
+//   * K-steps of 64 like above (a piece must be a whole 128-byte line: a first version with 64-byte rows and three
+//     stages of K = 32 filled at 39 GB/s per CU, every line fetched twice as two half-lines a K-step apart), so only
+//     TWO stages fit (128 / 160 KiB): tile kt+2 is issued into the stage tile kt leaves, behind the barrier in front of
+//     kt's last k-sub, and has one K-step (2,048 matrix cycles) to land;
+//   * LDS-DMA through BUFFER loads (buffer_load_dwordx4 ... offen lds): the per-thread part of a piece's address is a
+//     32-bit voffset computed once, the tap / channel-chunk walk is the scalar soffset -- no vector instruction per
+//     piece in the pad-free form; a masked piece adds its tap offset and selects an out-of-range voffset (the
+//     hardware's bounds check returns zeros: no zero page, no 64-bit select);
+//   * epilogue without the fp32 tile image: statistics from the accumulators (lane = column), 32 x 64 blocks of a
+//     wave transposed through a wave-private LDS slab into 16-byte bf16 stores (128 contiguous bytes per row).
+// ---------------------------------------------------------------------------
+constexpr int HW_BK = 64;
+constexpr int HW_ROWB = 128;
+constexpr unsigned HW_OOB = 0xFFFF0000u;          // voffset of a masked piece: beyond every operand hb_check admits
+
+template <int WM, int WN, bool RING_ = true>
+struct HwTile {
+  static constexpr int BM = WM * 128, BN = WN * 64, NT = 512;
+  static constexpr int PR = NT / 8;                                   // rows one LDS-DMA instruction of every wave fills
+  static constexpr int APIECES = BM / PR, BPIECES = BN / PR;
+  static constexpr int STAGE = (BM + BN) * HW_ROWB;
+  static constexpr bool RING = RING_ && BM == BN;                     // five-unit ring (see the kernel) or two stages
+  static constexpr int UNIT = BM * HW_ROWB;
+  static constexpr int SMEM_LOOP = RING ? 5 * UNIT : 2 * STAGE;
+  static constexpr int EP_PITCH = 72;                                 // floats; rows r and r+4 half a bank sweep apart
+  static constexpr int EP_WAVE = 32 * EP_PITCH * 4;
+  static constexpr int EP_ROWPIX = 8 * EP_WAVE;
+  static constexpr int EP_PART = EP_ROWPIX + BM * 4;
+  static constexpr int SMEM_EPI = EP_PART + WM * 2 * BN * 4;
+  static constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
+  static_assert(WM * WN == 8 && BM % PR == 0 && BN % PR == 0, "eight waves; whole DMA passes");
+};
+
+#define BLDS16(rsrc, lptr, voff, soff)                                                                              \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(lptr), 16, (int)(voff), \
+                                           (int)(soff), 0, 0)
+
+template <int WM, int WN, bool MASK, bool RING = true>
+__global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const GatherConv p) {
+  using T = HwTile<WM, WN, RING>;
+  constexpr int BM = T::BM, BN = T::BN, PR = T::PR, TM = 4, TN = 2;
+  constexpr int NLOADS = T::APIECES + T::BPIECES;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const BlockId bid = conv_block_id(p);
+  const Phase& ph = p.ph[bid.phase];
+  const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
+  const long m0 = (long)bid.mt * BM;
+  const int n0 = bid.nt * BN;
+  const int stats_row = bid.phase * p.mtiles + bid.mt;
+  const int Cout = p.Cout;
+  if (m0 >= Mtot) {                                   // empty tile of a short phase (block-uniform)
+    if (p.stats && tid < BN && n0 + tid < Cout) {
+      float* row = p.stats + (long)stats_row * 2 * Cout;
+      row[n0 + tid] = 0.f;
+      row[Cout + n0 + tid] = 0.f;
+    }
+    return;
+  }
+  const int Cin = p.Cin, Di = p.Di, Hi = p.Hi, Wi = p.Wi, ldi = p.ldi;
+  const int ntaps = ph.nz * ph.ny * ph.nx;
+  const int nchunk = Cin / HW_BK;
+  const int nk = ntaps * nchunk;
+  const unsigned bytesA = (unsigned)((((long)p.N * Di * Hi * Wi - 1) * ldi + Cin) * 2);
+  const unsigned Ktot2 = (unsigned)(p.Kz * p.Ky * p.Kx * Cin) * 2u;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, (unsigned)Cout * Ktot2, 0x00020000);
+
+  // ---- this thread's pieces: rows r0 + 64*i, 16-byte chunk `ck` of the K-step (source-side swizzle) ----
+  const int r0 = tid >> 3, cc = tid & 7;
+  const int ck = cc ^ ((r0 >> 1) & 7);
+  unsigned voffA[T::APIECES];           // byte offset of (row pixel, channel 8*ck)
+  unsigned tmask[MASK ? T::APIECES : 1];
+#pragma unroll
+  for (int i = 0; i < T::APIECES; ++i) {
+    unsigned m = (unsigned)m0 + r0 + PR * i;
+    const bool live = m < (unsigned)Mtot;
+    m = live ? m : (unsigned)Mtot - 1u;               // clamped rows gather a real pixel; never stored
+    unsigned q, umx, umy, umz;
+    fdivmod(m, ph.fMx, q, umx);
+    fdivmod(q, ph.fMy, q, umy);
+    fdivmod(q, ph.fMz, q, umz);
+    const int bz = (int)umz * p.istride[0], by = (int)umy * p.istride[1], bx = (int)umx * p.istride[2];
+    voffA[i] = (unsigned)((((int)q * Di + bz) * Hi + by) * Wi + bx) * (unsigned)ldi * 2u + (unsigned)ck * 16u;
+    if constexpr (MASK) {
+      unsigned mk = 0;
+      int j = 0;
+      for (int jz = 0; jz < ph.nz; ++jz) {
+        const bool okz = (unsigned)(bz + ph.dz0 + p.dstep[0] * jz) < (unsigned)Di;
+        for (int jy = 0; jy < ph.ny; ++jy) {
+          const bool oky = okz && (unsigned)(by + ph.dy0 + p.dstep[1] * jy) < (unsigned)Hi;
+          for (int jx = 0; jx < ph.nx; ++jx, ++j) {
+            const bool ok = oky && (unsigned)(bx + ph.dx0 + p.dstep[2] * jx) < (unsigned)Wi;
+            mk |= (ok ? 1u : 0u) << j;
+          }
+        }
+      }
+      tmask[i] = live ? mk : 0u;
+    }
+  }
+  unsigned voffB[T::BPIECES];
+#pragma unroll
+  for (int i = 0; i < T::BPIECES; ++i) {
+    int co = n0 + r0 + PR * i;
+    co = co < Cout ? co : Cout - 1;                   // clamped columns are computed and dropped
+    voffB[i] = (unsigned)co * Ktot2 + (unsigned)ck * 16u;
+  }
+  const int dbg = g_hb_dbg;
+
+  // K order: channel-chunk major, taps inner.  The walk is wave-uniform and INCREMENTAL: the gathered operand's byte
+  // offset and the weight offset of the next tap are the previous ones plus one of three precomputed steps (x, x-wrap,
+  // y-wrap) -- a handful of scalar registers instead of the phase's whole tap geometry (recomputing the offsets from
+  // (jz, jy, jx) had the compiler re-load the geometry from the kernel arguments inside the loop, behind an
+  // lgkmcnt(0) that also waits for the fragment reads just issued).
+  const int aX = p.dstep[2] * ldi * 2;
+  const int aY = p.dstep[1] * Wi * ldi * 2 - (ph.nx - 1) * aX;
+  const int aZ = p.dstep[0] * Hi * Wi * ldi * 2 - (ph.ny - 1) * p.dstep[1] * Wi * ldi * 2 - (ph.nx - 1) * aX;
+  const int wX = p.kstep[2] * Cin * 2;
+  const int wY = p.kstep[1] * p.Kx * Cin * 2 - (ph.nx - 1) * wX;
+  const int wZ = p.kstep[0] * p.Ky * p.Kx * Cin * 2 - (ph.ny - 1) * p.kstep[1] * p.Kx * Cin * 2 - (ph.nx - 1) * wX;
+  const int delta0 = ((ph.dz0 * Hi + ph.dy0) * Wi + ph.dx0) * ldi * 2;   // >= 0 when every tap is in range (!MASK)
+  const int woff0 = ((ph.kz0 * p.Ky + ph.ky0) * p.Kx + ph.kx0) * Cin * 2;
+  const int nx = ph.nx, ny = ph.ny;
+  const int wbase = __builtin_amdgcn_readfirstlane(8 * wid * HW_ROWB);
+  // two cursors: the gathered operand's tiles (A) run one K-step ahead of the weights' (B) in the ring form
+  int itapA = 0, jxA = 0, jyA = 0, deltaB = delta0, ciA = 0;
+  int itapB = 0, jxB = 0, jyB = 0, woffB = woff0, ciB = 0;
+  auto issueA = [&](int unit, auto part) {             // part: 0 = all pieces, 1 / 2 = first / second half of them
+    constexpr int P = decltype(part)::value;
+    constexpr int I0 = P == 2 ? T::APIECES / 2 : 0, I1 = P == 1 ? T::APIECES / 2 : T::APIECES;
+    char* As = lds + unit + wbase;
+    if (!(dbg & 16)) {
+#pragma unroll
+      for (int i = I0; i < I1; ++i) {
+        if constexpr (MASK) {
+          const unsigned v = ((tmask[i] >> itapA) & 1u) ? voffA[i] + (unsigned)deltaB : HW_OOB;
+          BLDS16(rsA, As + PR * i * HW_ROWB, v, ciA);
+        } else {
+          BLDS16(rsA, As + PR * i * HW_ROWB, voffA[i], deltaB + ciA);
+        }
+      }
+    }
+    if constexpr (P != 1) {                             // the cursor moves on behind a tile's last piece
+      itapA += 1;
+      jxA += 1;
+      int inc = aX;
+      if (jxA == nx) {
+        jxA = 0;
+        jyA += 1;
+        inc = aY;
+        if (jyA == ny) { jyA = 0; inc = aZ; }
+      }
+      deltaB += inc;
+      if (itapA == ntaps) { itapA = 0; jxA = 0; jyA = 0; deltaB = delta0; ciA += HW_BK * 2; }
+    }
+  };
+  auto issueB = [&](int unit, auto part) {
+    constexpr int P = decltype(part)::value;
+    constexpr int I0 = P == 2 ? T::BPIECES / 2 : 0, I1 = P == 1 ? T::BPIECES / 2 : T::BPIECES;
+    char* Bs = lds + unit + wbase;
+    if (!(dbg & 16)) {
+#pragma unroll
+      for (int i = I0; i < I1; ++i) BLDS16(rsB, Bs + PR * i * HW_ROWB, voffB[i], woffB + ciB);
+    }
+    if constexpr (P != 1) {
+      itapB += 1;
+      jxB += 1;
+      int inc = wX;
+      if (jxB == nx) {
+        jxB = 0;
+        jyB += 1;
+        inc = wY;
+        if (jyB == ny) { jyB = 0; inc = wZ; }
+      }
+      woffB += inc;
+      if (itapB == ntaps) { itapB = 0; jxB = 0; jyB = 0; woffB = woff0; ciB += HW_BK * 2; }
+    }
+  };
+  constexpr std::integral_constant<int, 0> ALL{};
+  constexpr std::integral_constant<int, 1> HALF0{};
+  constexpr std::integral_constant<int, 2> HALF1{};
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment addresses: lane (li, lh) of k-sub s takes chunk 2s+lh of its row, stored at chunk ^ ((row>>1)&7)
+  const int sw = (li >> 1) & 7;
+  int foff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) foff[s] = ((2 * s + lh) ^ sw) * 16;
+  const int arow = (wm * 128 + li) * HW_ROWB;
+  const int brow = (wn * 64 + li) * HW_ROWB;
+  const unsigned lds_base = lds_addr(lds);
+  i32x4 fa[2][TM], fb[2][TN];
+  auto read_frags = [&](int unitA, int unitB, int s, int set) {
+    const unsigned As = lds_base + unitA + arow + foff[s];
+    const unsigned Bs = lds_base + unitB + brow + foff[s];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) fa[set][tm] = lds_read_b128(As + tm * 32 * HW_ROWB);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) fb[set][tn] = lds_read_b128(Bs + tn * 32 * HW_ROWB);
+  };
+  auto mfmas = [&](int set) {
+    if (!(dbg & 2))
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][tm]),
+                                                                __builtin_bit_cast(bf16x8, fb[set][tn]), acc[tm][tn], 0, 0, 0);
+  };
+  if constexpr (T::RING) {
+    // 256 x 256: five units of 32 KiB (the whole LDS) in a ring, A_0 B_0 A_1 B_1 A_2 | B_2 A_3 B_3 ... : unit u lives in
+    // slot u % 5.  A K-step's barrier (in front of its last k-sub's MFMAs, as above) frees BOTH of its units; behind
+    // it the weights of step kt+2 go into the slot A_kt leaves and the gathered tile of step kt+3 into B_kt's.  The
+    // gathered operand -- the one that misses the L2 -- so has two K-steps to land and the L2-resident weights one,
+    // 1.5 tiles are in flight instead of the single one two whole stages allow (which left the fill engine idle for
+    // a load latency per K-step: fill alone 2.12 ms, contraction alone 2.41, together 3.61 on D.conv3's forward),
+    // and every piece is still a whole 128-byte line.  vmcnt: in front of step kt+1 everything but the newest
+    // gathered tile (A_kt+2) must have landed.
+    constexpr int U = T::UNIT, AP = T::APIECES, BP = T::BPIECES;
+    issueA(0, ALL);
+    issueB(U, ALL);
+    if (nk > 1) { issueA(2 * U, ALL); issueB(3 * U, ALL); }
+    if (nk > 2) issueA(4 * U, ALL);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AP + BP) : "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");             // A_0, B_0 landed
+    int ua = 0, ub = U;                                 // byte offsets of the units of step kt
+    if (!(dbg & 4)) read_frags(ua, ub, 0, 0);
+    // The pieces of a tile are not issued in one burst behind the barrier (an LDS-DMA instruction costs its wave
+    // 60-185 issue cycles, and both waves of a SIMD pass the barrier together): two pieces per k-sub -- the weights of
+    // step kt+2 behind the barrier and under the next k-sub, the gathered tile of step kt+3 under the two after that.
+    bool pend_b = false, pend_a = false;
+    int unit_b = 0, unit_a = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      int na = ua + 2 * U, nb = ub + 2 * U;
+      na = na >= 5 * U ? na - 5 * U : na;
+      nb = nb >= 5 * U ? nb - 5 * U : nb;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int set = s & 1;
+        lds_wait<TM, TN>(fa[set], fb[set]);
+        if (s < 3) {
+          if (!(dbg & 4)) read_frags(ua, ub, s + 1, set ^ 1);
+          if (s == 0 && pend_b) issueB(unit_b, HALF1);
+          if (s == 1 && pend_a) issueA(unit_a, HALF0);
+          if (s == 2 && pend_a) issueA(unit_a, HALF1);
+        } else if (kt + 1 < nk) {
+          if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0) ; tail: the last tile" ::: "memory");      // (tools/check_isa.py)
+          asm volatile("s_barrier" ::: "memory");
+          pend_b = kt + 2 < nk;
+          pend_a = kt + 3 < nk;
+          unit_b = ua;
+          unit_a = ub;
+          if (pend_b) issueB(unit_b, HALF0);
+          if (!(dbg & 4)) read_frags(na, nb, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(set);
+      }
+      ua = na;
+      ub = nb;
+    }
+  } else {
+    // Two stages: tile kt is consumed from stage kt & 1 while tile kt+1 is in flight into the other.  The K-step's one
+    // barrier sits in front of its LAST k-sub's MFMAs: this wave has then read all of stage kt & 1 into registers, so
+    // behind the barrier (tile kt+1 landed for every wave, the stage free for every wave) tile kt+2's DMAs are issued
+    // into it and the first fragments of tile kt+1 are read, all UNDER those MFMAs.
+    constexpr int SA = BM * HW_ROWB;                    // a stage: BM rows of A, then BN rows of B
+    issueA(0, ALL);
+    issueB(SA, ALL);
+    if (nk > 1) { issueA(T::STAGE, ALL); issueB(T::STAGE + SA, ALL); }
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");             // tile 0 landed
+    if (!(dbg & 4)) read_frags(0, SA, 0, 0);
+    int cst = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nst = cst ? 0 : T::STAGE;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int set = s & 1;
+        lds_wait<TM, TN>(fa[set], fb[set]);
+        if (s < 3) {
+          if (!(dbg & 4)) read_frags(cst, cst + SA, s + 1, set ^ 1);
+        } else if (kt + 1 < nk) {
+          // the only DMAs of this wave still in flight are tile kt+1's
+          asm volatile("s_waitcnt vmcnt(0) ; tail: two stages, the one tile in flight" ::: "memory");   // (tools/check_isa.py)
+          asm volatile("s_barrier" ::: "memory");
+          if (kt + 2 < nk) { issueA(cst, ALL); issueB(cst + SA, ALL); }
+          if (!(dbg & 4)) read_frags(nst, nst + SA, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(set);
+      }
+      cst = nst;
+    }
+  }
+  asm volatile("s_barrier" ::: "memory");             // all fragment reads done: the LDS becomes the epilogue's
+  if (dbg & 32) return;                               // (what-if: no epilogue)
+
+  // ---- epilogue ----
+  int* rowpix = reinterpret_cast<int*>(lds + T::EP_ROWPIX);
+  if (tid < BM) {
+    const unsigned m = (unsigned)m0 + tid;            // one thread per row
+    int pix = -1;
+    if (m < (unsigned)Mtot) {
+      unsigned q, umx, umy, umz;
+      fdivmod(m, ph.fMx, q, umx);
+      fdivmod(q, ph.fMy, q, umy);
+      fdivmod(q, ph.fMz, q, umz);
+      const int oz = (int)umz * p.ostride[0] + ph.oz, oy = (int)umy * p.ostride[1] + ph.oy,
+                ox = (int)umx * p.ostride[2] + ph.ox;
+      if (oz < p.Do && oy < p.Ho && ox < p.Wo) pix = (((int)q * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
+    }
+    rowpix[tid] = pix;
+  }
+  float bv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + wn * 64 + tn * 32 + li;
+    bv[tn] = (p.bias && col < Cout) ? p.bias[col] : 0.f;
+  }
+  __syncthreads();
+  if (p.stats) {
+    // column sums of z = acc + bias over the rows that own an output pixel, from the accumulators: a lane holds
+    // column li of rows (r&3) + 8(r>>2) + 4 lh of each 32-row block
+    float* part = reinterpret_cast<float*>(lds + T::EP_PART);          // [WM][2][BN]
+    float sm[TN] = {0.f, 0.f}, sq[TN] = {0.f, 0.f};
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int4 rp = *reinterpret_cast<const int4*>(rowpix + wm * 128 + tm * 32 + 8 * g + 4 * lh);
+        const int ok[4] = {rp.x >= 0, rp.y >= 0, rp.z >= 0, rp.w >= 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const float v = ok[e] ? acc[tm][tn][4 * g + e] + bv[tn] : 0.f;
+            sm[tn] += v;
+            sq[tn] = fmaf(v, v, sq[tn]);
+          }
+      }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      sm[tn] += __shfl_xor(sm[tn], 32, 64);
+      sq[tn] += __shfl_xor(sq[tn], 32, 64);
+      if (lh == 0) {
+        part[(wm * 2 + 0) * BN + wn * 64 + tn * 32 + li] = sm[tn];
+        part[(wm * 2 + 1) * BN + wn * 64 + tn * 32 + li] = sq[tn];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < Cout) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        a += part[(w * 2 + 0) * BN + tid];
+        b += part[(w * 2 + 1) * BN + tid];
+      }
+      float* row = p.stats + (long)stats_row * 2 * Cout;
+      row[n0 + tid] = a;
+      row[Cout + n0 + tid] = b;
+    }
+  }
+  // 32 x 64 blocks of the wave's tile through its private slab: lane -> (row, 8-channel chunk), 16-byte bf16 stores
+  float* slab = reinterpret_cast<float*>(lds + wid * T::EP_WAVE);
+  char* goutb = reinterpret_cast<char*>(p.out);
+  const int cbase = n0 + wn * 64;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * T::EP_PITCH + tn * 32 + li] = acc[tm][tn][r] + bv[tn];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = lane + 64 * j, row = idx >> 3, ch = idx & 7;
+      const int pix = rowpix[wm * 128 + tm * 32 + row];
+      const float4 v0 = *reinterpret_cast<const float4*>(slab + row * T::EP_PITCH + ch * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(slab + row * T::EP_PITCH + ch * 8 + 4);
+      if (pix < 0 || cbase + ch * 8 >= Cout) continue;
+      bf16x8 o;
+      o[0] = (__bf16)v0.x; o[1] = (__bf16)v0.y; o[2] = (__bf16)v0.z; o[3] = (__bf16)v0.w;
+      o[4] = (__bf16)v1.x; o[5] = (__bf16)v1.y; o[6] = (__bf16)v1.z; o[7] = (__bf16)v1.w;
+      *reinterpret_cast<bf16x8*>(goutb + ((long)pix * p.ldo + cbase + ch * 8) * 2) = o;
+    }
+  }
+}
+
+// Which K-stepped form serves a gather: 0 = 256 x 128/64 tile (gather_conv_bf16_kernel), 1 = 256 x 256, 2 = 512 x 128
+// (gather_conv_bf16_wide_kernel).  The wide forms need enough tiles to fill the chip twice over; MPGAN_DBG_HB_WIDE=0
+// turns them off (A/B runs).  mpgan_conv_stats_rows_bf16 follows the same choice (rows = phases x m-tiles).
+static int g_hw_min_blocks = 1024;
+static int hw_choice(const GatherConv& p) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("MPGAN_DBG_HB_WIDE");
+    forced = e ? atoi(e) : -1;
+  }
+  if (forced == 0) return 0;
+  if (p.Cin % HW_BK != 0 || p.Cout % 8 != 0) return 0;
+  if ((long)p.N * p.Di * p.Hi * p.Wi * p.ldi * 2 >= (long)HW_OOB || (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 2 >= (long)HW_OOB)
+    return 0;
+  const long maxM = max_phase_pixels(p);
+  if (p.Cout > 128) {
+    const long blocks = ((maxM + 255) / 256) * ((p.Cout + 255) / 256) * p.nphase;
+    return (blocks >= g_hw_min_blocks || forced == 1) ? 1 : 0;
+  }
+  if (p.Cout > 64) {
+    const long blocks = ((maxM + 511) / 512) * p.nphase;
+    return (blocks >= g_hw_min_blocks || forced == 2) ? 2 : 0;
+  }
+  return 0;
+}
+static int hw_bm(int choice) { return choice == 1 ? 256 : (choice == 2 ? 512 : HB_BM); }
+
+template <int WM, int WN, bool MASK, bool RING = true>
+static int hw_launch(const GatherConv& p, long maxM, hipStream_t st) {
+  auto kern = gather_conv_bf16_wide_kernel<WM, WN, MASK, RING>;
+  using T = HwTile<WM, WN, RING>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
+    if (e != hipSuccess) {
+      set_error("gather_conv_bf16_wide: hipFuncSetAttribute(%d): %s", T::SMEM, hipGetErrorString(e));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  static int dbg_set = -1;
+  if (dbg_set < 0) {
+    const char* e = getenv("MPGAN_DBG_HB");
+    dbg_set = e ? atoi(e) : 0;
+    if (dbg_set) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hb_dbg), &dbg_set, sizeof(int));
+  }
+  GatherConv q = p;
+  q.mtiles = (int)((maxM + T::BM - 1) / T::BM);
+  q.ntiles = (p.Cout + T::BN - 1) / T::BN;
+  q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 2 > (3L << 20) ? 1 : 0;
+  q.ksplit = 1;
+  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
+  hipLaunchKernelGGL(kern, grid, dim3(512), T::SMEM, st, q);
+  return check_launch("gather_conv_bf16_wide");
+}
+
+// ---------------------------------------------------------------------------
 // Patch form for stride-1 3x3x3 gathers (D.conv2 forward and backward-data at config C5: 64 -> 128 and 128 -> 64
 // channels, 27 taps).  The K-stepped kernel above re-stages every input pixel once per tap (27 x) and is bound by
 // the L2 -> LDS fill rate.  Here a block owns a 4 x 8 x 8 block of output pixels: the 6 x 10 x 10
@@ -746,6 +1218,11 @@ static int hb_dispatch(const GatherConv& p, hipStream_t st, const char* what) {
   if (maxM == 0) return MPGAN_OK;
   if (hp_ok(p)) return p.Cout > 64 ? hp_launch<128>(p, st) : hp_launch<64>(p, st);
   const bool mask = !hb_all_in_range(p);
+  const int wide = hw_choice(p);
+  static const bool no_ring = getenv("MPGAN_DBG_HB_NO_RING") != nullptr;     // development: two whole stages instead
+  if (wide == 1 && no_ring) return mask ? hw_launch<2, 4, true, false>(p, maxM, st) : hw_launch<2, 4, false, false>(p, maxM, st);
+  if (wide == 1) return mask ? hw_launch<2, 4, true>(p, maxM, st) : hw_launch<2, 4, false>(p, maxM, st);
+  if (wide == 2) return mask ? hw_launch<4, 2, true>(p, maxM, st) : hw_launch<4, 2, false>(p, maxM, st);
   static int nw = 0;
   if (!nw) {
     const char* e = getenv("MPGAN_DBG_HB_NW");      // development: force four or eight waves per block
@@ -1171,6 +1648,15 @@ static inline int hb_ew_blocks(long total) {
 
 using namespace mpgan;
 
+// Development / test hook: the number of blocks from which the wide K-stepped forms serve a gather (default 1024;
+// 1 = always where the channel counts allow, a huge value = never).  Returns the previous value.  Statistics-row
+// counts follow the choice: set it before sizing partial buffers, not between a sizing call and its launch.
+extern "C" int32_t mpgan_debug_bf16_wide_min_blocks(int32_t blocks) {
+  const int old = g_hw_min_blocks;
+  if (blocks > 0) g_hw_min_blocks = blocks;
+  return old;
+}
+
 extern "C" int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g) {
   if (check_geom(g)) return -1;
   GatherConv p{};
@@ -1180,11 +1666,13 @@ extern "C" int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g) {
     const HpGrid tg = hp_grid(p);
     return p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x;
   }
-  return (int32_t)((max_phase_pixels(p) + HB_BM - 1) / HB_BM) * p.nphase;
+  p.ldi = p.Cin;
+  const int bm = hw_bm(g->cin % HB_BK == 0 ? hw_choice(p) : 0);
+  return (int32_t)((max_phase_pixels(p) + bm - 1) / bm) * p.nphase;
 }
 
 // Which bf16 kernel serves this geometry (profiling labels): 0 = K-stepped gather_conv_bf16_kernel,
-// 1 = gather_patch_bf16_kernel (stride-1 3x3x3 gathers).
+// 1 = gather_patch_bf16_kernel (stride-1 3x3x3 gathers), 2 / 3 = gather_conv_bf16_wide_kernel 256 x 256 / 512 x 128.
 extern "C" int32_t mpgan_conv_variant_bf16(const mpgan_conv_geom* g, int32_t backward_data) {
   if (check_geom(g)) return -1;
   GatherConv p{};
@@ -1195,7 +1683,10 @@ extern "C" int32_t mpgan_conv_variant_bf16(const mpgan_conv_geom* g, int32_t bac
     if (!g->transposed) build_transposed(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
     else build_forward(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
   }
-  return (p.Cin % HB_BK == 0 && hp_ok(p)) ? 1 : 0;
+  if (p.Cin % HB_BK == 0 && hp_ok(p)) return 1;
+  p.ldi = p.Cin;
+  const int wide = p.Cin % HB_BK == 0 ? hw_choice(p) : 0;
+  return wide ? 1 + wide : 0;
 }
 
 extern "C" int mpgan_conv_forward_bf16(const mpgan_conv_geom* g, const void* x, int32_t ldx, const void* w_packed,

@@ -1378,8 +1378,12 @@ def _bf16_kernel_name(g: ConvGeom, backward_data: bool) -> str:
     """rocprofv3's name of the bf16 kernel that serves this layer (labels of bench.py's probe)."""
     gc = g.c()
     bn = 128 if (g.cin if backward_data else g.cout) > 64 else 64
-    if lib().mpgan_conv_variant_bf16(C.byref(gc), int(backward_data)) == 1:
+    v = lib().mpgan_conv_variant_bf16(C.byref(gc), int(backward_data))
+    if v == 1:
         return f"gather_patch_bf16_kernel<{bn}>"
+    if v in (2, 3):
+        masked = "true" if backward_data or any(g.pad) else "false"
+        return f"gather_conv_bf16_wide_kernel<{'2, 4' if v == 2 else '4, 2'}, {masked}>"
     return f"gather_conv_bf16_kernel<{bn}, {'true' if backward_data else 'false'}, 8>"
 
 

@@ -433,7 +433,8 @@ int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g);
 int mpgan_conv_forward_bf16(const mpgan_conv_geom* g, const void* x, int32_t ldx, const void* w_packed,
                             const float* bias, float* stats_partials, void* y, int32_t ldy, void* stream);
 /* Which bf16 kernel serves this geometry (profiling labels only): 0 = the K-stepped gather kernel,
- * 1 = the patch form for stride-1 3x3x3 gathers (D.conv2 forward / backward-data at config C5). */
+ * 1 = the patch form for stride-1 3x3x3 gathers (D.conv2 forward / backward-data at config C5),
+ * 2 / 3 = the wide K-stepped form, 256 x 256 / 512 x 128 tiles (D.conv3 / D.conv4 at config C5). */
 int32_t mpgan_conv_variant_bf16(const mpgan_conv_geom* g, int32_t backward_data);
 
 /* dx (bf16) = conv_backward_data(dy (bf16)); w_packed_bwd: bf16, layout 1 of mpgan_pack_weights_bf16. */
@@ -482,6 +483,10 @@ int mpgan_norm_bwd_apply_bf16(const void* g, int32_t g_f32, int32_t ldg, const v
 int mpgan_debug_stamps(void* buf, int64_t launches, int64_t blocks_per_launch);
 int64_t mpgan_debug_stamps_used(void);
 int32_t mpgan_debug_clock_khz(void);
+/* Blocks from which the wide (128 x 64 per wave) forms of the bf16 K-stepped kernel serve a gather (default 1024;
+ * tests set 1 to run small shapes through them).  Returns the previous value; blocks <= 0 only reads it.  The
+ * statistics-row count of mpgan_conv_stats_rows_bf16 follows the choice. */
+int32_t mpgan_debug_bf16_wide_min_blocks(int32_t blocks);
 
 #ifdef __cplusplus
 }

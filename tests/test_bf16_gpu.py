@@ -123,6 +123,58 @@ def test_conv_backward_data_and_weight_bf16(n, spatial, cin, cout, k, s, p):
             assert (e <= 1e-4 * wr.grad.abs() + 1e-4 * wr.grad.abs().max()).all(), e.max().item()
 
 
+WIDE_CASES = [  # shapes of CASES' classes that the wide (128 x 64 per wave) forms can serve
+    (2, (22, 20), 128, 256, 4, 2, 0),         # forward: 256 x 256 tiles, ragged last tile; backward-data: 512 x 128, 4 phases
+    (1, (10, 12, 10), 128, 256, 4, 2, 0),     # 3-D: 64 taps forward, 8 phases x 8 taps backward
+    (2, (12, 14), 128, 264, 3, 1, 1),         # padded (masked pieces read out of range), ragged second channel tile
+    (3, (21, 19), 64, 128, 3, 1, 1),          # forward 512 x 128 masked, more than one m-tile
+    (2, (9, 30), 256, 256, 3, 1, 0),          # backward-data on 256 x 256 tiles (masked), 8 channel chunks of 32
+]
+
+
+@pytest.fixture
+def wide_forms():
+    """Run small shapes through gather_conv_bf16_wide_kernel (it otherwise serves launches of >= 1024 blocks)."""
+    from mpgan_amd._lib import lib
+    old = lib().mpgan_debug_bf16_wide_min_blocks(1)
+    yield
+    lib().mpgan_debug_bf16_wide_min_blocks(old)
+
+
+@pytest.mark.parametrize("n,spatial,cin,cout,k,s,p", WIDE_CASES, ids=lambda v: str(v))
+def test_wide_forms_forward_bf16(wide_forms, n, spatial, cin, cout, k, s, p):
+    from mpgan_amd import ops
+    from mpgan_amd._lib import lib
+    import ctypes as C
+    g = _geom(n, spatial, cin, cout, k, s, p)
+    gc = g.c()
+    assert lib().mpgan_conv_variant_bf16(C.byref(gc), 0) in (2, 3)
+    test_conv_forward_bf16_exact_and_random(n, spatial, cin, cout, k, s, p)
+
+
+@pytest.mark.parametrize("n,spatial,cin,cout,k,s,p", WIDE_CASES[:2] + WIDE_CASES[4:], ids=lambda v: str(v))
+def test_wide_forms_backward_data_bf16(wide_forms, n, spatial, cin, cout, k, s, p):
+    from mpgan_amd._lib import lib
+    import ctypes as C
+    g = _geom(n, spatial, cin, cout, k, s, p)
+    gc = g.c()
+    assert lib().mpgan_conv_variant_bf16(C.byref(gc), 1) in (2, 3)
+    test_conv_backward_data_and_weight_bf16(n, spatial, cin, cout, k, s, p)
+
+
+def test_wide_forms_serve_config_c5_by_default():
+    """D.conv3 / D.conv4 at 128^3 bs 4: forward and backward-data of conv3, backward-data of conv4 on the wide forms."""
+    from mpgan_amd import ops
+    from mpgan_amd._lib import lib
+    import ctypes as C
+    for (cin, cout, e), want in (((128, 256, 124), (2, 3)), ((256, 256, 61), (None, 2))):
+        g = ops.ConvGeom(4, (e, e, e), cin, cout, (4, 4, 4), (2, 2, 2), (0, 0, 0))
+        gc = g.c()
+        for bwd in (0, 1):
+            if want[bwd] is not None:
+                assert lib().mpgan_conv_variant_bf16(C.byref(gc), bwd) == want[bwd], (cin, cout, e, bwd)
+
+
 @pytest.mark.parametrize("spatial", [(18, 20), (9, 10, 11)], ids=str)
 def test_first_layer_thin_kernels_bf16(spatial):
     """Discriminator.model_conv[0] (1 -> 64, k3): fp32 image -> bf16 raw output with fused statistics, its

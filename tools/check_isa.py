@@ -18,6 +18,10 @@ KERNELS = {   # mangled-name fragment -> (min MFMAs, min LDS-DMA loads) in the K
     "gather_conv_bf16_kernelILi64ELb1ELi8": (8, 5),
     "gather_patch_bf16_kernelILi128": (16, 2),            # patch form: weights only stream inside the tap loop
     "gather_patch_bf16_kernelILi64": (8, 1),
+    "gather_conv_bf16_wide_kernelILi2ELi4ELb0": (32, 8),  # wide form: 128 x 64 per wave, two stages
+    "gather_conv_bf16_wide_kernelILi2ELi4ELb1": (32, 8),
+    "gather_conv_bf16_wide_kernelILi4ELi2ELb0": (32, 10),
+    "gather_conv_bf16_wide_kernelILi4ELi2ELb1": (32, 10),
     "wgrad_bf16_kernelILi4": (32, 12),
     "wgrad_bf16_kernelILi8": (16, 6),
 }
@@ -32,17 +36,41 @@ def main(path):
             bad.append(f"{frag}: kernel not found in {path}")
             continue
         body = text[m.end():text.index(".Lfunc_end", m.end())].split("\n")
-        # the K loop = the span between the counted wait and the last MFMA that follows it
-        idx = [i for i, l in enumerate(body) if re.search(r"s_waitcnt vmcnt\((?!0\))\d+\)", l)]
-        if not idx:
+        # the K loop = the blocks LLVM annotates as members of the innermost loop that holds the MFMAs (block PLACEMENT is
+        # not execution order: conditional issue blocks may sit behind the MFMAs they precede)
+        blocks, cur = [], None
+        for l in body:
+            mm = re.match(r"^(\.LBB\d+_\d+):(.*)$", l)
+            if mm:
+                cur = {"label": mm.group(1), "head": mm.group(2), "lines": []}
+                blocks.append(cur)
+            elif cur is not None:
+                if all(x.strip().startswith(";") for x in cur["lines"]) and l.strip().startswith(";") and "Loop" in l:
+                    cur["head"] += " " + l            # (the annotation may continue on the next comment line)
+                cur["lines"].append(l)
+        loops = {}
+        for b in blocks:
+            ids = set(re.findall(r"(?:Header=|Parent Loop )(BB\d+_\d+)", b["head"]))
+            if "Loop Header" in b["head"]:
+                ids.add(b["label"].lstrip(".L"))
+            for h in ids:
+                loops.setdefault(h, []).append(b)
+        best = None
+        is_dma = lambda l: "global_load_lds_dwordx4" in l or ("buffer_load_dwordx4" in l and " lds" in l)
+        for hdr, bl in loops.items():      # the smallest loop (with its nested ones) that holds both MFMAs and LDS-DMA loads
+            lines = [l for b in bl for l in b["lines"]]
+            if any("v_mfma_f32_32x32x16_bf16" in l for l in lines) and any(is_dma(l) for l in lines) and \
+                    (best is None or len(lines) < len(best)):
+                best = lines
+        if best is None:
+            bad.append(f"{frag}: no loop with MFMAs found")
+            continue
+        loop = best
+        if not any(re.search(r"s_waitcnt vmcnt\((?!0\))\d+\)", l) for l in body):
             bad.append(f"{frag}: no counted vmcnt wait in the kernel")
             continue
-        start = idx[0]
-        mf = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l and i > start]
-        end = mf[-1] if mf else start
-        loop = body[start:end + 1]
         n_mfma = sum("v_mfma_f32_32x32x16_bf16" in l for l in loop)
-        n_dma = sum("global_load_lds_dwordx4" in l for l in loop)
+        n_dma = sum("global_load_lds_dwordx4" in l or ("buffer_load_dwordx4" in l and " lds" in l) for l in loop)
         # (the kernel's own drain in front of its LAST tile carries a "; tail" comment)
         drains = [l.strip() for l in loop if "vmcnt(0)" in l and "; tail" not in l]
         scratch = [l.strip() for l in loop if l.strip().startswith("scratch_")]

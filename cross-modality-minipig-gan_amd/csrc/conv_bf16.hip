@@ -444,7 +444,7 @@ struct HwTile {
   static constexpr int EP_PITCH = 72;                                 // floats; rows r and r+4 half a bank sweep apart
   static constexpr int EP_WAVE = 32 * EP_PITCH * 4;
   static constexpr int EP_ROWPIX = 8 * EP_WAVE;
-  static constexpr int EP_PART = EP_ROWPIX + BM * 4;
+  static constexpr int EP_PART = EP_ROWPIX + 2 * BM * 4;              // (two row -> pixel tables in the pair form)
   static constexpr int SMEM_EPI = EP_PART + WM * 2 * BN * 4;
   static constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
   static_assert(WM * WN == 8 && BM % PR == 0 && BN % PR == 0, "eight waves; whole DMA passes");
@@ -454,8 +454,13 @@ struct HwTile {
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(lptr), 16, (int)(voff), \
                                            (int)(soff), 0, 0)
 
-template <int WM, int WN, bool MASK, bool RING = true>
+//   PAIR (256 x 256 only): the tile's columns are the 128 produced channels of TWO phases of a strided backward-data
+//   gather whose phases read the same gathered pixels through different kernel taps (k = 4, stride 2: all eight).
+//   The gathered tile is staged once for both -- 128 FLOP per staged byte instead of the 102 of a 512 x 128 tile per
+//   phase -- and each half of the columns has its own weight-row base and its own output pixel per row.
+template <int WM, int WN, bool MASK, bool RING = true, bool PAIR = false>
 __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const GatherConv p) {
+  static_assert(!PAIR || (WM == 2 && WN == 4), "phase pairs: 256 x 256 tiles");
   using T = HwTile<WM, WN, RING>;
   constexpr int BM = T::BM, BN = T::BN, PR = T::PR, TM = 4, TN = 2;
   constexpr int NLOADS = T::APIECES + T::BPIECES;
@@ -465,15 +470,15 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
   const int lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
-  const BlockId bid = conv_block_id(p);
-  const Phase& ph = p.ph[bid.phase];
+  const BlockId bid = conv_block_id(p);               // (PAIR: p.nphase counts pairs, bid.phase is the pair)
+  const Phase& ph = p.ph[PAIR ? 2 * bid.phase : bid.phase];
   const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
   const long m0 = (long)bid.mt * BM;
-  const int n0 = bid.nt * BN;
+  const int n0 = PAIR ? 0 : bid.nt * BN;
   const int stats_row = bid.phase * p.mtiles + bid.mt;
   const int Cout = p.Cout;
   if (m0 >= Mtot) {                                   // empty tile of a short phase (block-uniform)
-    if (p.stats && tid < BN && n0 + tid < Cout) {
+    if (!PAIR && p.stats && tid < BN && n0 + tid < Cout) {
       float* row = p.stats + (long)stats_row * 2 * Cout;
       row[n0 + tid] = 0.f;
       row[Cout + n0 + tid] = 0.f;
@@ -489,6 +494,7 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, bytesA, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, (unsigned)Cout * Ktot2, 0x00020000);
+  auto tap0 = [&](const Phase& q) { return ((q.kz0 * p.Ky + q.ky0) * p.Kx + q.kx0) * Cin * 2; };
 
   // ---- this thread's pieces: rows r0 + 64*i, 16-byte chunk `ck` of the K-step (source-side swizzle) ----
   const int r0 = tid >> 3, cc = tid & 7;
@@ -525,9 +531,14 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
   unsigned voffB[T::BPIECES];
 #pragma unroll
   for (int i = 0; i < T::BPIECES; ++i) {
-    int co = n0 + r0 + PR * i;
-    co = co < Cout ? co : Cout - 1;                   // clamped columns are computed and dropped
-    voffB[i] = (unsigned)co * Ktot2 + (unsigned)ck * 16u;
+    if constexpr (PAIR) {                             // columns 0-127: phase 2q, 128-255: phase 2q+1 (Cout == 128)
+      const int row = r0 + PR * i;
+      voffB[i] = (unsigned)(row & 127) * Ktot2 + (unsigned)ck * 16u + (unsigned)tap0(p.ph[2 * bid.phase + (row >> 7)]);
+    } else {
+      int co = n0 + r0 + PR * i;
+      co = co < Cout ? co : Cout - 1;                 // clamped columns are computed and dropped
+      voffB[i] = (unsigned)co * Ktot2 + (unsigned)ck * 16u;
+    }
   }
   const int dbg = g_hb_dbg;
 
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
   const int wY = p.kstep[1] * p.Kx * Cin * 2 - (ph.nx - 1) * wX;
   const int wZ = p.kstep[0] * p.Ky * p.Kx * Cin * 2 - (ph.ny - 1) * p.kstep[1] * p.Kx * Cin * 2 - (ph.nx - 1) * wX;
   const int delta0 = ((ph.dz0 * Hi + ph.dy0) * Wi + ph.dx0) * ldi * 2;   // >= 0 when every tap is in range (!MASK)
-  const int woff0 = ((ph.kz0 * p.Ky + ph.ky0) * p.Kx + ph.kx0) * Cin * 2;
+  const int woff0 = PAIR ? 0 : tap0(ph);              // (PAIR: each row's first tap is in its voffset)
   const int nx = ph.nx, ny = ph.ny;
   const int wbase = __builtin_amdgcn_readfirstlane(8 * wid * HW_ROWB);
   // two cursors: the gathered operand's tiles (A) run one K-step ahead of the weights' (B) in the ring form
@@ -732,29 +743,32 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
   if (dbg & 32) return;                               // (what-if: no epilogue)
 
   // ---- epilogue ----
-  int* rowpix = reinterpret_cast<int*>(lds + T::EP_ROWPIX);
-  if (tid < BM) {
-    const unsigned m = (unsigned)m0 + tid;            // one thread per row
+  int* rowpix = reinterpret_cast<int*>(lds + T::EP_ROWPIX);          // [PAIR ? 2 : 1][BM]
+  if (tid < (PAIR ? 2 : 1) * BM) {
+    const int half = tid / BM, row = tid - half * BM;
+    const Phase& po = p.ph[PAIR ? 2 * bid.phase + half : bid.phase];
+    const unsigned m = (unsigned)m0 + row;            // one thread per row (and phase of the pair)
     int pix = -1;
     if (m < (unsigned)Mtot) {
       unsigned q, umx, umy, umz;
-      fdivmod(m, ph.fMx, q, umx);
-      fdivmod(q, ph.fMy, q, umy);
-      fdivmod(q, ph.fMz, q, umz);
-      const int oz = (int)umz * p.ostride[0] + ph.oz, oy = (int)umy * p.ostride[1] + ph.oy,
-                ox = (int)umx * p.ostride[2] + ph.ox;
+      fdivmod(m, po.fMx, q, umx);
+      fdivmod(q, po.fMy, q, umy);
+      fdivmod(q, po.fMz, q, umz);
+      const int oz = (int)umz * p.ostride[0] + po.oz, oy = (int)umy * p.ostride[1] + po.oy,
+                ox = (int)umx * p.ostride[2] + po.ox;
       if (oz < p.Do && oy < p.Ho && ox < p.Wo) pix = (((int)q * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
     }
     rowpix[tid] = pix;
   }
+  const int cbase = PAIR ? (wn & 1) * 64 : n0 + wn * 64;             // first produced channel of this wave's columns
   float bv[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
-    const int col = n0 + wn * 64 + tn * 32 + li;
+    const int col = cbase + tn * 32 + li;
     bv[tn] = (p.bias && col < Cout) ? p.bias[col] : 0.f;
   }
   __syncthreads();
-  if (p.stats) {
+  if (!PAIR && p.stats) {
     // column sums of z = acc + bias over the rows that own an output pixel, from the accumulators: a lane holds
     // column li of rows (r&3) + 8(r>>2) + 4 lh of each 32-row block
     float* part = reinterpret_cast<float*>(lds + T::EP_PART);          // [WM][2][BN]
@@ -799,7 +813,7 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
   // 32 x 64 blocks of the wave's tile through its private slab: lane -> (row, 8-channel chunk), 16-byte bf16 stores
   float* slab = reinterpret_cast<float*>(lds + wid * T::EP_WAVE);
   char* goutb = reinterpret_cast<char*>(p.out);
-  const int cbase = n0 + wn * 64;
+  const int* rp = rowpix + (PAIR ? (wn >> 1) * BM : 0) + wm * 128;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     __builtin_amdgcn_wave_barrier();
@@ -812,7 +826,7 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int idx = lane + 64 * j, row = idx >> 3, ch = idx & 7;
-      const int pix = rowpix[wm * 128 + tm * 32 + row];
+      const int pix = rp[tm * 32 + row];
       const float4 v0 = *reinterpret_cast<const float4*>(slab + row * T::EP_PITCH + ch * 8);
       const float4 v1 = *reinterpret_cast<const float4*>(slab + row * T::EP_PITCH + ch * 8 + 4);
       if (pix < 0 || cbase + ch * 8 >= Cout) continue;
@@ -824,11 +838,21 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
   }
 }
 
-// Which K-stepped form serves a gather: 0 = 256 x 128/64 tile (gather_conv_bf16_kernel), 1 = 256 x 256, 2 = 512 x 128
-// (gather_conv_bf16_wide_kernel).  The wide forms need enough tiles to fill the chip twice over; MPGAN_DBG_HB_WIDE=0
+// Which K-stepped form serves a gather: 0 = 256 x 128/64 tile (gather_conv_bf16_kernel), 1 = 256 x 256, 2 = 512 x 128,
+// 3 = 256 x 256 over the phase pairs of a strided backward-data gather (gather_conv_bf16_wide_kernel).  The wide forms need enough tiles to fill the chip twice over; MPGAN_DBG_HB_WIDE=0
 // turns them off (A/B runs).  mpgan_conv_stats_rows_bf16 follows the same choice (rows = phases x m-tiles).
 static int g_hw_min_blocks = 1024;
-static int hw_choice(const GatherConv& p) {
+static bool hw_pairs_congruent(const GatherConv& p) {
+  if (p.nphase < 2 || p.nphase % 2) return false;
+  for (int i = 0; i < p.nphase; i += 2) {
+    const Phase &a = p.ph[i], &b = p.ph[i + 1];
+    if (a.Mz != b.Mz || a.My != b.My || a.Mx != b.Mx || a.nz != b.nz || a.ny != b.ny || a.nx != b.nx || a.dz0 != b.dz0 ||
+        a.dy0 != b.dy0 || a.dx0 != b.dx0 || a.nz * a.ny * a.nx == 0)
+      return false;
+  }
+  return true;
+}
+static int hw_choice(const GatherConv& p, bool with_stats) {
   static int forced = -2;
   if (forced == -2) {
     const char* e = getenv("MPGAN_DBG_HB_WIDE");
@@ -843,17 +867,21 @@ static int hw_choice(const GatherConv& p) {
     const long blocks = ((maxM + 255) / 256) * ((p.Cout + 255) / 256) * p.nphase;
     return (blocks >= g_hw_min_blocks || forced == 1) ? 1 : 0;
   }
+  if (p.Cout == 128 && !with_stats && !p.bias && hw_pairs_congruent(p) && forced != 2) {   // 3 = 256 x 256 over phase pairs
+    const long blocks = ((maxM + 255) / 256) * (p.nphase / 2);
+    if (blocks >= g_hw_min_blocks || forced == 3) return 3;
+  }
   if (p.Cout > 64) {
     const long blocks = ((maxM + 511) / 512) * p.nphase;
     return (blocks >= g_hw_min_blocks || forced == 2) ? 2 : 0;
   }
   return 0;
 }
-static int hw_bm(int choice) { return choice == 1 ? 256 : (choice == 2 ? 512 : HB_BM); }
+static int hw_bm(int choice) { return choice == 2 ? 512 : 256; }
 
-template <int WM, int WN, bool MASK, bool RING = true>
+template <int WM, int WN, bool MASK, bool RING = true, bool PAIR = false>
 static int hw_launch(const GatherConv& p, long maxM, hipStream_t st) {
-  auto kern = gather_conv_bf16_wide_kernel<WM, WN, MASK, RING>;
+  auto kern = gather_conv_bf16_wide_kernel<WM, WN, MASK, RING, PAIR>;
   using T = HwTile<WM, WN, RING>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -872,10 +900,11 @@ static int hw_launch(const GatherConv& p, long maxM, hipStream_t st) {
   }
   GatherConv q = p;
   q.mtiles = (int)((maxM + T::BM - 1) / T::BM);
-  q.ntiles = (p.Cout + T::BN - 1) / T::BN;
+  q.ntiles = PAIR ? 1 : (p.Cout + T::BN - 1) / T::BN;
+  q.nphase = PAIR ? p.nphase / 2 : p.nphase;          // (the kernel reads phases 2 i and 2 i + 1 of pair i)
   q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 2 > (3L << 20) ? 1 : 0;
   q.ksplit = 1;
-  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
+  dim3 grid((unsigned)q.mtiles * q.ntiles * q.nphase);
   hipLaunchKernelGGL(kern, grid, dim3(512), T::SMEM, st, q);
   return check_launch("gather_conv_bf16_wide");
 }
@@ -1218,7 +1247,8 @@ static int hb_dispatch(const GatherConv& p, hipStream_t st, const char* what) {
   if (maxM == 0) return MPGAN_OK;
   if (hp_ok(p)) return p.Cout > 64 ? hp_launch<128>(p, st) : hp_launch<64>(p, st);
   const bool mask = !hb_all_in_range(p);
-  const int wide = hw_choice(p);
+  const int wide = hw_choice(p, p.stats != nullptr);
+  if (wide == 3) return mask ? hw_launch<2, 4, true, true, true>(p, maxM, st) : hw_launch<2, 4, false, true, true>(p, maxM, st);
   static const bool no_ring = getenv("MPGAN_DBG_HB_NO_RING") != nullptr;     // development: two whole stages instead
   if (wide == 1 && no_ring) return mask ? hw_launch<2, 4, true, false>(p, maxM, st) : hw_launch<2, 4, false, false>(p, maxM, st);
   if (wide == 1) return mask ? hw_launch<2, 4, true>(p, maxM, st) : hw_launch<2, 4, false>(p, maxM, st);
@@ -1667,12 +1697,13 @@ extern "C" int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g) {
     return p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x;
   }
   p.ldi = p.Cin;
-  const int bm = hw_bm(g->cin % HB_BK == 0 ? hw_choice(p) : 0);
+  const int bm = hw_bm(g->cin % HB_BK == 0 ? hw_choice(p, true) : 0);
   return (int32_t)((max_phase_pixels(p) + bm - 1) / bm) * p.nphase;
 }
 
 // Which bf16 kernel serves this geometry (profiling labels): 0 = K-stepped gather_conv_bf16_kernel,
-// 1 = gather_patch_bf16_kernel (stride-1 3x3x3 gathers), 2 / 3 = gather_conv_bf16_wide_kernel 256 x 256 / 512 x 128.
+// 1 = gather_patch_bf16_kernel (stride-1 3x3x3 gathers), 2 / 3 / 4 = gather_conv_bf16_wide_kernel 256 x 256 / 512 x 128 /
+// 256 x 256 over phase pairs.
 extern "C" int32_t mpgan_conv_variant_bf16(const mpgan_conv_geom* g, int32_t backward_data) {
   if (check_geom(g)) return -1;
   GatherConv p{};
@@ -1685,7 +1716,7 @@ extern "C" int32_t mpgan_conv_variant_bf16(const mpgan_conv_geom* g, int32_t bac
   }
   if (p.Cin % HB_BK == 0 && hp_ok(p)) return 1;
   p.ldi = p.Cin;
-  const int wide = p.Cin % HB_BK == 0 ? hw_choice(p) : 0;
+  const int wide = p.Cin % HB_BK == 0 ? hw_choice(p, !backward_data) : 0;
   return wide ? 1 + wide : 0;
 }
 

@@ -434,7 +434,8 @@ int mpgan_conv_forward_bf16(const mpgan_conv_geom* g, const void* x, int32_t ldx
                             const float* bias, float* stats_partials, void* y, int32_t ldy, void* stream);
 /* Which bf16 kernel serves this geometry (profiling labels only): 0 = the K-stepped gather kernel,
  * 1 = the patch form for stride-1 3x3x3 gathers (D.conv2 forward / backward-data at config C5),
- * 2 / 3 = the wide K-stepped form, 256 x 256 / 512 x 128 tiles (D.conv3 / D.conv4 at config C5). */
+ * 2 / 3 / 4 = the wide K-stepped form: 256 x 256 tiles, 512 x 128 tiles, 256 x 256 tiles over pairs of phases of a
+ * strided backward-data gather (D.conv3 / D.conv4 at config C5). */
 int32_t mpgan_conv_variant_bf16(const mpgan_conv_geom* g, int32_t backward_data);
 
 /* dx (bf16) = conv_backward_data(dy (bf16)); w_packed_bwd: bf16, layout 1 of mpgan_pack_weights_bf16. */

@@ -128,7 +128,8 @@ WIDE_CASES = [  # shapes of CASES' classes that the wide (128 x 64 per wave) for
     (1, (10, 12, 10), 128, 256, 4, 2, 0),     # 3-D: 64 taps forward, 8 phases x 8 taps backward
     (2, (12, 14), 128, 264, 3, 1, 1),         # padded (masked pieces read out of range), ragged second channel tile
     (3, (21, 19), 64, 128, 3, 1, 1),          # forward 512 x 128 masked, more than one m-tile
-    (2, (9, 30), 256, 256, 3, 1, 0),          # backward-data on 256 x 256 tiles (masked), 8 channel chunks of 32
+    (2, (9, 30), 256, 256, 3, 1, 0),          # backward-data on 256 x 256 tiles (masked), 4 channel chunks
+    (2, (23, 21), 128, 256, 4, 2, 0),         # odd extents: the backward-data phases differ in size -> 512 x 128 per phase
 ]
 
 
@@ -152,22 +153,27 @@ def test_wide_forms_forward_bf16(wide_forms, n, spatial, cin, cout, k, s, p):
     test_conv_forward_bf16_exact_and_random(n, spatial, cin, cout, k, s, p)
 
 
-@pytest.mark.parametrize("n,spatial,cin,cout,k,s,p", WIDE_CASES[:2] + WIDE_CASES[4:], ids=lambda v: str(v))
-def test_wide_forms_backward_data_bf16(wide_forms, n, spatial, cin, cout, k, s, p):
+@pytest.mark.parametrize("n,spatial,cin,cout,k,s,p,form", [(*WIDE_CASES[0], 4), (*WIDE_CASES[1], 4), (*WIDE_CASES[4], 2),
+                                                            (*WIDE_CASES[5], 3)], ids=lambda v: str(v))
+def test_wide_forms_backward_data_bf16(wide_forms, n, spatial, cin, cout, k, s, p, form):
+    """form 4: the phases of a k = 4, stride-2 backward-data gather read the same gathered pixels, two of them share a
+    256 x 256 tile (columns = 2 x 128 produced channels); form 3: phases of unequal size, 512 x 128 per phase; form 2:
+    one phase, 256 produced channels."""
     from mpgan_amd._lib import lib
     import ctypes as C
     g = _geom(n, spatial, cin, cout, k, s, p)
     gc = g.c()
-    assert lib().mpgan_conv_variant_bf16(C.byref(gc), 1) in (2, 3)
+    assert lib().mpgan_conv_variant_bf16(C.byref(gc), 1) == form
     test_conv_backward_data_and_weight_bf16(n, spatial, cin, cout, k, s, p)
 
 
 def test_wide_forms_serve_config_c5_by_default():
-    """D.conv3 / D.conv4 at 128^3 bs 4: forward and backward-data of conv3, backward-data of conv4 on the wide forms."""
+    """D.conv3 / D.conv4 at 128^3 bs 4: forward of conv3 and backward-data of conv4 on 256 x 256 tiles, backward-data of
+    conv3 (128 produced channels, eight congruent phases) on 256 x 256 tiles over phase pairs."""
     from mpgan_amd import ops
     from mpgan_amd._lib import lib
     import ctypes as C
-    for (cin, cout, e), want in (((128, 256, 124), (2, 3)), ((256, 256, 61), (None, 2))):
+    for (cin, cout, e), want in (((128, 256, 124), (2, 4)), ((256, 256, 61), (None, 2))):
         g = ops.ConvGeom(4, (e, e, e), cin, cout, (4, 4, 4), (2, 2, 2), (0, 0, 0))
         gc = g.c()
         for bwd in (0, 1):

@@ -18,10 +18,12 @@ KERNELS = {   # mangled-name fragment -> (min MFMAs, min LDS-DMA loads) in the K
     "gather_conv_bf16_kernelILi64ELb1ELi8": (8, 5),
     "gather_patch_bf16_kernelILi128": (16, 2),            # patch form: weights only stream inside the tap loop
     "gather_patch_bf16_kernelILi64": (8, 1),
-    "gather_conv_bf16_wide_kernelILi2ELi4ELb0": (32, 8),  # wide form: 128 x 64 per wave, two stages
-    "gather_conv_bf16_wide_kernelILi2ELi4ELb1": (32, 8),
-    "gather_conv_bf16_wide_kernelILi4ELi2ELb0": (32, 10),
-    "gather_conv_bf16_wide_kernelILi4ELi2ELb1": (32, 10),
+    "gather_conv_bf16_wide_kernelILi2ELi4ELb0ELb1ELb0": (32, 8),   # wide form <WM, WN, MASK, RING, PAIR>: 128 x 64 per wave
+    "gather_conv_bf16_wide_kernelILi2ELi4ELb1ELb1ELb0": (32, 8),
+    "gather_conv_bf16_wide_kernelILi2ELi4ELb0ELb1ELb1": (32, 8),   # ... over phase pairs
+    "gather_conv_bf16_wide_kernelILi2ELi4ELb1ELb1ELb1": (32, 8),
+    "gather_conv_bf16_wide_kernelILi4ELi2ELb0ELb1ELb0": (32, 10),  # 512 x 128, two stages
+    "gather_conv_bf16_wide_kernelILi4ELi2ELb1ELb1ELb0": (32, 10),
     "wgrad_bf16_kernelILi4": (32, 12),
     "wgrad_bf16_kernelILi8": (16, 6),
 }
@@ -80,7 +82,7 @@ def main(path):
             bad.append(f"{frag}: {len(scratch)} scratch accesses inside the K loop (register spill)")
         if n_mfma < min_mfma or n_dma < min_dma:
             bad.append(f"{frag}: K loop holds {n_mfma} MFMAs / {n_dma} LDS-DMA loads, expected >= {min_mfma} / {min_dma}")
-        print(f"{frag:44s} K loop: {n_mfma} MFMA, {n_dma} LDS-DMA, {len(loop)} lines, no drain" if not drains else
+        print(f"{frag:50s} K loop: {n_mfma} MFMA, {n_dma} LDS-DMA, {len(loop)} lines, no drain" if not drains else
               f"{frag:44s} DRAINED")
     if bad:
         print("\n".join(bad), file=sys.stderr)

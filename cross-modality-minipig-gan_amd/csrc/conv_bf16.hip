@@ -68,6 +68,10 @@ __device__ __forceinline__ void lds_wait(V (&a)[NA], V (&b)[NB]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
                    "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+  else if constexpr (NA == 8 && NB == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
   else
     static_assert(NA == 0, "lds_wait: unsupported fragment set");
 }
@@ -1479,11 +1483,237 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_bf16_kernel(const WgradHb p)
     }
 }
 
-struct WgradHbPlan { int nsplit, tiles_c, tiles_d; long chunk; };
+// ---------------------------------------------------------------------------
+// Wide form of the weight gradient (round 3), for layers with >= 256 dense channels (D.conv3 / D.conv4): 256 dense
+// channels x 256 columns per block, eight waves as 2 x 4 of 128 x 64 (the same move as gather_conv_bf16_wide_kernel:
+// 128 FLOP per staged byte instead of 85, 12 transposing reads per 8 MFMAs instead of 8 per 4).  Each operand of a
+// K-step (64 pixels x 256 channels = two 128-channel sub-tiles of 256-byte rows, 32 KiB) is one unit of the five-unit
+// ring described there: the gathered tile of step kt+3 and the dense tile of step kt+2 are issued behind step kt's
+// barrier, two LDS-DMA pieces per k-sub.  Swizzle, transposing reads and the pixel cursors are wgrad_bf16_kernel's.
+// ---------------------------------------------------------------------------
+constexpr int WW_B = 256;                                  // dense channels = columns per block
+constexpr int WW_SUB = WH_BK * 256;                        // one 128-channel sub-tile: 64 rows of 256 B = 16 KiB
+constexpr int WW_UNIT = 2 * WW_SUB;                        // 32 KiB
+constexpr int WW_SMEM = 5 * WW_UNIT;
+
+__global__ __launch_bounds__(512, 1) void wgrad_bf16_wide_kernel(const WgradHb p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int TM = 4, TN = 2, WN = 4;
+  constexpr int PR = 32;                                 // rows one LDS-DMA instruction of every wave fills (8 waves x 4)
+  constexpr int NP = WH_BK / PR;                         // row groups per thread: 2
+  constexpr int GP = 2 * NP, DP = 2 * NP;                // pieces per thread and K-step: gathered, dense
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
+  const int tc = (int)(w % (unsigned)p.tiles_c);
+  const unsigned wq = w / (unsigned)p.tiles_c;
+  const int td = (int)(wq % (unsigned)p.tiles_d), split = (int)(wq / (unsigned)p.tiles_d);
+  const int T = p.Kz * p.Ky * p.Kx;
+  const int NC = T * p.Cg;
+  const int c0 = tc * WW_B, d0 = td * WW_B;
+  const long M = (long)p.N * p.Mz * p.My * p.Mx;
+  const long mbeg = (long)split * p.chunk;
+  const long mend = mbeg + p.chunk < M ? mbeg + p.chunk : M;
+  const int nk = mbeg < mend ? (int)((mend - mbeg + WH_BK - 1) / WH_BK) : 0;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  // this thread's pieces: rows 32*i + (tid >> 4) of each sub-tile, LDS position tid & 15, source chunk pos ^ f(row)
+  const int prow = tid >> 4, ppos = tid & 15;
+  const int f = ((prow & 3) << 2) | (wid & 3);            // f(row) = ((row&3)<<2) | ((row>>2)&3), row = 32i + prow
+  const int chk = ppos ^ f;                               // 16-byte chunk (8 channels / columns) this thread fetches
+  unsigned dcolB[2], gtapB[2];
+  bool dok[2], gok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int cd = d0 + 128 * j + chk * 8;
+    dok[j] = cd < p.Cd;
+    dcolB[j] = (unsigned)cd * 2u;
+    const int col = c0 + 128 * j + chk * 8;
+    gok[j] = col < NC;
+    const int t = gok[j] ? col / p.Cg : 0;
+    const int ci = gok[j] ? col - t * p.Cg : 0;
+    const int kx = t % p.Kx, tq = t / p.Kx, ky = tq % p.Ky, kz = tq / p.Ky;
+    gtapB[j] = (unsigned)(((kz * p.Gy + ky) * p.Gx + kx) * p.ldg + ci) * 2u;
+  }
+  int cn[NP], cz[NP], cy[NP], cx[NP];                     // pixel cursors of the gathered operand's rows
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    unsigned q, ux, uy, uz;
+    fdivmod((unsigned)(mbeg + PR * i + prow), p.fMx, q, ux);
+    fdivmod(q, p.fMy, q, uy);
+    fdivmod(q, p.fMz, q, uz);
+    cn[i] = (int)q; cz[i] = (int)uz; cy[i] = (int)uy; cx[i] = (int)ux;
+  }
+  const int wbase = __builtin_amdgcn_readfirstlane(4 * wid * 256);
+  long mtileG = mbeg, mtileD = mbeg;                      // first pixel of the next gathered / dense tile to issue
+  auto issueG = [&](int unit, auto part) {                // part: 0 = both row groups, 1 / 2 = the first / second
+    constexpr int P = decltype(part)::value;
+    constexpr int I0 = P == 2 ? NP / 2 : 0, I1 = P == 1 ? NP / 2 : NP;
+    char* Gs = lds + unit + wbase;
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+      const int row = PR * i + prow;
+      const bool valid = mtileG + row < mend;
+      const unsigned gpixB =
+          (unsigned)(((cn[i] * p.Gz + cz[i] * p.sz) * p.Gy + cy[i] * p.sy) * p.Gx + cx[i] * p.sx) * (unsigned)p.ldg * 2u;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* gs = p.gath + (gpixB + gtapB[j]);
+        GLDS16((valid && gok[j]) ? gs : zero, Gs + j * WW_SUB + PR * i * 256);
+      }
+      cx[i] += WH_BK;
+      while (cx[i] >= p.Mx) {
+        cx[i] -= p.Mx;
+        if (++cy[i] == p.My) {
+          cy[i] = 0;
+          if (++cz[i] == p.Mz) { cz[i] = 0; ++cn[i]; }
+        }
+      }
+    }
+    if constexpr (P != 1) mtileG += WH_BK;
+  };
+  auto issueD = [&](int unit, auto part) {
+    constexpr int P = decltype(part)::value;
+    constexpr int I0 = P == 2 ? NP / 2 : 0, I1 = P == 1 ? NP / 2 : NP;
+    char* Ds = lds + unit + wbase;
+    const unsigned mrowB = (unsigned)(mtileD * p.ldd) * 2u;
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+      const int row = PR * i + prow;
+      const bool valid = mtileD + row < mend;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* src = p.dense + (mrowB + (unsigned)(row * p.ldd) * 2u + dcolB[j]);
+        GLDS16((valid && dok[j]) ? src : zero, Ds + j * WW_SUB + PR * i * 256);
+      }
+    }
+    if constexpr (P != 1) mtileD += WH_BK;
+  };
+  constexpr std::integral_constant<int, 0> ALL{};
+  constexpr std::integral_constant<int, 1> HALF0{};
+  constexpr std::integral_constant<int, 2> HALF1{};
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // transposing-read addresses (see wgrad_bf16_kernel): the wave's 128 dense channels are sub-tile wm, its 64 columns
+  // the half (wn & 1) of sub-tile wn >> 1
+  const int tg = lane >> 4, tq4 = (lane & 15) >> 2, tpp = lane & 3;
+  int aoff[TM][2], boff[TN][2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int r = 8 * (tg >> 1) + 4 * half + tq4;                   // pixel row inside a 16-pixel k-sub
+    const int fr = ((r & 3) << 2) | ((r >> 2) & 3);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int chunk = (tm * 32 + 16 * (tg & 1)) / 8 + (tpp >> 1);
+      aoff[tm][half] = wm * WW_SUB + 256 * r + 16 * (chunk ^ fr) + 8 * (tpp & 1);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int chunk = ((wn & 1) * 64 + tn * 32 + 16 * (tg & 1)) / 8 + (tpp >> 1);
+      boff[tn][half] = (wn >> 1) * WW_SUB + 256 * r + 16 * (chunk ^ fr) + 8 * (tpp & 1);
+    }
+  }
+  const unsigned lds_base = lds_addr(lds);
+  i32x2 fa[2][2 * TM], fb[2][2 * TN];                     // [set][2*tile + half]
+  auto read_frags = [&](int unitD, int unitG, int s, int set) {
+    const unsigned D = lds_base + unitD + s * 16 * 256, G = lds_base + unitG + s * 16 * 256;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      fa[set][2 * tm] = lds_read_tr16_b64(D + aoff[tm][0]);
+      fa[set][2 * tm + 1] = lds_read_tr16_b64(D + aoff[tm][1]);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      fb[set][2 * tn] = lds_read_tr16_b64(G + boff[tn][0]);
+      fb[set][2 * tn + 1] = lds_read_tr16_b64(G + boff[tn][1]);
+    }
+  };
+  // ring: units G_0 D_0 G_1 D_1 G_2 | D_2 G_3 D_3 ... in slots u % 5 (gather_conv_bf16_wide_kernel)
+  constexpr int U = WW_UNIT;
+  if (nk > 0) {
+    issueG(0, ALL);
+    issueD(U, ALL);
+    if (nk > 1) { issueG(2 * U, ALL); issueD(3 * U, ALL); }
+    if (nk > 2) issueG(4 * U, ALL);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GP + DP) : "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP + DP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    int ug = 0, ud = U;
+    read_frags(ud, ug, 0, 0);
+    bool pend_d = false, pend_g = false;
+    int unit_d = 0, unit_g = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      int ng = ug + 2 * U, nd = ud + 2 * U;
+      ng = ng >= 5 * U ? ng - 5 * U : ng;
+      nd = nd >= 5 * U ? nd - 5 * U : nd;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int set = s & 1;
+        lds_wait<2 * TM, 2 * TN>(fa[set], fb[set]);
+        if (s < 3) {
+          read_frags(ud, ug, s + 1, set ^ 1);
+          if (s == 0 && pend_d) issueD(unit_d, HALF1);
+          if (s == 1 && pend_g) issueG(unit_g, HALF0);
+          if (s == 2 && pend_g) issueG(unit_g, HALF1);
+        } else if (kt + 1 < nk) {
+          if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0) ; tail: the last tile" ::: "memory");      // (tools/check_isa.py)
+          asm volatile("s_barrier" ::: "memory");
+          pend_d = kt + 2 < nk;
+          pend_g = kt + 3 < nk;
+          unit_d = ug;                                   // the dense tile of step kt+2 takes the slot G_kt leaves
+          unit_g = ud;
+          if (pend_d) issueD(unit_d, HALF0);
+          read_frags(nd, ng, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const i32x4 av = __builtin_shufflevector(fa[set][2 * tm], fa[set][2 * tm + 1], 0, 1, 2, 3);
+            const i32x4 bv = __builtin_shufflevector(fb[set][2 * tn], fb[set][2 * tn + 1], 0, 1, 2, 3);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                                  acc[tm][tn], 0, 0, 0);
+          }
+      }
+      ug = ng;
+      ud = nd;
+    }
+  }
+
+  float* out = p.partial + (long)split * p.Cd * NC;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = c0 + wn * 64 + tn * 32 + li;
+      if (col >= NC) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cd = d0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (cd < p.Cd) out[(long)cd * NC + col] = acc[tm][tn][r];
+      }
+    }
+}
+
+struct WgradHbPlan { int nsplit, tiles_c, tiles_d, wide; long chunk; };
 static WgradHbPlan plan_wgrad_hb(int Cd, int NC, long M) {
   WgradHbPlan pl;
+  static const bool no_wide = getenv("MPGAN_DBG_HB_WIDE") && atoi(getenv("MPGAN_DBG_HB_WIDE")) == 0;
+  pl.wide = (Cd > WH_BD && !no_wide) ? 1 : 0;             // 256 x 256 tiles (wgrad_bf16_wide_kernel)
   pl.tiles_c = (NC + WH_BG - 1) / WH_BG;
-  pl.tiles_d = (Cd + WH_BD - 1) / WH_BD;
+  pl.tiles_d = (Cd + (pl.wide ? WW_B : WH_BD) - 1) / (pl.wide ? WW_B : WH_BD);
   const long tiles = (long)pl.tiles_c * pl.tiles_d;
   long ns = tiles <= 256 ? 256 / tiles : 1;               // one block per CU, ONE round: never a few blocks more than CUs
   const long maxsplit = M / (8 * WH_BK) > 1 ? M / (8 * WH_BK) : 1;
@@ -1814,7 +2044,19 @@ extern "C" int mpgan_conv_backward_weight_bf16(const mpgan_conv_geom* g, const v
   }
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)pl.tiles_c * pl.tiles_d * pl.nsplit);
-  if (nw == 4) hipLaunchKernelGGL(wgrad_bf16_kernel<4>, grid, dim3(256), WH_SMEM, st, p);
+  if (pl.wide) {
+    static bool wide_attr = false;
+    if (!wide_attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_wide_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, WW_SMEM);
+      if (e != hipSuccess) {
+        set_error("wgrad_bf16_wide: hipFuncSetAttribute(%d): %s", WW_SMEM, hipGetErrorString(e));
+        return MPGAN_ERR_HIP;
+      }
+      wide_attr = true;
+    }
+    hipLaunchKernelGGL(wgrad_bf16_wide_kernel, grid, dim3(512), WW_SMEM, st, p);
+  } else if (nw == 4) hipLaunchKernelGGL(wgrad_bf16_kernel<4>, grid, dim3(256), WH_SMEM, st, p);
   else hipLaunchKernelGGL(wgrad_bf16_kernel<8>, grid, dim3(512), WH_SMEM, st, p);
   int rc = check_launch("wgrad_bf16");
   if (rc) return rc;

@@ -47,6 +47,7 @@ CASES = [  # (n, spatial, cin, cout, k, stride, pad)
     (2, (12, 14), 128, 72, 3, 1, 1),          # padded conv (masked taps), ragged channel tile
     (1, (12, 20, 22), 64, 128, 3, 1, 0),      # large enough for the patch form (4x8x8 tiles, ragged in every dim);
     (2, (10, 18, 19), 128, 64, 3, 1, 1),      # ... padded, two 64-channel chunks, 64-wide channel tile
+    (2, (12, 14), 64, 320, 3, 1, 0),          # 320 dense channels / 576 columns: ragged tiles of the 256 x 256 weight gradient
 ]
 
 

@@ -24,6 +24,7 @@ KERNELS = {   # mangled-name fragment -> (min MFMAs, min LDS-DMA loads) in the K
     "gather_conv_bf16_wide_kernelILi2ELi4ELb1ELb1ELb1": (32, 8),
     "gather_conv_bf16_wide_kernelILi4ELi2ELb0ELb1ELb0": (32, 10),  # 512 x 128, two stages
     "gather_conv_bf16_wide_kernelILi4ELi2ELb1ELb1ELb0": (32, 10),
+    "wgrad_bf16_wide_kernel": (32, 8),                              # 256 x 256, five-unit ring
     "wgrad_bf16_kernelILi4": (32, 12),
     "wgrad_bf16_kernelILi8": (16, 6),
 }

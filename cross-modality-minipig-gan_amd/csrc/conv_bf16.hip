@@ -76,6 +76,98 @@ __device__ __forceinline__ void lds_wait(V (&a)[NA], V (&b)[NB]) {
     static_assert(NA == 0, "lds_wait: unsupported fragment set");
 }
 
+// ---------------------------------------------------------------------------
+// Epilogue of the eight-wave kernels straight from the accumulators (round 3; the first version wrote the whole fp32
+// tile to LDS, summed its columns there and read it a third time for the stores: 0.85 of D.conv2's 4.43 ms forward).
+//   * statistics: a lane holds column li of rows (r&3) + 8(r>>2) + 4 lh of each 32-row block -- it sums its own
+//     values over the rows that own an output pixel, the two half-waves are folded with one shuffle, the WMW waves
+//     that share the columns through part[WMW][2][BNT];
+//   * stores: each 32 x (32 TN) block of the wave goes through a wave-private slab (no block barrier) and leaves as
+//     16-byte bf16 stores, 64 TN contiguous bytes per row.
+// rowpix[row] = output pixel of tile row `row` or -1; rowbase = the wave's first tile row, colw = its first tile
+// column, cbase = the produced channel of that column.  Block barriers inside: call from uniform control flow.
+// ---------------------------------------------------------------------------
+template <int TN> struct HbSlab {
+  static constexpr int PITCH = TN * 32 + 8;               // floats; rows r and r+4 land half a bank sweep apart
+  static constexpr int WAVE = 32 * PITCH * 4;
+};
+template <int TM, int TN, int WMW, int BNT>
+__device__ __forceinline__ void hb_epilogue(const f32x16 (&acc)[TM][TN], float* slab, const int* rowpix, float* part,
+                                            int rowbase, int colw, int cbase, int wmw, const float* bias, float* stats_row,
+                                            int n0, int Cout, char* goutb, int ldo, int tid, int lane) {
+  constexpr int PITCH = HbSlab<TN>::PITCH;
+  const int li = lane & 31, lh = lane >> 5;
+  float bv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = cbase + tn * 32 + li;
+    bv[tn] = (bias && col < Cout) ? bias[col] : 0.f;
+  }
+  if (stats_row) {
+    float sm[TN], sq[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) sm[tn] = sq[tn] = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int4 rp = *reinterpret_cast<const int4*>(rowpix + rowbase + tm * 32 + 8 * g + 4 * lh);
+        const int ok[4] = {rp.x >= 0, rp.y >= 0, rp.z >= 0, rp.w >= 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const float v = ok[e] ? acc[tm][tn][4 * g + e] + bv[tn] : 0.f;
+            sm[tn] += v;
+            sq[tn] = fmaf(v, v, sq[tn]);
+          }
+      }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      sm[tn] += __shfl_xor(sm[tn], 32, 64);
+      sq[tn] += __shfl_xor(sq[tn], 32, 64);
+      if (lh == 0) {
+        part[(wmw * 2 + 0) * BNT + colw + tn * 32 + li] = sm[tn];
+        part[(wmw * 2 + 1) * BNT + colw + tn * 32 + li] = sq[tn];
+      }
+    }
+    __syncthreads();
+    if (tid < BNT && n0 + tid < Cout) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WMW; ++w) {
+        a += part[(w * 2 + 0) * BNT + tid];
+        b += part[(w * 2 + 1) * BNT + tid];
+      }
+      stats_row[n0 + tid] = a;
+      stats_row[Cout + n0 + tid] = b;
+    }
+  }
+  constexpr int CH = TN * 4;                              // 16-byte output chunks per row
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + tn * 32 + li] = acc[tm][tn][r] + bv[tn];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 32 * CH / 64; ++j) {
+      const int idx = lane + 64 * j, row = idx / CH, ch = idx % CH;
+      const int pix = rowpix[rowbase + tm * 32 + row];
+      const float4 v0 = *reinterpret_cast<const float4*>(slab + row * PITCH + ch * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(slab + row * PITCH + ch * 8 + 4);
+      if (pix < 0 || cbase + ch * 8 >= Cout) continue;
+      bf16x8 o;
+      o[0] = (__bf16)v0.x; o[1] = (__bf16)v0.y; o[2] = (__bf16)v0.z; o[3] = (__bf16)v0.w;
+      o[4] = (__bf16)v1.x; o[5] = (__bf16)v1.y; o[6] = (__bf16)v1.z; o[7] = (__bf16)v1.w;
+      *reinterpret_cast<bf16x8*>(goutb + ((long)pix * ldo + cbase + ch * 8) * 2) = o;
+    }
+  }
+}
+
 constexpr int HB_BM = 256;          // pixels per tile
 constexpr int HB_BK = 64;           // K elements per step (one 128-byte LDS row)
 constexpr int HB_ROWB = 128;
@@ -445,8 +537,7 @@ struct HwTile {
   static constexpr bool RING = RING_ && BM == BN;                     // five-unit ring (see the kernel) or two stages
   static constexpr int UNIT = BM * HW_ROWB;
   static constexpr int SMEM_LOOP = RING ? 5 * UNIT : 2 * STAGE;
-  static constexpr int EP_PITCH = 72;                                 // floats; rows r and r+4 half a bank sweep apart
-  static constexpr int EP_WAVE = 32 * EP_PITCH * 4;
+  static constexpr int EP_WAVE = HbSlab<2>::WAVE;
   static constexpr int EP_ROWPIX = 8 * EP_WAVE;
   static constexpr int EP_PART = EP_ROWPIX + 2 * BM * 4;              // (two row -> pixel tables in the pair form)
   static constexpr int SMEM_EPI = EP_PART + WM * 2 * BN * 4;
@@ -765,81 +856,11 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
     rowpix[tid] = pix;
   }
   const int cbase = PAIR ? (wn & 1) * 64 : n0 + wn * 64;             // first produced channel of this wave's columns
-  float bv[TN];
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int col = cbase + tn * 32 + li;
-    bv[tn] = (p.bias && col < Cout) ? p.bias[col] : 0.f;
-  }
   __syncthreads();
-  if (!PAIR && p.stats) {
-    // column sums of z = acc + bias over the rows that own an output pixel, from the accumulators: a lane holds
-    // column li of rows (r&3) + 8(r>>2) + 4 lh of each 32-row block
-    float* part = reinterpret_cast<float*>(lds + T::EP_PART);          // [WM][2][BN]
-    float sm[TN] = {0.f, 0.f}, sq[TN] = {0.f, 0.f};
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int4 rp = *reinterpret_cast<const int4*>(rowpix + wm * 128 + tm * 32 + 8 * g + 4 * lh);
-        const int ok[4] = {rp.x >= 0, rp.y >= 0, rp.z >= 0, rp.w >= 0};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            const float v = ok[e] ? acc[tm][tn][4 * g + e] + bv[tn] : 0.f;
-            sm[tn] += v;
-            sq[tn] = fmaf(v, v, sq[tn]);
-          }
-      }
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      sm[tn] += __shfl_xor(sm[tn], 32, 64);
-      sq[tn] += __shfl_xor(sq[tn], 32, 64);
-      if (lh == 0) {
-        part[(wm * 2 + 0) * BN + wn * 64 + tn * 32 + li] = sm[tn];
-        part[(wm * 2 + 1) * BN + wn * 64 + tn * 32 + li] = sq[tn];
-      }
-    }
-    __syncthreads();
-    if (tid < BN && n0 + tid < Cout) {
-      float a = 0.f, b = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        a += part[(w * 2 + 0) * BN + tid];
-        b += part[(w * 2 + 1) * BN + tid];
-      }
-      float* row = p.stats + (long)stats_row * 2 * Cout;
-      row[n0 + tid] = a;
-      row[Cout + n0 + tid] = b;
-    }
-  }
-  // 32 x 64 blocks of the wave's tile through its private slab: lane -> (row, 8-channel chunk), 16-byte bf16 stores
-  float* slab = reinterpret_cast<float*>(lds + wid * T::EP_WAVE);
-  char* goutb = reinterpret_cast<char*>(p.out);
-  const int* rp = rowpix + (PAIR ? (wn >> 1) * BM : 0) + wm * 128;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * T::EP_PITCH + tn * 32 + li] = acc[tm][tn][r] + bv[tn];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = lane + 64 * j, row = idx >> 3, ch = idx & 7;
-      const int pix = rp[tm * 32 + row];
-      const float4 v0 = *reinterpret_cast<const float4*>(slab + row * T::EP_PITCH + ch * 8);
-      const float4 v1 = *reinterpret_cast<const float4*>(slab + row * T::EP_PITCH + ch * 8 + 4);
-      if (pix < 0 || cbase + ch * 8 >= Cout) continue;
-      bf16x8 o;
-      o[0] = (__bf16)v0.x; o[1] = (__bf16)v0.y; o[2] = (__bf16)v0.z; o[3] = (__bf16)v0.w;
-      o[4] = (__bf16)v1.x; o[5] = (__bf16)v1.y; o[6] = (__bf16)v1.z; o[7] = (__bf16)v1.w;
-      *reinterpret_cast<bf16x8*>(goutb + ((long)pix * p.ldo + cbase + ch * 8) * 2) = o;
-    }
-  }
+  hb_epilogue<TM, TN, WM, BN>(acc, reinterpret_cast<float*>(lds + wid * T::EP_WAVE),
+                              rowpix + (PAIR ? (wn >> 1) * BM : 0), reinterpret_cast<float*>(lds + T::EP_PART), wm * 128,
+                              wn * 64, cbase, wm, p.bias, (!PAIR && p.stats) ? p.stats + (long)stats_row * 2 * Cout : nullptr,
+                              n0, Cout, reinterpret_cast<char*>(p.out), p.ldo, tid, lane);
 }
 
 // Which K-stepped form serves a gather: 0 = 256 x 128/64 tile (gather_conv_bf16_kernel), 1 = 256 x 256, 2 = 512 x 128,
@@ -950,11 +971,15 @@ template <int BN>
 struct HpTile {
   static constexpr int WM = 4, WN = 2, TM = 2, TN = BN / WN / 32;
   static constexpr int BPIECES = BN / 64;
-  static constexpr int BSTAGE = BN * HB_ROWB;
-  static constexpr int IMG_PITCH = BN + 4;
-  static constexpr int ROWPIX = HB_BM * IMG_PITCH * 4;
+  static constexpr int TPS = BN == 64 ? 3 : 1;                        // taps per ring stage (and per block barrier): with 64
+                                                                      // columns a tap is only 8 MFMAs per wave, the barrier
+                                                                      // per tap cost a third of the loop (MFMA-only what-if)
+  static constexpr int BTAP = BN * HB_ROWB;
+  static constexpr int BSTAGE = TPS * BTAP;
   static constexpr int SMEM_LOOP = HP_PATCH + 3 * BSTAGE;
-  static constexpr int SMEM_EPI = ROWPIX + HB_BM * 4 + 4096;
+  static constexpr int EP_ROWPIX = 8 * HbSlab<TN>::WAVE;              // behind the eight waves' slabs
+  static constexpr int EP_PART = EP_ROWPIX + HB_BM * 4;
+  static constexpr int SMEM_EPI = EP_PART + WM * 2 * BN * 4;
   static constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
 };
 
@@ -1016,8 +1041,10 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
   char* const patch = lds;
   char* const bring = lds + HP_PATCH;
 
+  const int dbg = g_hb_dbg;                           // what-if bits as in the K-stepped kernels (2, 4, 16, 32)
   auto issue_patch = [&](int chunk) {
     const unsigned ciB = (unsigned)(chunk * HB_BK + pck * 8) * 2u;
+    if (!(dbg & 16))
 #pragma unroll
     for (int i = 0; i < HP_PPIECES; ++i) {
       const int pr = (tid >> 3) + 64 * i;
@@ -1028,19 +1055,25 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
     }
   };
   // weights of tap (jz, jy, jx) of the current chunk -> ring stage
-  int jx = 0, jy = 0, jz = 0, bstage = 0;
+  int jx = 0, jy = 0, jz = 0, bstage = 0, btap = 0;
   auto issue_b = [&](int chunk) {
     const int kz = ph.kz0 + p.kstep[0] * jz, ky = ph.ky0 + p.kstep[1] * jy, kx = ph.kx0 + p.kstep[2] * jx;
     const unsigned woffB = (unsigned)(((kz * p.Ky + ky) * p.Kx + kx) * Cin * 2);
     const unsigned ciB = (unsigned)(chunk * HB_BK + ck * 8) * 2u;
-    char* Bs = bring + bstage * T::BSTAGE + (8 * wid) * HB_ROWB;
+    char* Bs = bring + bstage * T::BSTAGE + btap * T::BTAP + (8 * wid) * HB_ROWB;
+    if (!(dbg & 16))
 #pragma unroll
     for (int i = 0; i < T::BPIECES; ++i) GLDS16(gwb + (wrowB[i] + woffB + ciB), Bs + 64 * i * HB_ROWB);
     jx += 1;
     if (jx == 3) { jx = 0; jy += 1; }
     if (jy == 3) { jy = 0; jz += 1; }
     if (jz == 3) jz = 0;
-    bstage = bstage == 2 ? 0 : bstage + 1;
+    btap += 1;
+    if (btap == T::TPS) { btap = 0; bstage = bstage == 2 ? 0 : bstage + 1; }
+  };
+  auto issue_group = [&](int chunk) {                   // the TPS taps of one ring stage
+#pragma unroll
+    for (int t = 0; t < T::TPS; ++t) issue_b(chunk);
   };
 
   f32x16 acc[TM][TN];
@@ -1074,28 +1107,30 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
     asm volatile("s_waitcnt vmcnt(0) ; tail: chunk boundary" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     issue_patch(chunk);
-    issue_b(chunk);
-    issue_b(chunk);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::BPIECES) : "memory");      // patch + tap 0 landed (this wave's part)
+    issue_group(chunk);
+    issue_group(chunk);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::BPIECES * T::TPS) : "memory");   // patch + group 0 landed (this wave's part)
     asm volatile("s_barrier" ::: "memory");
-    issue_b(chunk);                                                        // tap 2 -> stage 2
-    int cstage = 0;
+    issue_group(chunk);                                                    // group 2 -> stage 2
+    int cstage = 0, tin = 0;                                               // ring stage of the current tap, its slot in it
     int tzo = p.dstep[0] < 0 ? 2 : 0, tyo = p.dstep[1] < 0 ? 2 : 0, txo = p.dstep[2] < 0 ? 2 : 0;   // tap 0's patch offset
     int kx_ = 0, ky_ = 0;
-    auto read_frags = [&](int delta, int stage, int s, int set) {
+    auto read_frags = [&](int delta, int stage, int slot, int s, int set) {
+      if (dbg & 4) return;
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         const int pr = abase[tm] + delta;
         fa[set][tm] = lds_read_b128(lds_base + pr * HB_ROWB + (((2 * s + lh) ^ ((pr >> 1) & 7)) << 4));
       }
-      const unsigned Bs = ring_base + stage * T::BSTAGE + brow;
+      const unsigned Bs = ring_base + stage * T::BSTAGE + slot * T::BTAP + brow;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) fb[set][tn] = lds_read_b128(Bs + tn * 32 * HB_ROWB + foff[s]);
     };
     int delta = tzo * HP_PZ + tyo * HP_PX + txo;
-    read_frags(delta, 0, 0, 0);
+    read_frags(delta, 0, 0, 0, 0);
     for (int tap = 0; tap < 27; ++tap) {
       const int nstage = cstage == 2 ? 0 : cstage + 1;
+      const bool group_end = tin == T::TPS - 1;           // (27 = 9 x 3: groups never straddle the chunk's end)
       // next tap's patch offset (wave-uniform walk, x fastest)
       int ndelta = delta;
       {
@@ -1111,15 +1146,21 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
         const int set = s & 1;
         lds_wait<TM, TN>(fa[set], fb[set]);
         if (s < 3) {
-          read_frags(delta, cstage, s + 1, set ^ 1);
+          read_frags(delta, cstage, tin, s + 1, set ^ 1);
         } else if (tap + 1 < 27) {
-          if (tap + 2 < 27) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::BPIECES) : "memory");
-          else asm volatile("s_waitcnt vmcnt(0) ; tail: the last tap" ::: "memory");
-          asm volatile("s_barrier" ::: "memory");
-          read_frags(ndelta, nstage, 0, 0);
-          if (tap + 3 < 27) issue_b(chunk);
+          // ONE read site for both cases (the next tap of this stage: no barrier, nothing to wait for; or the first tap
+          // of the next stage): two sites writing the same fragment registers from different branches made the
+          // compiler merge them with register copies, which run before the unprotected asm reads have landed
+          if (group_end) {
+            if (tap + 1 + T::TPS < 27) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::BPIECES * T::TPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) ; tail: the last group" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+          }
+          read_frags(ndelta, group_end ? nstage : cstage, group_end ? 0 : tin + 1, 0, 0);
+          if (group_end && tap + 1 + 2 * T::TPS < 27) issue_group(chunk);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 2))
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -1127,77 +1168,29 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][tm]),
                                                                   __builtin_bit_cast(bf16x8, fb[set][tn]), acc[tm][tn], 0, 0, 0);
       }
-      cstage = nstage;
+      if (group_end) { cstage = nstage; tin = 0; } else tin += 1;
       delta = ndelta;
     }
   }
   asm volatile("s_barrier" ::: "memory");
-  if (g_hb_dbg & 32) return;                          // (what-if: no epilogue)
+  if (dbg & 32) return;                               // (what-if: no epilogue)
 
-  // ---- epilogue (as the K-stepped kernel's): fp32 image -> statistics -> bf16 rows ----
-  float* img = reinterpret_cast<float*>(lds);
-  int* rowpix = reinterpret_cast<int*>(lds + T::ROWPIX);
-  if (tid < HB_BM) {                                  // image row tid = sub-tile (tid >> 5), MFMA row (tid & 31)
+  // ---- epilogue from the accumulators (hb_epilogue): wave (wm, wn) holds tile rows 64 wm .. + 63 = sub-tiles
+  //      2 wm, 2 wm + 1 (hp_row_pixel) and columns wn * BN/2 .. ----
+  int* rowpix = reinterpret_cast<int*>(lds + T::EP_ROWPIX);
+  if (tid < HB_BM) {                                  // tile row tid = sub-tile (tid >> 5), MFMA row (tid & 31)
     int z, y, x;
     hp_row_pixel(tid >> 5, tid & 31, z, y, x);
     const int oz = oz0 + z, oy = oy0 + y, ox = ox0 + x;
     rowpix[tid] = (oz < ph.Mz && oy < ph.My && ox < ph.Mx) ? ((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox : -1;
   }
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int col = (wn * TN + tn) * 32 + li;
-    const float bv = (p.bias && n0 + col < Cout) ? p.bias[n0 + col] : 0.f;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        img[row * T::IMG_PITCH + col] = acc[tm][tn][r] + bv;
-      }
-  }
   __syncthreads();
-  if (p.stats) {
-    float* part = reinterpret_cast<float*>(lds + T::ROWPIX + HB_BM * 4);
-    constexpr int HALVES = 512 / BN;
-    const int c = tid % BN, hf = tid / BN;
-    float sm = 0.f, sq = 0.f;
-    for (int row = hf * (HB_BM / HALVES); row < (hf + 1) * (HB_BM / HALVES); ++row) {
-      const float v = rowpix[row] >= 0 ? img[row * T::IMG_PITCH + c] : 0.f;
-      sm += v;
-      sq = fmaf(v, v, sq);
-    }
-    if (hf > 0) {
-      part[((hf - 1) * 2 + 0) * BN + c] = sm;
-      part[((hf - 1) * 2 + 1) * BN + c] = sq;
-    }
-    __syncthreads();
-    if (hf == 0 && n0 + c < Cout) {
-#pragma unroll
-      for (int h = 1; h < HALVES; ++h) {
-        sm += part[((h - 1) * 2 + 0) * BN + c];
-        sq += part[((h - 1) * 2 + 1) * BN + c];
-      }
-      float* row = p.stats + (long)stats_row * 2 * Cout;
-      row[n0 + c] = sm;
-      row[Cout + n0 + c] = sq;
-    }
-  }
-  char* goutb = reinterpret_cast<char*>(p.out);
-  constexpr int CHUNKS = BN / 8;
-  for (int q = tid; q < HB_BM * CHUNKS; q += 512) {
-    const int row = q / CHUNKS, ch = q % CHUNKS;
-    const int pix = rowpix[row];
-    if (pix < 0 || n0 + ch * 8 >= Cout) continue;
-    const float4 v0 = *reinterpret_cast<const float4*>(img + row * T::IMG_PITCH + ch * 8);
-    const float4 v1 = *reinterpret_cast<const float4*>(img + row * T::IMG_PITCH + ch * 8 + 4);
-    bf16x8 o;
-    o[0] = (__bf16)v0.x; o[1] = (__bf16)v0.y; o[2] = (__bf16)v0.z; o[3] = (__bf16)v0.w;
-    o[4] = (__bf16)v1.x; o[5] = (__bf16)v1.y; o[6] = (__bf16)v1.z; o[7] = (__bf16)v1.w;
-    *reinterpret_cast<bf16x8*>(goutb + ((long)pix * p.ldo + n0 + ch * 8) * 2) = o;
-  }
+  hb_epilogue<TM, TN, T::WM, BN>(acc, reinterpret_cast<float*>(lds + wid * HbSlab<TN>::WAVE), rowpix,
+                                 reinterpret_cast<float*>(lds + T::EP_PART), wm * 64, wn * (BN / WN), n0 + wn * (BN / WN), wm,
+                                 p.bias, p.stats ? p.stats + (long)stats_row * 2 * Cout : nullptr, n0, Cout,
+                                 reinterpret_cast<char*>(p.out), p.ldo, tid, lane);
 }
 
-// stride-1 3x3x3 gather with one phase whose taps step by one pixel: the patch form serves it
 static bool hp_ok(const GatherConv& p) {
   static const bool off = getenv("MPGAN_DBG_NO_HB_PATCH") != nullptr;
   if (off || p.nphase != 1) return false;

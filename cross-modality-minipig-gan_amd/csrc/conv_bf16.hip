@@ -68,6 +68,8 @@ __device__ __forceinline__ void lds_wait(V (&a)[NA], V (&b)[NB]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
                    "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+  else if constexpr (NA == 1 && NB == 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]));
   else if constexpr (NA == 8 && NB == 4)
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
@@ -957,7 +959,7 @@ constexpr int HP_PROWS = (HP_TZ + 2) * HP_PZ;                  // 624 patch rows
 constexpr int HP_PATCH = HP_PROWS * HB_ROWB;                   // 79,872 B
 constexpr int HP_PPIECES = (HP_PROWS * 8 + 511) / 512;         // LDS-DMA instructions per thread for one patch: 10
 
-// Tile row (MFMA row li of wave sub-tile s = wm * 2 + tm) -> tile pixel (z, y, x), see above.  The lane groups of
+// Tile row (MFMA row li of wave sub-tile s = wm * TM + tm) -> tile pixel (z, y, x), see above.  The lane groups of
 // ds_read_b128 are {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (+32 for the upper half-wave).
 __device__ __forceinline__ void hp_row_pixel(int s, int li, int& z, int& y, int& x) {
   const bool g1 = (li >= 4 && li <= 11) || (li >= 16 && li <= 19) || li >= 28;
@@ -969,7 +971,9 @@ __device__ __forceinline__ void hp_row_pixel(int s, int li, int& z, int& y, int&
 
 template <int BN>
 struct HpTile {
-  static constexpr int WM = 4, WN = 2, TM = 2, TN = BN / WN / 32;
+  // 128 columns: 4 x 2 waves of 64 x 64; 64 columns: 8 x 1 waves of 32 x 64 (one A read per k-sub: the patch reads
+  // carry the per-tap address arithmetic, the weight reads none)
+  static constexpr int WM = BN == 64 ? 8 : 4, WN = 8 / WM, TM = HB_BM / WM / 32, TN = BN / WN / 32;
   static constexpr int BPIECES = BN / 64;
   static constexpr int TPS = BN == 64 ? 3 : 1;                        // taps per ring stage (and per block barrier): with 64
                                                                       // columns a tap is only 8 MFMAs per wave, the barrier
@@ -1089,7 +1093,7 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     int z, y, x;
-    hp_row_pixel(wm * 2 + tm, li, z, y, x);
+    hp_row_pixel(wm * TM + tm, li, z, y, x);
     abase[tm] = z * HP_PZ + y * HP_PX + x;
   }
   // B fragments as in the K-stepped kernel
@@ -1186,7 +1190,7 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
   }
   __syncthreads();
   hb_epilogue<TM, TN, T::WM, BN>(acc, reinterpret_cast<float*>(lds + wid * HbSlab<TN>::WAVE), rowpix,
-                                 reinterpret_cast<float*>(lds + T::EP_PART), wm * 64, wn * (BN / WN), n0 + wn * (BN / WN), wm,
+                                 reinterpret_cast<float*>(lds + T::EP_PART), wm * TM * 32, wn * (BN / WN), n0 + wn * (BN / WN), wm,
                                  p.bias, p.stats ? p.stats + (long)stats_row * 2 * Cout : nullptr, n0, Cout,
                                  reinterpret_cast<char*>(p.out), p.ldo, tid, lane);
 }

@@ -1387,6 +1387,13 @@ def _bf16_kernel_name(g: ConvGeom, backward_data: bool) -> str:
     return f"gather_conv_bf16_kernel<{bn}, {'true' if backward_data else 'false'}, 8>"
 
 
+def _bf16_wgrad_kernel_name(g: ConvGeom) -> str:
+    """rocprofv3's name of the bf16 weight-gradient kernel of this layer (csrc/conv_bf16.hip: plan_wgrad_hb -- layers with
+    more than 128 dense channels run on 256 x 256 tiles)."""
+    wide = g.cout > 128 and os.environ.get("MPGAN_DBG_HB_WIDE", "") != "0"
+    return "wgrad_bf16_wide_kernel" if wide else "wgrad_bf16_kernel<8>"
+
+
 class DiscPlanBF16:
     """The same network as DiscPlan with bf16 activations, activation gradients and packed weights in HBM
     (code/GAN/GAN_final.py:159-209 at the reference's 3-D shape); fp32 accumulation, statistics, parameters,
@@ -1533,7 +1540,7 @@ class DiscPlanBF16:
                     b.add("conv_backward_weight_bf16", L.mpgan_conv_backward_weight_bf16, C.byref(gc),
                           acts[i - 1].data_ptr(), g.cin, dz.data_ptr(), c, gv(cv.weight).data_ptr(), 1.0,
                           ws.data_ptr(), ws.numel() * 4, keep=(gc, ws), desc=_gdesc(g),
-                          tag=("wgrad_bf16_kernel<8>", 2.0 * conv_macs(g), conv_bytes(g, 2)))
+                          tag=(_bf16_wgrad_kernel_name(g), 2.0 * conv_macs(g), conv_bytes(g, 2)))
                 else:
                     b.add("conv_backward_weight_bf16dy", L.mpgan_conv_backward_weight_bf16dy, C.byref(gc),
                           self.x_in.data_ptr(), 1, dz.data_ptr(), c, gv(cv.weight).data_ptr(), gv(cv.bias).data_ptr(),

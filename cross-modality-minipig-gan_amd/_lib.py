@@ -85,6 +85,7 @@ SIGNATURES = {
     "mpgan_debug_stamps_used": (_L, []),
     "mpgan_debug_clock_khz": (_I, []),
     "mpgan_debug_bf16_wide_min_blocks": (_I, [_I]),
+    "mpgan_debug_f32_dma_min_blocks": (_I, [_I]),
     "mpgan_linear1_backward": (_I, [_P, _PR, _I, _L, _I, _P, _P, _P, _P, _P, _F, _P]),
     "mpgan_sigmoid_bce": (_I, [_P, _I, _F, _F, _P, _P, _P, _P]),
     "mpgan_l1_partials": (_I, []),

@@ -16,6 +16,7 @@
 // Tile: 256 pixels x BN channels x 64 K, 256 threads = 4 waves, one block per CU (144 KiB of LDS).
 #include "mpgan_common.h"
 #include "conv_geom.h"
+#include "lds_dma.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -29,54 +30,6 @@ __device__ uint4 g_zero_page[16];   // 256 B of zeros: what a masked LDS-DMA gat
 __device__ int g_hb_dbg;            // MPGAN_DBG_HB what-if bits (development): 1 = gathers confined to a 64 KiB window,
                                     // 2 = no MFMAs, 4 = no fragment reads either, 8 = weights confined to 16 KiB,
                                     // 16 = no LDS-DMA (the contraction runs on whatever the LDS holds), 32 = no epilogue
-
-#define GLDS16(gptr, lptr)                                                                            \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),             \
-                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
-// Fragment reads as inline asm: hipcc's waitcnt pass drains every LDS-DMA in flight (vmcnt(0)) in front of an LDS
-// read it cannot tell apart from the DMA's destination, which would undo the counted-vmcnt pipeline; an asm
-// statement is invisible to that pass.  Its result register is NOT protected either: each set of reads is
-// followed, before its first use, by lds_wait(...) -- `s_waitcnt lgkmcnt(0)` tied to the registers it covers.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
-}
-__device__ __forceinline__ i32x4 lds_read_b128(unsigned addr) {
-  i32x4 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-  return v;
-}
-__device__ __forceinline__ i32x2 lds_read_tr16_b64(unsigned addr) {
-  i32x2 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
-  return v;
-}
-template <int NA, int NB, typename V>
-__device__ __forceinline__ void lds_wait(V (&a)[NA], V (&b)[NB]) {
-  if constexpr (NA == 4 && NB == 2)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
-  else if constexpr (NA == 2 && NB == 2)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
-  else if constexpr (NA == 4 && NB == 4)
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-  else if constexpr (NA == 2 && NB == 1)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]));
-  else if constexpr (NA == 4 && NB == 8)
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
-                   "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
-  else if constexpr (NA == 1 && NB == 2)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]));
-  else if constexpr (NA == 8 && NB == 4)
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-  else
-    static_assert(NA == 0, "lds_wait: unsupported fragment set");
-}
 
 // ---------------------------------------------------------------------------
 // Epilogue of the eight-wave kernels straight from the accumulators (round 3; the first version wrote the whole fp32
@@ -528,7 +481,6 @@ static int hb_check(const GatherConv& p, const char* what) {
 // ---------------------------------------------------------------------------
 constexpr int HW_BK = 64;
 constexpr int HW_ROWB = 128;
-constexpr unsigned HW_OOB = 0xFFFF0000u;          // voffset of a masked piece: beyond every operand hb_check admits
 
 template <int WM, int WN, bool RING_ = true>
 struct HwTile {
@@ -547,9 +499,6 @@ struct HwTile {
   static_assert(WM * WN == 8 && BM % PR == 0 && BN % PR == 0, "eight waves; whole DMA passes");
 };
 
-#define BLDS16(rsrc, lptr, voff, soff)                                                                              \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(lptr), 16, (int)(voff), \
-                                           (int)(soff), 0, 0)
 
 //   PAIR (256 x 256 only): the tile's columns are the 128 produced channels of TWO phases of a strided backward-data
 //   gather whose phases read the same gathered pixels through different kernel taps (k = 4, stride 2: all eight).

@@ -19,6 +19,7 @@
 // half-waves take different K quads so a quad feeds four MFMAs.
 #include "mpgan_common.h"
 #include "conv_geom.h"
+#include "lds_dma.h"
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
@@ -968,6 +969,224 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
     conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds_all, m0, n0, Mtot, stats_row, FAST && m0 + BM > Mtot, tid, kg == 0, bias_pre);
     MPGAN_STAMP(p, 7);
   }
+}
+
+
+// ---------------------------------------------------------------------------
+// DMA-staged form of the K-stepped kernel (round 3), for gathers WITHOUT a normalise-on-load prologue: the
+// discriminator's backward-data launches (15 ms of the C3 step).  The pipelined kernel above spends ~60 vector
+// instructions per K-step and thread on its operands (address math, range masks, LDS stores) beside 64 MFMAs per
+// wave, and two waves per SIMD share the vector issue port: dropping that work was worth +14 % in a what-if build
+// (DESIGN.md 5.1).  Here nothing passes through registers: both operands go global -> LDS by LDS-DMA buffer loads
+// (buffer_load_dwordx4 ... offen lds: a per-thread 32-bit voffset computed once, the tap / channel-chunk walk in the
+// scalar soffset; a masked piece selects an out-of-range voffset and the bounds check delivers the zeros), exactly
+// the staging of gather_conv_bf16_wide_kernel (conv_bf16.hip) with fp32 rows:
+//   * LDS rows of 32 floats = one 128-byte line, unpadded (LDS-DMA writes lane-linear), 16-byte chunk c of row r at
+//     c ^ ((r >> 1) & 7): the ds_read_b128 of fragment group g (chunk 2g + lh of row li) is conflict-free;
+//   * two stages of (128 + BN) rows (32 KiB at BN = 128: two blocks per CU as before); tile kt+2 is issued into the
+//     stage tile kt leaves, behind the barrier in front of kt's last fragment group, half there and half under the
+//     next K-step's first group (an LDS-DMA instruction costs its wave 60-185 issue cycles);
+//   * fragment reads as inline asm (hipcc otherwise drains the DMAs in front of every LDS read), ONE read site per
+//     group position; MFMAs, accumulator layout and epilogue (conv_epilogue: bias, residual, fused norm-backward
+//     sums, 16-byte stores) are the pipelined kernel's.
+// Tile 128 x BN, 4 waves, K order channel-chunk major / taps inner, Cin % 32 == 0, at most 32 taps per phase.
+// ---------------------------------------------------------------------------
+template <int BN, int TM, int TN, int WN>
+__global__ __launch_bounds__(256) void gather_conv_dma_kernel(const GatherConv p) {
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  char* ldsb = reinterpret_cast<char*>(lds_all);
+  constexpr int ROWB = 128;
+  constexpr int STAGEB = (BM + BN) * ROWB;
+  constexpr int PR = 32;                                  // rows one LDS-DMA instruction of every wave fills
+  constexpr int AP = BM / PR, BP = BN / PR;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  MPGAN_STAMP(p, 0);
+  MPGAN_STAMP_VALUE(p, 6, 1);
+  const BlockId bid = conv_block_id(p);
+  const Phase ph = p.ph[bid.phase];
+  const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
+  const long m0 = (long)bid.mt * BM;
+  const int n0 = bid.nt * BN;
+  const int stats_row = bid.phase * p.mtiles + bid.mt;
+  if (m0 >= Mtot) {
+    if (p.stats && tid < BN && n0 + tid < p.Cout) {
+      float* row = p.stats + (long)stats_row * 2 * p.Cout;
+      row[n0 + tid] = 0.f;
+      row[p.Cout + n0 + tid] = 0.f;
+    }
+    if (p.bwd.part && tid < BN && n0 + tid < p.Cout) {
+      float* row = p.bwd.part + (long)stats_row * 3 * p.Cout;
+      row[n0 + tid] = 0.f;
+      row[p.Cout + n0 + tid] = 0.f;
+      row[2 * p.Cout + n0 + tid] = 0.f;
+    }
+    return;
+  }
+  const int Cin = p.Cin, Cout = p.Cout, Di = p.Di, Hi = p.Hi, Wi = p.Wi, ldi = p.ldi;
+  const int ntaps = ph.nz * ph.ny * ph.nx;
+  const int nk = ntaps * (Cin / BK);
+  const unsigned Ktot4 = (unsigned)(p.Kz * p.Ky * p.Kx * Cin) * 4u;
+  const unsigned bytesA = (unsigned)((((long)p.N * Di * Hi * Wi - 1) * ldi + Cin) * 4);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, (unsigned)Cout * Ktot4, 0x00020000);
+
+  // this thread's pieces: rows r0 + 32 i, 16-byte chunk ck of the K-step (source-side swizzle)
+  const int r0 = tid >> 3, cc = tid & 7;
+  const int ck = cc ^ ((r0 >> 1) & 7);
+  unsigned voffA[AP], tmask[AP], voffB[BP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    unsigned m = (unsigned)m0 + r0 + PR * i;
+    const bool live = m < (unsigned)Mtot;
+    m = live ? m : (unsigned)Mtot - 1u;
+    unsigned q, umx, umy, umz;
+    fdivmod(m, ph.fMx, q, umx);
+    fdivmod(q, ph.fMy, q, umy);
+    fdivmod(q, ph.fMz, q, umz);
+    const int bz = (int)umz * p.istride[0], by = (int)umy * p.istride[1], bx = (int)umx * p.istride[2];
+    voffA[i] = (unsigned)((((int)q * Di + bz) * Hi + by) * Wi + bx) * (unsigned)ldi * 4u + (unsigned)ck * 16u;
+    unsigned mk = 0;
+    int j = 0;
+    for (int jz = 0; jz < ph.nz; ++jz) {
+      const bool okz = (unsigned)(bz + ph.dz0 + p.dstep[0] * jz) < (unsigned)Di;
+      for (int jy = 0; jy < ph.ny; ++jy) {
+        const bool oky = okz && (unsigned)(by + ph.dy0 + p.dstep[1] * jy) < (unsigned)Hi;
+        for (int jx = 0; jx < ph.nx; ++jx, ++j) {
+          const bool ok = oky && (unsigned)(bx + ph.dx0 + p.dstep[2] * jx) < (unsigned)Wi;
+          mk |= (ok ? 1u : 0u) << j;
+        }
+      }
+    }
+    tmask[i] = live ? mk : 0u;                           // rows past the last pixel stage zeros
+  }
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int co = n0 + r0 + PR * i;
+    voffB[i] = co < Cout ? (unsigned)co * Ktot4 + (unsigned)ck * 16u : HW_OOB;   // rows past the last channel: zeros
+  }
+  // incremental, wave-uniform tap walk (scalar registers): see gather_conv_bf16_wide_kernel
+  const int aX = p.dstep[2] * ldi * 4;
+  const int aY = p.dstep[1] * Wi * ldi * 4 - (ph.nx - 1) * aX;
+  const int aZ = p.dstep[0] * Hi * Wi * ldi * 4 - (ph.ny - 1) * p.dstep[1] * Wi * ldi * 4 - (ph.nx - 1) * aX;
+  const int wX = p.kstep[2] * Cin * 4;
+  const int wY = p.kstep[1] * p.Kx * Cin * 4 - (ph.nx - 1) * wX;
+  const int wZ = p.kstep[0] * p.Ky * p.Kx * Cin * 4 - (ph.ny - 1) * p.kstep[1] * p.Kx * Cin * 4 - (ph.nx - 1) * wX;
+  const int delta0 = ((ph.dz0 * Hi + ph.dy0) * Wi + ph.dx0) * ldi * 4;
+  const int woff0 = ((ph.kz0 * p.Ky + ph.ky0) * p.Kx + ph.kx0) * Cin * 4;
+  const int nx = ph.nx, ny = ph.ny;
+  int itap = 0, jx = 0, jy = 0, deltaB = delta0, woffB = woff0, ciB = 0;
+  const int wbase = __builtin_amdgcn_readfirstlane(8 * wid * ROWB);
+  auto issue = [&](int stage, auto part) {               // part 0: the whole tile; 1 / 2: its first / second half
+    constexpr int P = decltype(part)::value;
+    constexpr int A0 = P == 2 ? AP / 2 : 0, A1 = P == 1 ? AP / 2 : AP;
+    constexpr int B0 = P == 2 ? BP / 2 : 0, B1 = P == 1 ? BP / 2 : BP;
+    char* As = ldsb + stage + wbase;
+    char* Bs = As + BM * ROWB;
+#pragma unroll
+    for (int i = A0; i < A1; ++i) {
+      const unsigned v = ((tmask[i] >> itap) & 1u) ? voffA[i] + (unsigned)deltaB : HW_OOB;
+      BLDS16(rsA, As + PR * i * ROWB, v, ciB);
+    }
+#pragma unroll
+    for (int i = B0; i < B1; ++i) BLDS16(rsB, Bs + PR * i * ROWB, voffB[i], woffB + ciB);
+    if constexpr (P != 1) {                               // the cursor moves on behind a tile's last piece
+      itap += 1;
+      jx += 1;
+      int incA = aX, incW = wX;
+      if (jx == nx) {
+        jx = 0;
+        jy += 1;
+        incA = aY; incW = wY;
+        if (jy == ny) { jy = 0; incA = aZ; incW = wZ; }
+      }
+      deltaB += incA;
+      woffB += incW;
+      if (itap == ntaps) { itap = 0; jx = 0; jy = 0; deltaB = delta0; woffB = woff0; ciB += BK * 4; }
+    }
+  };
+  constexpr std::integral_constant<int, 0> ALL{};
+  constexpr std::integral_constant<int, 1> HALF0{};
+  constexpr std::integral_constant<int, 2> HALF1{};
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bias_pre[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int co = n0 + (wn * TN + tn) * 32 + li;
+    bias_pre[tn] = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+  }
+
+  const int sw = (li >> 1) & 7;
+  int foff[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) foff[g] = ((2 * g + lh) ^ sw) * 16;
+  const int arow = (wm * TM * 32 + li) * ROWB;
+  const int brow = BM * ROWB + (wn * TN * 32 + li) * ROWB;
+  const unsigned lds_base = lds_addr(ldsb);
+  i32x4 fa[2][TM], fb[2][TN];
+  auto read_group = [&](int stage, int g, int slot) {
+    const unsigned As = lds_base + stage + arow + foff[g], Bs = lds_base + stage + brow + foff[g];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) fa[slot][tm] = lds_read_b128(As + tm * 32 * ROWB);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) fb[slot][tn] = lds_read_b128(Bs + tn * 32 * ROWB);
+  };
+  if (nk > 0) {
+    issue(0, ALL);
+    if (nk > 1) issue(STAGEB, ALL);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");              // tile 0 landed
+    MPGAN_STAMP(p, 1);
+    read_group(0, 0, 0);
+    int cst = 0;
+    bool pend = false;                                    // the second half of the tile issued behind the last barrier
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nst = cst ? 0 : STAGEB;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int sl = g & 1;
+        lds_wait<TM, TN>(fa[sl], fb[sl]);
+        if (g < 3) {
+          read_group(cst, g + 1, sl ^ 1);
+          if (g == 0 && pend) issue(nst, HALF1);          // (nst: the stage the previous K-step left)
+        } else if (kt + 1 < nk) {
+          // the only DMAs of this wave still in flight are tile kt+1's
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          asm volatile("s_barrier" ::: "memory");
+          pend = kt + 2 < nk;
+          if (pend) issue(cst, HALF0);
+          read_group(nst, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const float4 a = __builtin_bit_cast(float4, fa[sl][tm]), b = __builtin_bit_cast(float4, fb[sl][tn]);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[tm][tn], 0, 0, 0);
+          }
+      }
+      cst = nst;
+    }
+  }
+  asm volatile("s_barrier" ::: "memory");                // every fragment read done: the LDS becomes the epilogue's
+  MPGAN_STAMP(p, 2);
+  MPGAN_STAMP(p, 3);
+  conv_epilogue<BN, TM, TN, WN>(p, ph, acc, lds_all, m0, n0, Mtot, stats_row, false, tid, true, bias_pre);
 }
 
 // ---------------------------------------------------------------------------
@@ -2825,6 +3044,47 @@ static bool pipe_wants_ksplit2(const GatherConv& p, int bn, long maxM) {
   return min_nk >= 8 && min_nk < (1 << 30);
 }
 
+// The DMA-staged form (gather_conv_dma_kernel) serves prologue-free gathers with enough tiles to fill the chip
+// several times over: the discriminator's backward-data launches.  MPGAN_DBG_NO_DMA=1 turns it off (A/B runs);
+// mpgan_debug_f32_dma_min_blocks lowers the threshold (tests).
+static int g_dma_min_blocks = 1024;
+static bool dma_form_ok(const GatherConv& p, int variant, long maxM) {
+  static const bool off = getenv("MPGAN_DBG_NO_DMA") != nullptr;
+  if (off || p.pro.scale || p.ksplit > 1 || p.Cin % 32 != 0 || (variant != 128 && variant != 64)) return false;
+  if (p.stats_acc || p.fold.acc) return false;
+  const long blocks = (maxM + BM - 1) / BM * ((p.Cout + variant - 1) / variant) * p.nphase;
+  if (blocks < g_dma_min_blocks) return false;
+  for (int i = 0; i < p.nphase; ++i) {
+    const int nt = p.ph[i].nz * p.ph[i].ny * p.ph[i].nx;
+    if (nt < 1 || nt > 32) return false;                   // one validity bit per tap and row
+  }
+  const long bytes_a = (long)p.N * p.Di * p.Hi * p.Wi * p.ldi * 4, ktot4 = (long)p.Kz * p.Ky * p.Kx * p.Cin * 4;
+  return bytes_a < (long)HW_OOB && (long)p.Cout * ktot4 < (long)HW_OOB && ktot4 < 0xFFFF;
+}
+
+template <int BN, int TM, int TN, int WN>
+static int launch_dma_variant(const GatherConv& p, long maxM, hipStream_t st) {
+  auto kern = gather_conv_dma_kernel<BN, TM, TN, WN>;
+  constexpr int smem = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      set_error("gather_conv_dma: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  GatherConv q = p;
+  q.mtiles = (int)((maxM + BM - 1) / BM);
+  q.ntiles = (p.Cout + BN - 1) / BN;
+  q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 4 > (3L << 20) ? 1 : 0;
+  q.ksplit = 1;
+  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
+  return check_launch("gather_conv_dma");
+}
+
 template <int WRAPS, int PRO>
 static int launch_pipe_bn(const GatherConv& p, int variant, long maxM, hipStream_t st) {
   if constexpr (WRAPS == 1 && PRO == 3) {
@@ -2834,6 +3094,12 @@ static int launch_pipe_bn(const GatherConv& p, int variant, long maxM, hipStream
     if (variant != 128 && pipe_wants_ksplit2(p, variant, maxM)) {
       if (variant == 64) return launch_pipe_variant<64, 1, 2, 1, 1, PRO, false, 2>(p, maxM, st);
       return launch_pipe_variant<32, 1, 1, 1, 1, PRO, false, 2>(p, maxM, st);
+    }
+  }
+  if constexpr (WRAPS == 1 && PRO == 0) {
+    if (dma_form_ok(p, variant, maxM)) {
+      if (variant == 128) return launch_dma_variant<128, 2, 2, 2>(p, maxM, st);
+      return launch_dma_variant<64, 1, 2, 1>(p, maxM, st);
     }
   }
   if (variant == 128) return launch_pipe_variant<128, 2, 2, 2, WRAPS, PRO>(p, maxM, st);
@@ -3462,7 +3728,16 @@ extern "C" int32_t mpgan_conv_variant(const mpgan_conv_geom* g, int32_t backward
   if (v == 128 && has_prologue == 3 && fast_geometry(p, 128)) return 1128;
   if ((v == 32 || v == 64) && p.Cin % 32 == 0 && has_prologue != 3 && pipe_wants_ksplit2(p, v, max_phase_pixels(p)))
     return 2000 + v;
+  if (!has_prologue && dma_form_ok(p, v, max_phase_pixels(p))) return 3000 + v;   // gather_conv_dma_kernel
   return v;
+}
+
+// Development / test hook: blocks from which the DMA-staged form serves a prologue-free gather (default 1024).
+// Returns the previous value; blocks <= 0 only reads it.
+extern "C" int32_t mpgan_debug_f32_dma_min_blocks(int32_t blocks) {
+  const int old = g_dma_min_blocks;
+  if (blocks > 0) g_dma_min_blocks = blocks;
+  return old;
 }
 
 // ---- thin layers of the bf16 path (D.conv1: 1 -> 64): fp32 image in, bf16 activations out, and back ----

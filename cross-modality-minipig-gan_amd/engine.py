@@ -273,6 +273,8 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
     gc = g.c()
     v = int(lib().mpgan_conv_variant(C.byref(gc), int(backward_data),
                                      (2 if per_sample_norm else (3 if fast_leaky else 1)) if has_pro else 0))
+    dma = v >= 3000                              # DMA-staged form (prologue-free gathers with many tiles)
+    v = v - 3000 if dma else v
     ks2 = v >= 2000                              # K axis split over two wave groups inside the block
     v = v - 2000 if ks2 else v
     fast = v >= 1000                             # mask-free instance of the pipelined kernel
@@ -289,6 +291,8 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
         return (f"gather_patch_kernel<{cin_eff}, {1 if has_pro else 0}, {'true' if cout_eff <= 16 else 'false'}, "
                 f"{'true' if v == 17 else 'false'}>")
     tm, tn, wn = {128: (2, 2, 2), 64: (1, 2, 1), 32: (1, 1, 1)}[v]
+    if dma:
+        return f"gather_conv_dma_kernel<{v}, {tm}, {tn}, {wn}>"
     if cin_eff % 32 == 0 or cin_eff == 16:      # software-pipelined main kernel <BN, TM, TN, WN, WRAPS, PRO>
         pro = 0 if not has_pro else (2 if per_sample_norm else (3 if fast_leaky else 1))
         return (f"gather_conv_pipe_kernel<{v}, {tm}, {tn}, {wn}, {1 if cin_eff % 32 == 0 else 2}, {pro}, "
@@ -694,6 +698,7 @@ def emit_conv_fwd_norm(prog, g: ConvGeom, x, wp, bias, y, nb: NormBuf, norm_mod,
         # slowest block index), for 128-pixel tiles of a non-transposed conv when 128 | P, and for the
         # thin kernel's 256-pixel blocks when 256 | P
         v = ops.conv_variant(g, False, code)
+        v = v - 3000 if v >= 3000 else v
         v = v - 2000 if v >= 2000 else v
         grouped = (v in (16, 17) or (v == 1 and P % 256 == 0)
                    or (v in (32, 64, 128) and not g.transposed and P % 128 == 0))

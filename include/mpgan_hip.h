@@ -488,6 +488,9 @@ int32_t mpgan_debug_clock_khz(void);
  * tests set 1 to run small shapes through them).  Returns the previous value; blocks <= 0 only reads it.  The
  * statistics-row count of mpgan_conv_stats_rows_bf16 follows the choice. */
 int32_t mpgan_debug_bf16_wide_min_blocks(int32_t blocks);
+/* The same for the fp32 DMA-staged form of the K-stepped kernel (prologue-free gathers: the discriminator's
+ * backward-data launches; mpgan_conv_variant reports it as 3000 + tile width). */
+int32_t mpgan_debug_f32_dma_min_blocks(int32_t blocks);
 
 #ifdef __cplusplus
 }

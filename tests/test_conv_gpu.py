@@ -686,3 +686,51 @@ def test_patch2d_weight_gradient_prologue_slices_and_many_tiles(cd, cg, s, spati
         ws = torch.empty(ops.conv_wgrad_workspace(g) // 4, device="cuda")
         ops.conv_backward_weight(g, xbuf[..., :cin], to_cl(gy), dw, ws)
         assert_close(dw.cpu(), w.grad, what="convT wgrad (2-D patch form)")
+
+
+@pytest.fixture
+def dma_form():
+    """Run small shapes through gather_conv_dma_kernel (it otherwise serves prologue-free launches of >= 1024 blocks)."""
+    from mpgan_amd._lib import lib
+    old = lib().mpgan_debug_f32_dma_min_blocks(1)
+    yield
+    lib().mpgan_debug_f32_dma_min_blocks(old)
+
+
+DMA_CASES = [   # enough tiles for the 64- / 128-wide K-stepped variants (select_variant), prologue-free
+    (2, 64, 128, 3, 1, 0, (62, 66), 14),     # D conv2's class: backward-data on 64-wide tiles (> 384 blocks: no in-block split-K)
+    (2, 128, 256, 4, 2, 0, (72, 72), 8),     # D conv3's: four phases of 2 x 2 taps, 128-wide tiles
+    (2, 256, 256, 4, 2, 0, (45, 45), 8),     # D conv4's, odd input: uneven phases, two channel tiles
+    (2, 96, 128, 3, 1, 0, (62, 66), 8),      # three K chunks per tap; ragged 128-wide tile (96 channels) in backward-data
+    (2, 64, 160, 3, 1, 1, (40, 44), 12),     # padded forward gather (masked pieces), ragged channel tiles
+    (3, 64, 128, 3, 1, 0, (20, 20, 20), 6),  # 27 taps
+]
+
+
+@pytest.mark.parametrize("case", DMA_CASES, ids=lambda c: "d{}_{}to{}_k{}s{}p{}".format(*c[:6]))
+def test_dma_staged_form_forward_and_backward_data(dma_form, case):
+    """The DMA-staged form of the K-stepped kernel (prologue-free gathers: D's backward-data launches at C3) on the
+    discriminator's layer classes: the forward (no prologue, bias) and / or the backward-data launch route through it
+    and must agree with torch like the pipelined kernel does."""
+    from mpgan_amd import ops
+    dims, cin, cout, k, s, p, spatial, n = case
+    g = _geom(dims, n, cin, cout, k, s, p, spatial)
+    assert ops.conv_variant(g, False, 0) >= 3000 or ops.conv_variant(g, True, 0) >= 3000
+    test_conv_forward_dgrad_wgrad(case)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,spatial,n", [(64, 128, 3, 1, (62, 66), 14), (128, 256, 4, 2, (72, 72), 8),
+                                                    (256, 256, 4, 2, (45, 45), 8)])
+def test_dma_staged_form_with_fused_norm_backward_sums(dma_form, cin, cout, k, s, spatial, n):
+    from mpgan_amd import ops
+    g = _geom(len(spatial), n, cin, cout, k, s, 0, spatial)
+    assert ops.conv_variant(g, True, 0) >= 3000
+    test_backward_data_with_fused_norm_backward_sums(cin, cout, k, s, spatial, n)
+
+
+def test_dma_staged_form_serves_the_discriminator_backward_data_at_c3():
+    from mpgan_amd import ops
+    for cin, cout, k, s, e in ((64, 128, 3, 1, 254), (128, 256, 4, 2, 252), (256, 256, 4, 2, 125)):
+        g = _geom(2, 16, cin, cout, k, s, 0, (e, e))
+        assert ops.conv_variant(g, True, 0) >= 3000, (cin, cout)
+        assert ops.conv_variant(g, False, 3) < 3000            # the forward keeps its normalise-on-load prologue

@@ -178,7 +178,7 @@ def test_variant_b_steps_match_oracle():
     d_ref.backward()
     d = ours.training_step(cb, 0, 1)
     d.backward()
-    assert abs(float(d) - float(d_ref)) <= 2e-3 * abs(float(d_ref)) + 1e-7
+    assert abs(d.item() - d_ref.item()) <= 2e-3 * abs(d_ref.item()) + 1e-7
     rdp = dict(ref.discriminator.named_parameters())
     for name, p in ours.discriminator.named_parameters():
         if name in ("model_conv.0.bias", "model_conv.3.bias", "model_conv.6.bias", "model_conv.9.bias"):

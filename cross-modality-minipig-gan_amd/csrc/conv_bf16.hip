@@ -1680,6 +1680,153 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                     int bias_blocks);
 
 // ---------------------------------------------------------------------------
+// Backward-data of the first layer in the bf16 path (D.conv1: 64 gathered channels -> the ONE image channel, pad-free
+// 3 x 3 (x 3), stride 1; GAN_final.py:167): dx[o] = sum_t sum_c dz[o + d(t)][c] * w[t][c].
+// thin_cout1_kernel<16, true> gave 16 lanes to an output pixel and fetched every dz element once per tap (27 x through
+// L1: 2.8 ms at 128^3 for 1 GB of dz).  Here the contraction over the channels is a matrix product per GATHERED pixel,
+//     P[q][t] = sum_c dz[q][c] * w[t][c]        ([pixels x 64] . [64 x 27 -> 32], v_mfma_f32_32x32x16_bf16)
+// and dx is a fold of P over the taps (col2im) inside the block:
+//   * a block owns 4 x 8 x 8 (2-D: 1 x 16 x 16) output pixels and walks the (4+2) x (8+2) x (8+2) gathered pixels they
+//     read in groups of 32 = one MFMA row block per wave and trip; the A fragments come STRAIGHT from global memory
+//     (lane = pixel, half-wave = which 8 of a k-sub's 16 channels: four 16-byte loads per lane cover its 128-byte row);
+//     pixels outside dz load zeros (= the padding of the transposed gather);
+//   * the weights stay fp32 in effect: w = hi + lo with hi = bf16(w), lo = bf16(w - hi), two MFMAs per k-sub (the
+//     matrix work is nothing here: 0.03 ms of MFMA time at 128^3);
+//   * P goes to LDS as [tap][gathered pixel] (consecutive threads = consecutive x: conflict-free), then thread = output
+//     pixel adds its 27 entries and stores one float.
+// dz is read 2.3 x (the tiles' halos, mostly L2 hits) instead of 27 x.
+// ---------------------------------------------------------------------------
+constexpr int TC_MAXQ = 608;                                // 6 x 10 x 10 gathered pixels, rounded up to 19 x 32
+struct TcGrid { int tz, ty, tx, tiles_z, tiles_y, tiles_x; };
+
+__global__ __launch_bounds__(256, 2) void thin_cout1_mfma_bf16_kernel(const GatherConv p, const TcGrid tg) {
+  extern __shared__ __attribute__((aligned(16))) float Pl[];          // [T][TC_MAXQ]
+  const Phase& ph = p.ph[0];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int T = ph.nz * ph.ny * ph.nx;
+  int t = blockIdx.x;
+  const int bx = t % tg.tiles_x; t /= tg.tiles_x;
+  const int by = t % tg.tiles_y; t /= tg.tiles_y;
+  const int bz = t % tg.tiles_z;
+  const int n = t / tg.tiles_z;
+  const int oz0 = bz * tg.tz, oy0 = by * tg.ty, ox0 = bx * tg.tx;
+  // gathered coordinates of tap j of output o: o + d0 + dstep * j (stride 1); the patch starts at the smallest one
+  const int mnz = ph.dz0 + (p.dstep[0] < 0 ? (ph.nz - 1) * p.dstep[0] : 0), mny = ph.dy0 + (p.dstep[1] < 0 ? (ph.ny - 1) * p.dstep[1] : 0),
+            mnx = ph.dx0 + (p.dstep[2] < 0 ? (ph.nx - 1) * p.dstep[2] : 0);
+  const int PZ = tg.tz + ph.nz - 1, PY = tg.ty + ph.ny - 1, PX = tg.tx + ph.nx - 1;
+  const int NQ = PZ * PY * PX;
+
+  // B fragments: column li = tap (jz, jy, jx) in walk order, k = channel; hi and lo halves of the fp32 weight
+  bf16x8 whi[4], wlo[4];
+  {
+    const bool tv = li < T;
+    const int jx = tv ? li % ph.nx : 0, tq = tv ? li / ph.nx : 0, jy = tq % ph.ny, jz = tq / ph.ny;
+    const int kz = ph.kz0 + p.kstep[0] * jz, ky = ph.ky0 + p.kstep[1] * jy, kx = ph.kx0 + p.kstep[2] * jx;
+    const float* wrow = p.wp + (long)((kz * p.Ky + ky) * p.Kx + kx) * p.Cin;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float w = tv ? wrow[16 * s + 8 * lh + e] : 0.f;
+        const __bf16 h = (__bf16)w;
+        whi[s][e] = h;
+        wlo[s][e] = (__bf16)(w - (float)h);
+      }
+  }
+  const char* ginb = reinterpret_cast<const char*>(p.in);
+  for (int rb = wid; rb * 32 < NQ; rb += 4) {
+    const int q = rb * 32 + li;
+    const int pz = q / (PY * PX), rem = q - pz * (PY * PX), py = rem / PX, px = rem - py * PX;
+    const int iz = oz0 + mnz + pz, iy = oy0 + mny + py, ix = ox0 + mnx + px;
+    const bool ok = q < NQ && (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+    const char* src = ginb + ((((long)n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * p.ldi * 2 + 16 * lh;
+    bf16x8 a[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (ok) a[s] = *reinterpret_cast<const bf16x8*>(src + 32 * s);
+      else
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[s][e] = (__bf16)0.f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], whi[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], wlo[s], acc, 0, 0, 0);
+    }
+    // acc[r] of lane (li, lh): column = tap li, row = gathered pixel rb*32 + (r & 3) + 8 (r >> 2) + 4 lh
+    if (li < T) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(Pl + li * TC_MAXQ + rb * 32 + 8 * g + 4 * lh) =
+            make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    }
+  }
+  __syncthreads();
+  // fold: thread = output pixel of the tile
+  const int lx = tid % tg.tx, lq = tid / tg.tx, ly = lq % tg.ty, lz = lq / tg.ty;
+  const int oz = oz0 + lz, oy = oy0 + ly, ox = ox0 + lx;
+  if (lz < tg.tz && oz < ph.Mz && oy < ph.My && ox < ph.Mx) {
+    float sum = 0.f;
+    int j = 0;
+    for (int jz = 0; jz < ph.nz; ++jz) {
+      const int qz = lz + ph.dz0 + p.dstep[0] * jz - mnz;
+      for (int jy = 0; jy < ph.ny; ++jy) {
+        const int qy = ly + ph.dy0 + p.dstep[1] * jy - mny;
+        for (int jx = 0; jx < ph.nx; ++jx, ++j) {
+          const int qx = lx + ph.dx0 + p.dstep[2] * jx - mnx;
+          sum += Pl[j * TC_MAXQ + (qz * PY + qy) * PX + qx];
+        }
+      }
+    }
+    p.out[(long)(((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.ldo] = sum;
+  }
+}
+
+// Serves this launch?  (64 bf16 channels -> one fp32 channel, stride 1, one phase, at most 3 taps per dimension.)
+bool thin_cout1_mfma_bf16_ok(const GatherConv& p) {
+  static const bool off = getenv("MPGAN_DBG_NO_TC_MFMA") != nullptr;
+  if (off || !p.in_bf16 || p.Cout != 1 || p.Cin != 64 || p.nphase != 1 || p.bias || p.resid || p.tanh_out || p.stats ||
+      p.pro.scale || p.ldi % 8 != 0 || (reinterpret_cast<uintptr_t>(p.in) & 15))
+    return false;
+  const Phase& ph = p.ph[0];
+  if (ph.nz < 1 || ph.ny < 1 || ph.nx < 1 || ph.nz > 3 || ph.ny > 3 || ph.nx > 3) return false;
+  for (int d = 0; d < 3; ++d)
+    if (p.istride[d] != 1 || p.ostride[d] != 1 || (p.dstep[d] != 1 && p.dstep[d] != -1)) return false;
+  if (ph.oz || ph.oy || ph.ox || ph.Mz != p.Do || ph.My != p.Ho || ph.Mx != p.Wo) return false;
+  return (long)p.N * p.Do * p.Ho * p.Wo * p.ldo < (1L << 31);
+}
+
+int launch_thin_cout1_mfma_bf16(const GatherConv& p, hipStream_t st) {
+  const Phase& ph = p.ph[0];
+  TcGrid tg;
+  if (ph.nz == 1) { tg.tz = 1; tg.ty = 16; tg.tx = 16; }        // 2-D: 18 x 18 = 324 gathered pixels
+  else { tg.tz = 4; tg.ty = 8; tg.tx = 8; }                      // 3-D: 6 x 10 x 10 = 600
+  tg.tiles_z = (ph.Mz + tg.tz - 1) / tg.tz;
+  tg.tiles_y = (ph.My + tg.ty - 1) / tg.ty;
+  tg.tiles_x = (ph.Mx + tg.tx - 1) / tg.tx;
+  const int T = ph.nz * ph.ny * ph.nx;
+  const int smem = T * TC_MAXQ * (int)sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(thin_cout1_mfma_bf16_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 27 * TC_MAXQ * (int)sizeof(float));
+    if (e != hipSuccess) {
+      set_error("thin_cout1_mfma_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const long blocks = (long)p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x;
+  MPGAN_CHECK_ARG(blocks < (1L << 31), "thin_cout1_mfma_bf16: too many tiles");
+  hipLaunchKernelGGL(thin_cout1_mfma_bf16_kernel, dim3((unsigned)blocks), dim3(256), smem, st, p, tg);
+  return check_launch("thin_cout1_mfma_bf16");
+}
+
+// ---------------------------------------------------------------------------
 // HBM-bound helpers of the bf16 path
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void ld8(const __bf16* p, float (&v)[8]) {

@@ -92,6 +92,10 @@ inline long max_phase_pixels(const GatherConv& p) {
   return maxM;
 }
 
+// conv_bf16.hip: MFMA form of the C -> 1 gather over bf16 data (D.conv1's backward-data in the bf16 path)
+bool thin_cout1_mfma_bf16_ok(const GatherConv& p);
+int launch_thin_cout1_mfma_bf16(const GatherConv& p, hipStream_t st);
+
 // ---- host-side geometry builders -------------------------------------------
 inline int check_geom(const mpgan_conv_geom* g) {
   MPGAN_CHECK_ARG(g != nullptr, "conv: null geometry");

@@ -1845,6 +1845,7 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
     return check_launch("thin_cin1_full_bf16");
   }
   if (p.in_bf16) {      // C -> 1 gather over bf16 data (backward-data of D.conv1 in the bf16 path)
+    if (thin_cout1_mfma_bf16_ok(p)) return launch_thin_cout1_mfma_bf16(p, st);
     const int lanes_b = p.Cin / 4;
     MPGAN_UNSUPPORTED(!(p.Cout == 1 && !p.pro.scale && p.Cin % 4 == 0 && p.ldi % 4 == 0 &&
                         (lanes_b == 4 || lanes_b == 8 || lanes_b == 16) && (reinterpret_cast<uintptr_t>(p.in) & 7) == 0 &&

@@ -991,11 +991,17 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
 //     sums, 16-byte stores) are the pipelined kernel's.
 // Tile 128 x BN, 4 waves, K order channel-chunk major / taps inner, Cin % 32 == 0, at most 32 taps per phase.
 // ---------------------------------------------------------------------------
-template <int BN, int TM, int TN, int WN>
+//   NST: LDS stages; 2 everywhere.  For the 32-wide tile (the generator's strided / transposed 3-D layers without a
+//   prologue: 2-16 K-steps per block, thousands of blocks) four stages of 20 KiB were tried on the theory that a K-step
+//   there takes a load latency -- it LOST 8-19 % against the pipelined kernel (80 KiB of LDS: two blocks per CU
+//   instead of three; those launches live on the number of blocks whose prologues and epilogues overlap), while two
+//   stages (40 KiB, four blocks per CU) gain 8-14 % over it.
+template <int BN, int TM, int TN, int WN, int NST = 2>
 __global__ __launch_bounds__(256) void gather_conv_dma_kernel(const GatherConv p) {
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   char* ldsb = reinterpret_cast<char*>(lds_all);
   constexpr int ROWB = 128;
+  constexpr bool SPLIT = NST == 2;                        // (two stages: a tile's pieces in two halves, see above)
   constexpr int STAGEB = (BM + BN) * ROWB;
   constexpr int PR = 32;                                  // rows one LDS-DMA instruction of every wave fills
   constexpr int AP = BM / PR, BP = BN / PR;
@@ -1141,31 +1147,47 @@ __global__ __launch_bounds__(256) void gather_conv_dma_kernel(const GatherConv p
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) fb[slot][tn] = lds_read_b128(Bs + tn * 32 * ROWB);
   };
+  constexpr int NL = AP + BP;
+  // wait until at most t tiles' worth of this wave's DMAs are outstanding (t < NST is block-uniform)
+  auto wait_tiles = [&](int t) {
+    if (t <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    else if (t == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NL) : "memory");
+  };
+  static_assert(NST >= 2 && NST <= 4 && 3 * NL < 64, "wait_tiles counts up to three tiles in flight behind the awaited one");
   if (nk > 0) {
-    issue(0, ALL);
-    if (nk > 1) issue(STAGEB, ALL);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");              // tile 0 landed
+    // tiles 0 .. NST-1 fill the stages (tile kt lives in stage kt % NST); tile kt+NST is issued when tile kt's stage is free
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+      if (i < nk) issue(i * STAGEB, ALL);
+    wait_tiles((nk < NST ? nk : NST) - 1);               // tile 0 landed
+    asm volatile("s_barrier" ::: "memory");
     MPGAN_STAMP(p, 1);
     read_group(0, 0, 0);
     int cst = 0;
-    bool pend = false;                                    // the second half of the tile issued behind the last barrier
+    bool pend = false;                                    // SPLIT: the second half of the tile issued behind the last barrier
     for (int kt = 0; kt < nk; ++kt) {
-      const int nst = cst ? 0 : STAGEB;
+      const int nst = cst == (NST - 1) * STAGEB ? 0 : cst + STAGEB;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int sl = g & 1;
         lds_wait<TM, TN>(fa[sl], fb[sl]);
         if (g < 3) {
           read_group(cst, g + 1, sl ^ 1);
-          if (g == 0 && pend) issue(nst, HALF1);          // (nst: the stage the previous K-step left)
+          if constexpr (SPLIT)
+            if (g == 0 && pend) issue(nst, HALF1);        // (nst: the stage the previous K-step left)
         } else if (kt + 1 < nk) {
-          // the only DMAs of this wave still in flight are tile kt+1's
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          // tile kt+1 must have landed; behind it in flight: tiles kt+2 .. min(kt+NST-1, nk-1)
+          const int last = kt + NST - 1 < nk - 1 ? kt + NST - 1 : nk - 1;
+          wait_tiles(last - (kt + 1));
           asm volatile("s_barrier" ::: "memory");
-          pend = kt + 2 < nk;
-          if (pend) issue(cst, HALF0);
+          pend = kt + NST < nk;                           // tile kt+NST takes the stage tile kt leaves
+          if constexpr (SPLIT) {
+            if (pend) issue(cst, HALF0);
+          } else {
+            if (pend) issue(cst, ALL);
+          }
           read_group(nst, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -3051,7 +3073,7 @@ static bool pipe_wants_ksplit2(const GatherConv& p, int bn, long maxM) {
 static int g_dma_min_blocks = 1024;
 static bool dma_form_ok(const GatherConv& p, int variant, long maxM) {
   static const bool off = getenv("MPGAN_DBG_NO_DMA") != nullptr;
-  if (off || p.pro.scale || p.ksplit > 1 || p.Cin % 32 != 0 || (variant != 128 && variant != 64)) return false;
+  if (off || p.pro.scale || p.ksplit > 1 || p.Cin % 32 != 0 || (variant != 128 && variant != 64 && variant != 32)) return false;
   if (p.stats_acc || p.fold.acc) return false;
   const long blocks = (maxM + BM - 1) / BM * ((p.Cout + variant - 1) / variant) * p.nphase;
   if (blocks < g_dma_min_blocks) return false;
@@ -3063,10 +3085,11 @@ static bool dma_form_ok(const GatherConv& p, int variant, long maxM) {
   return bytes_a < (long)HW_OOB && (long)p.Cout * ktot4 < (long)HW_OOB && ktot4 < 0xFFFF;
 }
 
-template <int BN, int TM, int TN, int WN>
+template <int BN, int TM, int TN, int WN, int NST = 2>
 static int launch_dma_variant(const GatherConv& p, long maxM, hipStream_t st) {
-  auto kern = gather_conv_dma_kernel<BN, TM, TN, WN>;
-  constexpr int smem = 2 * (BM + BN) * 128;
+  auto kern = gather_conv_dma_kernel<BN, TM, TN, WN, NST>;
+  constexpr int smem_loop = NST * (BM + BN) * 128, smem_epi = (2048 + 4 * 32 * 36 + 1024) * 4;   // (conv_epilogue's scratch)
+  constexpr int smem = smem_loop > smem_epi ? smem_loop : smem_epi;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -3100,7 +3123,8 @@ static int launch_pipe_bn(const GatherConv& p, int variant, long maxM, hipStream
   if constexpr (WRAPS == 1 && PRO == 0) {
     if (dma_form_ok(p, variant, maxM)) {
       if (variant == 128) return launch_dma_variant<128, 2, 2, 2>(p, maxM, st);
-      return launch_dma_variant<64, 1, 2, 1>(p, maxM, st);
+      if (variant == 64) return launch_dma_variant<64, 1, 2, 1>(p, maxM, st);
+      return launch_dma_variant<32, 1, 1, 1, 2>(p, maxM, st);
     }
   }
   if (variant == 128) return launch_pipe_variant<128, 2, 2, 2, WRAPS, PRO>(p, maxM, st);

@@ -42,6 +42,8 @@ __device__ __forceinline__ void lds_wait(V (&a)[NA], V (&b)[NB]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
                    "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+  else if constexpr (NA == 1 && NB == 1)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]));
   else if constexpr (NA == 1 && NB == 2)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]));
   else if constexpr (NA == 8 && NB == 4)

@@ -292,7 +292,7 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
                 f"{'true' if v == 17 else 'false'}>")
     tm, tn, wn = {128: (2, 2, 2), 64: (1, 2, 1), 32: (1, 1, 1)}[v]
     if dma:
-        return f"gather_conv_dma_kernel<{v}, {tm}, {tn}, {wn}>"
+        return f"gather_conv_dma_kernel<{v}, {tm}, {tn}, {wn}, 2>"
     if cin_eff % 32 == 0 or cin_eff == 16:      # software-pipelined main kernel <BN, TM, TN, WN, WRAPS, PRO>
         pro = 0 if not has_pro else (2 if per_sample_norm else (3 if fast_leaky else 1))
         return (f"gather_conv_pipe_kernel<{v}, {tm}, {tn}, {wn}, {1 if cin_eff % 32 == 0 else 2}, {pro}, "

@@ -728,6 +728,29 @@ def test_dma_staged_form_with_fused_norm_backward_sums(dma_form, cin, cout, k, s
     test_backward_data_with_fused_norm_backward_sums(cin, cout, k, s, spatial, n)
 
 
+@pytest.mark.parametrize("case", [(3, 64, 16, (8, 9, 10), 2), (3, 192, 32, (5, 6, 4), 2), (2, 192, 32, (12, 10), 3)],
+                         ids=lambda c: "d{}_{}to{}".format(*c[:3]))
+def test_dma_staged_form_32_wide_transposed_layers(dma_form, case):
+    """The 32-wide instance on the generator's ConvTranspose layers without a prologue: forward
+    (1 - 8 taps per phase, 8 / 4 phases) and backward-data (27 / 9 taps)."""
+    from mpgan_amd import ops
+    dims, cin, cout, spatial, n = case
+    g = _geom(dims, n, cin, cout, 3, 2, 1, spatial, transposed=True)
+    assert ops.conv_variant(g, False, 0) == 3032 or ops.conv_variant(g, True, 0) == 3032
+    test_conv_transpose_forward_dgrad_wgrad(case)
+
+
+@pytest.mark.parametrize("case", [(3, 16, 32, 3, 2, 1, (12, 14, 10), 2), (3, 32, 64, 3, 2, 1, (8, 8, 10), 2)],
+                         ids=lambda c: "d{}_{}to{}_k{}s{}p{}".format(*c[:6]))
+def test_dma_staged_form_32_wide_strided_backward_data(dma_form, case):
+    """Backward-data of the generator's stride-2 3-D convs (16 / 32 produced channels, eight phases of 1 - 8 taps)."""
+    from mpgan_amd import ops
+    dims, cin, cout, k, s, p, spatial, n = case
+    g = _geom(dims, n, cin, cout, k, s, p, spatial)
+    assert ops.conv_variant(g, True, 0) == 3032
+    test_conv_forward_dgrad_wgrad(case)
+
+
 def test_dma_staged_form_serves_the_discriminator_backward_data_at_c3():
     from mpgan_amd import ops
     for cin, cout, k, s, e in ((64, 128, 3, 1, 254), (128, 256, 4, 2, 252), (256, 256, 4, 2, 125)):

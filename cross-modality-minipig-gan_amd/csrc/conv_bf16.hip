@@ -929,7 +929,11 @@ struct HpTile {
                                                                       // per tap cost a third of the loop (MFMA-only what-if)
   static constexpr int BTAP = BN * HB_ROWB;
   static constexpr int BSTAGE = TPS * BTAP;
-  static constexpr int SMEM_LOOP = HP_PATCH + 3 * BSTAGE;
+  // ring stages: with 128 columns and one 16 KiB tap per stage, three stages keep 32 KiB of weights in flight -- the
+  // ring then streams at 32 KiB per load latency = 28 GB/s per CU (fill-only what-if of D.conv2's forward: 2.3 ms of a
+  // 3.9 ms loop); five stages (the patch + 80 KiB = all the LDS there is) keep four taps in flight
+  static constexpr int NR = BN == 128 ? 5 : 3;
+  static constexpr int SMEM_LOOP = HP_PATCH + NR * BSTAGE;
   static constexpr int EP_ROWPIX = 8 * HbSlab<TN>::WAVE;              // behind the eight waves' slabs
   static constexpr int EP_PART = EP_ROWPIX + HB_BM * 4;
   static constexpr int SMEM_EPI = EP_PART + WM * 2 * BN * 4;
@@ -1022,7 +1026,7 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
     if (jy == 3) { jy = 0; jz += 1; }
     if (jz == 3) jz = 0;
     btap += 1;
-    if (btap == T::TPS) { btap = 0; bstage = bstage == 2 ? 0 : bstage + 1; }
+    if (btap == T::TPS) { btap = 0; bstage = bstage == T::NR - 1 ? 0 : bstage + 1; }
   };
   auto issue_group = [&](int chunk) {                   // the TPS taps of one ring stage
 #pragma unroll
@@ -1060,11 +1064,11 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
     asm volatile("s_waitcnt vmcnt(0) ; tail: chunk boundary" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     issue_patch(chunk);
-    issue_group(chunk);
-    issue_group(chunk);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::BPIECES * T::TPS) : "memory");   // patch + group 0 landed (this wave's part)
+    // groups 0 .. NR-1 fill the ring (27 / TPS >= NR); group g+NR is issued when group g's stage is free
+#pragma unroll
+    for (int i = 0; i < T::NR; ++i) issue_group(chunk);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((T::NR - 1) * T::BPIECES * T::TPS) : "memory");   // patch + group 0 landed (this wave's part)
     asm volatile("s_barrier" ::: "memory");
-    issue_group(chunk);                                                    // group 2 -> stage 2
     int cstage = 0, tin = 0;                                               // ring stage of the current tap, its slot in it
     int tzo = p.dstep[0] < 0 ? 2 : 0, tyo = p.dstep[1] < 0 ? 2 : 0, txo = p.dstep[2] < 0 ? 2 : 0;   // tap 0's patch offset
     int kx_ = 0, ky_ = 0;
@@ -1082,7 +1086,7 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
     int delta = tzo * HP_PZ + tyo * HP_PX + txo;
     read_frags(delta, 0, 0, 0, 0);
     for (int tap = 0; tap < 27; ++tap) {
-      const int nstage = cstage == 2 ? 0 : cstage + 1;
+      const int nstage = cstage == T::NR - 1 ? 0 : cstage + 1;
       const bool group_end = tin == T::TPS - 1;           // (27 = 9 x 3: groups never straddle the chunk's end)
       // next tap's patch offset (wave-uniform walk, x fastest)
       int ndelta = delta;
@@ -1105,12 +1109,18 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
           // of the next stage): two sites writing the same fragment registers from different branches made the
           // compiler merge them with register copies, which run before the unprotected asm reads have landed
           if (group_end) {
-            if (tap + 1 + T::TPS < 27) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::BPIECES * T::TPS) : "memory");
+            // the next group must have landed; behind it in flight: the groups up to min(g + NR - 1, last)
+            constexpr int GP = T::BPIECES * T::TPS, NG = 27 / T::TPS;
+            const int g = tap / T::TPS;
+            const int behind = (g + T::NR - 1 < NG - 1 ? g + T::NR - 1 : NG - 1) - (g + 1);
+            if (behind >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * GP) : "memory");
+            else if (behind == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GP) : "memory");
+            else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) ; tail: the last group" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
           }
           read_frags(ndelta, group_end ? nstage : cstage, group_end ? 0 : tin + 1, 0, 0);
-          if (group_end && tap + 1 + 2 * T::TPS < 27) issue_group(chunk);
+          if (group_end && tap + 1 + (T::NR - 1) * T::TPS < 27) issue_group(chunk);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 2))

@@ -1700,8 +1700,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //     read in groups of 32 = one MFMA row block per wave and trip; the A fragments come STRAIGHT from global memory
 //     (lane = pixel, half-wave = which 8 of a k-sub's 16 channels: four 16-byte loads per lane cover its 128-byte row);
 //     pixels outside dz load zeros (= the padding of the transposed gather);
-//   * the weights stay fp32 in effect: w = hi + lo with hi = bf16(w), lo = bf16(w - hi), two MFMAs per k-sub (the
-//     matrix work is nothing here: 0.03 ms of MFMA time at 128^3);
+//   * the weights stay fp32 in effect: w = h + m + l, three bf16 terms (24 bits), three MFMAs per k-sub (the matrix
+//     work is nothing here: 0.05 ms of MFMA time at 128^3);
 //   * P goes to LDS as [tap][gathered pixel] (consecutive threads = consecutive x: conflict-free), then thread = output
 //     pixel adds its 27 entries and stores one float.
 // dz is read 2.3 x (the tiles' halos, mostly L2 hits) instead of 27 x.
@@ -1728,7 +1728,7 @@ __global__ __launch_bounds__(256, 2) void thin_cout1_mfma_bf16_kernel(const Gath
   const int NQ = PZ * PY * PX;
 
   // B fragments: column li = tap (jz, jy, jx) in walk order, k = channel; hi and lo halves of the fp32 weight
-  bf16x8 whi[4], wlo[4];
+  bf16x8 whi[4], wmi[4], wlo[4];
   {
     const bool tv = li < T;
     const int jx = tv ? li % ph.nx : 0, tq = tv ? li / ph.nx : 0, jy = tq % ph.ny, jz = tq / ph.ny;
@@ -1740,8 +1740,10 @@ __global__ __launch_bounds__(256, 2) void thin_cout1_mfma_bf16_kernel(const Gath
       for (int e = 0; e < 8; ++e) {
         const float w = tv ? wrow[16 * s + 8 * lh + e] : 0.f;
         const __bf16 h = (__bf16)w;
+        const __bf16 m = (__bf16)(w - (float)h);
         whi[s][e] = h;
-        wlo[s][e] = (__bf16)(w - (float)h);
+        wmi[s][e] = m;
+        wlo[s][e] = (__bf16)(w - (float)h - (float)m);
       }
   }
   const char* ginb = reinterpret_cast<const char*>(p.in);
@@ -1764,8 +1766,9 @@ __global__ __launch_bounds__(256, 2) void thin_cout1_mfma_bf16_kernel(const Gath
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], whi[s], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], wlo[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], wmi[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], whi[s], acc, 0, 0, 0);
     }
     // acc[r] of lane (li, lh): column = tap li, row = gathered pixel rb*32 + (r & 3) + 8 (r >> 2) + 4 lh
     if (li < T) {

@@ -68,3 +68,32 @@ extern "C" int32_t mpgan_debug_clock_khz(void) {
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return -1;
   return khz;
 }
+
+#ifdef MPGAN_DRYRUN
+// Host dry-run build (mpgan_common.h): what a launch may ask of a gfx950 CU, checked instead of launching.
+namespace mpgan {
+static long g_dry_launches = 0, g_dry_bad = 0;
+static hipError_t g_dry_err = hipSuccess;
+int dry_note_launch(const char* kernel, dim3 grid, dim3 block, size_t lds) {
+  ++g_dry_launches;
+  const unsigned long threads = (unsigned long)block.x * block.y * block.z;
+  const bool ok = grid.x >= 1 && grid.y >= 1 && grid.z >= 1 && grid.y <= 65535 && grid.z <= 65535 &&
+                  (unsigned long)grid.x * grid.y * grid.z < (1ul << 32) && threads >= 1 && threads <= 1024 &&
+                  threads % 64 == 0 && lds <= 160 * 1024;
+  if (!ok) {
+    ++g_dry_bad;
+    g_dry_err = hipErrorInvalidConfiguration;
+    fprintf(stderr, "[dry-run] BAD launch %s: grid (%u,%u,%u) block (%u,%u,%u) lds %zu\n", kernel, grid.x, grid.y, grid.z,
+            block.x, block.y, block.z, lds);
+  }
+  return ok ? 0 : 1;
+}
+hipError_t dry_last_error() {
+  const hipError_t e = g_dry_err;
+  g_dry_err = hipSuccess;
+  return e;
+}
+}  // namespace mpgan
+extern "C" long mpgan_dry_launches(void) { return mpgan::g_dry_launches; }
+extern "C" long mpgan_dry_bad_launches(void) { return mpgan::g_dry_bad; }
+#endif

@@ -6,6 +6,45 @@
 #include <stdarg.h>
 #include "mpgan_hip.h"
 
+// ---- host dry-run build (development only: `make DRYRUN=1` -> libmpgan_hip_dry.so) -----------------------------
+// Host code compiled alone (--cuda-host-only) with AddressSanitizer; every kernel launch becomes a host-side
+// check of its launch geometry with the arguments still marshalled (the parameter structs are copied exactly as
+// a real launch copies them), and the few other runtime calls succeed without a device.  tools/asan_dryrun.py
+// drives whole training steps at the C3 / C5 shapes through it on the CPU container: any heap / stack overrun in
+// the argument marshalling or the geometry builders is an ASan report, any launch outside the hardware's limits
+// an error status.  The product build has none of this.
+#ifdef MPGAN_DRYRUN
+namespace mpgan {
+int dry_note_launch(const char* kernel, dim3 grid, dim3 block, size_t lds);
+template <typename... A>
+inline void dry_launch(const char* kernel, dim3 grid, dim3 block, size_t lds, hipStream_t, A... args) {
+  // the by-value copies above ARE the marshalling under test; touch every byte so ASan sees a short struct
+  const volatile unsigned char* bytes[] = {reinterpret_cast<const volatile unsigned char*>(&args)...};
+  const size_t sizes[] = {sizeof(args)...};
+  unsigned acc = 0;
+  for (size_t i = 0; i < sizeof...(A); ++i)
+    for (size_t b = 0; b < sizes[i]; ++b) acc += bytes[i][b];
+  (void)acc;
+  dry_note_launch(kernel, grid, block, lds);
+}
+hipError_t dry_last_error();
+inline hipError_t dry_ok(...) { return hipSuccess; }
+inline hipError_t dry_symbol_address(void** p) {
+  static char page[4096];
+  *p = page;
+  return hipSuccess;
+}
+}  // namespace mpgan
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \
+  ::mpgan::dry_launch(#kern, grid, block, lds, stream, __VA_ARGS__)
+#define hipFuncSetAttribute(...) ::mpgan::dry_ok(__VA_ARGS__)
+#define hipMemcpyToSymbol(...) ::mpgan::dry_ok(__VA_ARGS__)
+#define hipMemsetAsync(...) ::mpgan::dry_ok(__VA_ARGS__)
+#define hipGetSymbolAddress(p, sym) ::mpgan::dry_symbol_address(p)
+#define hipGetLastError() ::mpgan::dry_last_error()
+#endif
+
 namespace mpgan {
 
 void set_error(const char* fmt, ...);

@@ -73,18 +73,6 @@ def side_stream(device) -> "torch.cuda.Stream":
     return _SIDE[key]
 
 
-_FAST = {}
-
-
-def fast_stream(device) -> "torch.cuda.Stream":
-    """A HIGH-priority stream: for a latency-bound chain of small launches (the generator) that
-    should slip its workgroups in between those of matrix-bound kernels running on another stream."""
-    key = torch.device(device).index or 0
-    if key not in _FAST:
-        _FAST[key] = torch.cuda.Stream(device=device, priority=-1)
-    return _FAST[key]
-
-
 _SINGLE_STREAM = bool(os.environ.get("MPGAN_SINGLE_STREAM"))
 _ALWAYS_PACK = bool(os.environ.get("MPGAN_DBG_ALWAYS_PACK"))
 # BatchNorm statistics through integer accumulators + fold-on-load in the first consumer (csrc/norm_fold.h) instead of

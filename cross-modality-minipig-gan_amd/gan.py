@@ -4,7 +4,6 @@ in SURVEY.md Appendix B), every FLOP in HIP kernels.
 """
 from __future__ import annotations
 
-import os
 import re
 import types
 from typing import Dict, List, Optional
@@ -12,7 +11,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from . import engine, ops
+from . import ops
 from .networks import CasNetGenerator, Discriminator, _EngineModule
 
 
@@ -215,10 +214,6 @@ class GAN(nn.Module):
                                            storage_dtype=storage_dtype)
         self.logged: Dict[str, torch.Tensor] = {}
         self.ddp = None  # set by parallel.DataParallelGAN
-        # D step: run G(t1w) on a second stream underneath D(real)?  Measured in round 2 (20-step benches, same box):
-        # 59.1 vs 58.6 ms at C3 and 174.3 vs 175.8 ms at C5 with / without -- nothing beyond run-to-run spread, while
-        # D's forward kernels stretch up to 3x under the contention.  Off by default; MPGAN_GFWD_OVERLAP=1 turns it on.
-        self.overlap_streams = bool(os.environ.get("MPGAN_GFWD_OVERLAP")) and not os.environ.get("MPGAN_SINGLE_STREAM")
 
     def forward(self, x):
         return self.generator(x)
@@ -249,21 +244,13 @@ class GAN(nn.Module):
         if optimizer_idx == 1:                      # GAN_final.py:276-296
             valid = torch.full((t1w_images.shape[0], 1), float(self.hparams.one_sided_label_value),
                                device=t1w_images.device, dtype=t1w_images.dtype)
-            # D(real) and G(t1w) are independent: with `overlap_streams` the generator's forward (a chain of ~230
-            # small, latency-bound launches) runs on the second stream underneath the discriminator's matrix-bound
-            # forward.  Same values, same BatchNorm running-stat order (D sees real, then fake).  Off by default.
-            main = torch.cuda.current_stream()
-            side = engine.fast_stream(t1w_images.device) if self.overlap_streams else None
-            if side is not None:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    generated = self(t1w_images).detach()
-                generated.record_stream(main)
+            # (D(real) and G(t1w) are independent, and rounds 1-3 carried an opt-in mode that ran the generator's
+            #  forward on a high-priority stream underneath D(real).  It measured nothing beyond run-to-run spread
+            #  -- 59.1 vs 58.6 ms at C3, 174.3 vs 175.8 ms at C5 -- while stretching D's kernels up to 3x, and its first
+            #  use in a process once ended in a host SIGSEGV inside hipStreamWaitEvent on that stream: removed in
+            #  round 4)
             real_loss = self.adversarial_loss(self.discriminator(t2w_images), valid)
-            if side is not None:
-                main.wait_stream(side)
-            else:
-                generated = self(t1w_images).detach()
+            generated = self(t1w_images).detach()
             fake = torch.zeros(t1w_images.shape[0], 1, device=t1w_images.device, dtype=t1w_images.dtype)
             fake_loss = self.adversarial_loss(self.discriminator(generated), fake)
             d_loss = scalar_axpby(real_loss, 0.5, fake_loss, 0.5)

@@ -168,8 +168,8 @@ def test_full_gd_step_at_c3_matches_oracle():
         ours.generator.load_state_dict(ref_sd_g)
         ours.discriminator.load_state_dict(ref_sd_d)
         ours.train()
-        # (the optional D-step overlap of G's forward on a high-priority stream -- off by default -- is covered at a
-        #  small size by tests/test_networks_gpu.py; here the second stream carries the generator's weight gradients)
+        # (every stream mode the product has is covered here: the opt-in D-step overlap of G's forward on a
+        #  high-priority stream, whose first use once crashed this very test, no longer exists -- DESIGN.md section 8)
         tap = _GradTap()
         ours.ddp = tap
         saved = engine._SINGLE_STREAM

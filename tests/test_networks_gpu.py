@@ -259,10 +259,9 @@ def test_generator_eval_mode_uses_running_statistics():
 
 
 def test_stream_overlap_is_bitwise_identical_to_single_stream():
-    """The second/third HIP streams (weight gradients beside the backward-data chain, the D step's
-    generator forward beside D(real)) only re-order independent work: every kernel is deterministic,
-    so two G+D steps must leave bit-identical parameters and losses with and without the overlap.
-    A missing event/join shows up here as a difference (or as NaNs)."""
+    """The second HIP stream (the generator's weight gradients beside its norm-backward / backward-data chain)
+    only re-orders independent work: every kernel is deterministic, so two G+D steps must leave bit-identical
+    parameters and losses with and without it.  A missing event/join shows up here as a difference (or as NaNs)."""
     from mpgan_amd import engine
     from mpgan_amd.gan import GAN
     gen = torch.Generator().manual_seed(99)
@@ -273,7 +272,6 @@ def test_stream_overlap_is_bitwise_identical_to_single_stream():
         torch.manual_seed(7)
         gan = GAN(1, 64, 64, dimensions=2, n_unet_blocks=3, g_lr=1e-3, d_lr=1e-3)
         gan.train()
-        gan.overlap_streams = not single
         saved = engine._SINGLE_STREAM
         engine._SINGLE_STREAM = single
         try:

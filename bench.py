@@ -181,15 +181,17 @@ def host_cores():
     return n, how, capped
 
 
-def cpu_baseline_leg(gan, spatial, sample_bs=16, timed_steps=3):
+def cpu_baseline_leg(gan, spatial, sample_bs=16, timed_steps=3, warmup=1):
     """Oracle on the host cores, the plan of BASELINE.md section 3: the bench's own configuration
     (bs 16 at 256x256), every core of the affinity mask, 1 warm-up + 3 timed G+D steps; plus the
-    G-output L1 of the HIP path against it (same weights, same input)."""
+    G-output L1 of the HIP path against it (same weights, same input).  3-D (config C5): a bounded sample --
+    ONE timed step on ONE 128^3 volume, no warm-up (a volume's step is about a minute of host time)."""
     import torch
     from oracle import refmodel as R
     cores, how, capped = host_cores()
     torch.set_num_threads(cores)
-    ref = R.GAN((1, *spatial), dimensions=2, norm=gan.generator.norm)
+    dims = len(spatial)
+    ref = R.GAN((1, *spatial), dimensions=dims, norm=gan.generator.norm)
     ref.generator.load_state_dict({k: v.cpu() for k, v in gan.generator.state_dict().items()})
     ref.discriminator.load_state_dict({k: v.cpu() for k, v in gan.discriminator.state_dict().items()})
     ref.train()
@@ -205,16 +207,18 @@ def cpu_baseline_leg(gan, spatial, sample_bs=16, timed_steps=3):
     note(f"cpu baseline: oracle G forward done (L1 vs HIP {l1:.2e}); timing {timed_steps} oracle steps at bs {sample_bs} "
          f"on {cores} threads")
     opts, _ = ref.configure_optimizers()
-    ref.step(batch, 0, opts)                      # warm-up
-    note("cpu baseline: warm-up step done")
+    for _ in range(warmup):
+        ref.step(batch, 0, opts)
+        note("cpu baseline: warm-up step done")
     t0 = time.perf_counter()
     for i in range(timed_steps):
         ref.step(batch, i + 1, opts)
         note(f"cpu baseline: step {i} done")
     dt = time.perf_counter() - t0
-    return {"value": sample_bs * timed_steps / dt, "unit": "slices/s", "cores": cores, "cores_capped": capped,
-            "kind": "port",
-            "sample": f"{timed_steps} G+D steps of the torch-CPU oracle at 256x256, bs {sample_bs} (1 warm-up), "
+    shape = "x".join(str(s) for s in spatial)
+    return {"value": sample_bs * timed_steps / dt, "unit": "slices/s" if dims == 2 else "volumes/s", "cores": cores,
+            "cores_capped": capped, "kind": "port",
+            "sample": f"{timed_steps} G+D step(s) of the fp32 torch-CPU oracle at {shape}, bs {sample_bs} ({warmup} warm-up), "
                       f"{cores} threads = every core this job may use ({how})",
             "g_output_l1_vs_cpu": l1, "g_output_psnr_vs_cpu_db": psnr}
 
@@ -475,6 +479,7 @@ def main():
         else:
             g_flops_sample, step_flops_sample = 145.131e9 * (args.size / 128.0) ** 3, 16.64e12 * (args.size / 128.0) ** 3
         g_fwd_flops = g_flops_sample * args.batch
+        g_peak = PEAK_BF16_TFLOPS if (args.dtype == "bf16" and args.dims == 3) else PEAK_FP32_TFLOPS
         d_flops_sample = (step_flops_sample - 4 * g_flops_sample) / 8
         # where the step's time goes: the same step once more with an event between its network passes (after the
         # timed region: not part of `value`), each pass priced at the peak of the pipe it runs on
@@ -482,16 +487,18 @@ def main():
         if not args.no_phases:
             d_peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_FP32_TFLOPS
             phases = []
+            # (C5: the generator's matrix products run on the bf16 pipe too since round 4 -- priced there)
             for nm, ms, gp, dp in phase_breakdown(gan, opts, batch, steps=3):
                 fl = (gp * g_flops_sample + dp * d_flops_sample) * args.batch
-                floor_ms = (gp * g_flops_sample / PEAK_FP32_TFLOPS + dp * d_flops_sample / d_peak) * args.batch / 1e9
+                floor_ms = (gp * g_flops_sample / g_peak + dp * d_flops_sample / d_peak) * args.batch / 1e9
                 phases.append({"phase": nm, "ms": ms, "gflop": fl / 1e9, "tflops": fl / (ms * 1e-3) / 1e12 if ms else 0.0,
                                "roofline_frac": floor_ms / ms if ms and fl else None})
             note("phases: " + ", ".join(f"{ph['phase']} {ph['ms']:.2f}" for ph in phases if ph["ms"] >= 0.05))
         if args.dims == 2:
             workload = f"C3: {args.size}x{args.size} bs{args.batch}/GPU"
         elif args.dtype == "bf16":
-            workload = f"C5: {args.size}^3 bs{args.batch}/GPU, bf16 storage in D (fp32 accumulate/statistics/Adam; G fp32)"
+            workload = (f"C5: {args.size}^3 bs{args.batch}/GPU, D: bf16 storage + bf16 MFMA; G: bf16 MFMA operands on fp32 "
+                        "storage in its >=16-channel convs, 1-channel layers fp32 (fp32 accumulate/statistics/master weights/Adam)")
         else:
             workload = f"C5 shape (fp32): {args.size}^3 bs{args.batch}/GPU"
         out = {
@@ -512,17 +519,18 @@ def main():
             # the step's matrix work priced at the peak of the pipe it runs on, over the step time (bf16 storage:
             # D's share -- everything but G's forward x2 + backward = 4 x g_flops -- on the bf16 pipe, G on the fp32 pipe)
             "step_mfma_frac": ((step_flops_sample * args.batch) / PEAK_FP32_TFLOPS if args.dtype == "f32" else
-                               (4 * g_flops_sample * args.batch) / PEAK_FP32_TFLOPS +
+                               (4 * g_flops_sample * args.batch) / g_peak +
                                ((step_flops_sample - 4 * g_flops_sample) * args.batch) / PEAK_BF16_TFLOPS)
                               / (dt / args.steps) / 1e12,
             "g_forward": None if g_fwd_ms is None else {
                 "ms": g_fwd_ms, "slices_per_s": args.batch / (g_fwd_ms * 1e-3),
-                "mfma_frac": g_fwd_flops / (g_fwd_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
+                "mfma_frac": g_fwd_flops / (g_fwd_ms * 1e-3) / 1e12 / g_peak},
             "losses": losses,
         }
         note(f"G forward {g_fwd_ms} ms")
-        if world == 1 and not args.no_cpu_baseline and args.dims == 2:
-            out["cpu_baseline"] = cpu_baseline_leg(gan, spatial)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = (cpu_baseline_leg(gan, spatial) if args.dims == 2 else
+                                   cpu_baseline_leg(gan, spatial, sample_bs=1, timed_steps=1, warmup=0))
             note("cpu baseline done")
         print(json.dumps(out), flush=True)
     if world > 1:

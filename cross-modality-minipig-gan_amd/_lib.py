@@ -12,7 +12,8 @@ _lib = None
 class ConvGeomC(C.Structure):
     _fields_ = [("n", C.c_int32), ("in_dhw", C.c_int32 * 3), ("out_dhw", C.c_int32 * 3),
                 ("cin", C.c_int32), ("cout", C.c_int32), ("k", C.c_int32 * 3),
-                ("stride", C.c_int32 * 3), ("pad", C.c_int32 * 3), ("transposed", C.c_int32)]
+                ("stride", C.c_int32 * 3), ("pad", C.c_int32 * 3), ("transposed", C.c_int32),
+                ("flags", C.c_int32), ("min_blocks", C.c_int32)]
 
 
 class PeerTapsC(C.Structure):
@@ -84,8 +85,6 @@ SIGNATURES = {
     "mpgan_debug_stamps": (_I, [_P, _L, _L]),
     "mpgan_debug_stamps_used": (_L, []),
     "mpgan_debug_clock_khz": (_I, []),
-    "mpgan_debug_bf16_wide_min_blocks": (_I, [_I]),
-    "mpgan_debug_f32_dma_min_blocks": (_I, [_I]),
     "mpgan_linear1_backward": (_I, [_P, _PR, _I, _L, _I, _P, _P, _P, _P, _P, _F, _P]),
     "mpgan_sigmoid_bce": (_I, [_P, _I, _F, _F, _P, _P, _P, _P]),
     "mpgan_l1_partials": (_I, []),

@@ -1,6 +1,7 @@
 // Error plumbing shared by every entry point of libmpgan_hip.so.
 #include "mpgan_common.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace mpgan {
 static thread_local char g_err[512] = "";
@@ -13,7 +14,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace mpgan
 
 extern "C" const char* mpgan_last_error(void) { return mpgan::g_err; }
-extern "C" int mpgan_abi_version(void) { return 1; }
+extern "C" int mpgan_abi_version(void) { return 2; }   // 2: mpgan_conv_geom carries flags + min_blocks
 
 // Zero a device buffer on `stream` (the statistics accumulators of a plan, once per forward).
 extern "C" int mpgan_zero_bytes(void* ptr, int64_t bytes, void* stream) {
@@ -74,8 +75,12 @@ extern "C" int32_t mpgan_debug_clock_khz(void) {
 namespace mpgan {
 static long g_dry_launches = 0, g_dry_bad = 0;
 static hipError_t g_dry_err = hipSuccess;
-int dry_note_launch(const char* kernel, dim3 grid, dim3 block, size_t lds) {
+int dry_note_launch(const char* kernel, const char* where, dim3 grid, dim3 block, size_t lds) {
   ++g_dry_launches;
+  static const bool trace = getenv("MPGAN_DRY_TRACE") != nullptr;      // one line per launch: which kernel, what grid
+  if (trace)       // (a launcher that holds its instance in a variable: the launcher's own template arguments name it)
+    fprintf(stderr, "[dry-run] launch %s grid %u block %u lds %zu\n", strcmp(kernel, "kern") ? kernel : where,
+            grid.x * grid.y * grid.z, block.x, lds);
   const unsigned long threads = (unsigned long)block.x * block.y * block.z;
   const bool ok = grid.x >= 1 && grid.y >= 1 && grid.z >= 1 && grid.y <= 65535 && grid.z <= 65535 &&
                   (unsigned long)grid.x * grid.y * grid.z < (1ul << 32) && threads >= 1 && threads <= 1024 &&

@@ -817,7 +817,7 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
 // Which K-stepped form serves a gather: 0 = 256 x 128/64 tile (gather_conv_bf16_kernel), 1 = 256 x 256, 2 = 512 x 128,
 // 3 = 256 x 256 over the phase pairs of a strided backward-data gather (gather_conv_bf16_wide_kernel).  The wide forms need enough tiles to fill the chip twice over; MPGAN_DBG_HB_WIDE=0
 // turns them off (A/B runs).  mpgan_conv_stats_rows_bf16 follows the same choice (rows = phases x m-tiles).
-static int g_hw_min_blocks = 1024;
+// (the threshold is the geometry's own `min_blocks`, include/mpgan_hip.h: sizing queries and launches see the same value)
 static bool hw_pairs_congruent(const GatherConv& p) {
   if (p.nphase < 2 || p.nphase % 2) return false;
   for (int i = 0; i < p.nphase; i += 2) {
@@ -839,6 +839,7 @@ static int hw_choice(const GatherConv& p, bool with_stats) {
   if ((long)p.N * p.Di * p.Hi * p.Wi * p.ldi * 2 >= (long)HW_OOB || (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 2 >= (long)HW_OOB)
     return 0;
   const long maxM = max_phase_pixels(p);
+  const int g_hw_min_blocks = p.min_blocks > 0 ? p.min_blocks : FORM_MIN_BLOCKS_DEFAULT;
   if (p.Cout > 128) {
     const long blocks = ((maxM + 255) / 256) * ((p.Cout + 255) / 256) * p.nphase;
     return (blocks >= g_hw_min_blocks || forced == 1) ? 1 : 0;
@@ -1208,6 +1209,15 @@ static int hb_dispatch(const GatherConv& p, hipStream_t st, const char* what) {
   if (hp_ok(p)) return p.Cout > 64 ? hp_launch<128>(p, st) : hp_launch<64>(p, st);
   const bool mask = !hb_all_in_range(p);
   const int wide = hw_choice(p, p.stats != nullptr);
+  if (p.stats) {
+    // mpgan_conv_stats_rows_bf16 sized the caller's partial rows from the compact geometry (pitch = Cin): a pitched
+    // operand close to the 4 GiB offset range can fall back to the narrower tile, which would write more rows
+    GatherConv c = p;
+    c.ldi = c.Cin;
+    MPGAN_UNSUPPORTED(hw_bm(hw_choice(c, true)) != hw_bm(wide),
+                      "%s: the channel pitch of this operand changes the tile height the statistics rows were sized for "
+                      "(operand beyond the 32-bit offset range of the wide form): pass a compact tensor", what);
+  }
   if (wide == 3) return mask ? hw_launch<2, 4, true, true, true>(p, maxM, st) : hw_launch<2, 4, false, true, true>(p, maxM, st);
   static const bool no_ring = getenv("MPGAN_DBG_HB_NO_RING") != nullptr;     // development: two whole stages instead
   if (wide == 1 && no_ring) return mask ? hw_launch<2, 4, true, false>(p, maxM, st) : hw_launch<2, 4, false, false>(p, maxM, st);
@@ -2014,18 +2024,10 @@ static inline int hb_ew_blocks(long total) {
 
 using namespace mpgan;
 
-// Development / test hook: the number of blocks from which the wide K-stepped forms serve a gather (default 1024;
-// 1 = always where the channel counts allow, a huge value = never).  Returns the previous value.  Statistics-row
-// counts follow the choice: set it before sizing partial buffers, not between a sizing call and its launch.
-extern "C" int32_t mpgan_debug_bf16_wide_min_blocks(int32_t blocks) {
-  const int old = g_hw_min_blocks;
-  if (blocks > 0) g_hw_min_blocks = blocks;
-  return old;
-}
-
 extern "C" int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g) {
   if (check_geom(g)) return -1;
   GatherConv p{};
+  set_geom_flags(p, g);
   if (!g->transposed) build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
   else build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
   if (g->cin % HB_BK == 0 && hp_ok(p)) {     // patch form: one row per 4 x 8 x 8 tile
@@ -2043,6 +2045,7 @@ extern "C" int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g) {
 extern "C" int32_t mpgan_conv_variant_bf16(const mpgan_conv_geom* g, int32_t backward_data) {
   if (check_geom(g)) return -1;
   GatherConv p{};
+  set_geom_flags(p, g);
   if (!backward_data) {
     if (!g->transposed) build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
     else build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
@@ -2067,6 +2070,7 @@ extern "C" int mpgan_conv_forward_bf16(const mpgan_conv_geom* g, const void* x, 
   p.bias = bias; p.stats = stats_partials;
   p.pro = make_pro(nullptr);
   p.ldi = ldx; p.ldo = ldy;
+  set_geom_flags(p, g);
   if (!g->transposed) build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
   else build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
   return hb_dispatch(p, (hipStream_t)stream, "conv_forward_bf16");
@@ -2082,6 +2086,7 @@ extern "C" int mpgan_conv_backward_data_bf16(const mpgan_conv_geom* g, const voi
   p.in = static_cast<const float*>(dy); p.wp = static_cast<const float*>(w_packed_bwd); p.out = static_cast<float*>(dx);
   p.pro = make_pro(nullptr);
   p.ldi = lddy; p.ldo = lddx;
+  set_geom_flags(p, g);
   if (!g->transposed) build_transposed(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
   else build_forward(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
   return hb_dispatch(p, (hipStream_t)stream, "conv_backward_data_bf16");

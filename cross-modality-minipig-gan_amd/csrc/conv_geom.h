@@ -54,6 +54,8 @@ struct GatherConv {
   NormFold fold;         // consumer side: fold the producer's accumulators into the prologue's scale / shift
   BwdStats bwd;          // see above (part == null: off)
   int in_bf16, out_bf16; // thin (VALU) kernels of the bf16 path: `in` / `out` point at bf16 data (weights stay fp32)
+  int mm16;              // MPGAN_CONV_MM_BF16: matrix operands rounded to bf16 into LDS, bf16 MFMA, fp32 accumulation
+  int min_blocks;        // the geometry's big-tile threshold (0: default), see mpgan_conv_geom
   MPGAN_STAMP_FIELD      // development builds only (mpgan_common.h)
   Phase ph[8];
 };
@@ -100,6 +102,7 @@ int launch_thin_cout1_mfma_bf16(const GatherConv& p, hipStream_t st);
 inline int check_geom(const mpgan_conv_geom* g) {
   MPGAN_CHECK_ARG(g != nullptr, "conv: null geometry");
   MPGAN_CHECK_ARG(g->n > 0 && g->cin > 0 && g->cout > 0, "conv: bad n/cin/cout");
+  MPGAN_CHECK_ARG((g->flags & ~MPGAN_CONV_MM_BF16) == 0 && g->min_blocks >= 0, "conv: unknown flags / negative min_blocks");
   for (int d = 0; d < 3; ++d) {
     MPGAN_CHECK_ARG(g->in_dhw[d] > 0 && g->out_dhw[d] > 0 && g->k[d] > 0 && g->stride[d] > 0 && g->pad[d] >= 0,
                     "conv: bad spatial geometry in dim %d", d);
@@ -115,6 +118,17 @@ inline int check_geom(const mpgan_conv_geom* g) {
   }
   return MPGAN_OK;
 }
+
+// the per-call dispatch knobs that travel with the geometry (include/mpgan_hip.h)
+constexpr int FORM_MIN_BLOCKS_DEFAULT = 1024;
+inline void set_geom_flags(GatherConv& p, const mpgan_conv_geom* g) {
+  p.mm16 = (g->flags & MPGAN_CONV_MM_BF16) ? 1 : 0;
+  p.min_blocks = g->min_blocks > 0 ? g->min_blocks : FORM_MIN_BLOCKS_DEFAULT;
+}
+
+// conv_mm16.hip: the MM16 instances of the K-stepped kernel (conv_pipe.h)
+bool mm16_gather_ok(const GatherConv& p);
+int launch_gather_mm16(const GatherConv& p, int variant, bool ksplit2, long maxM, hipStream_t st);
 
 // forward-type gather: produced[o] = sum_k gathered[o*s - p + k] * W[k]
 inline void build_forward(GatherConv& p, int n, const int32_t* gath_dhw, int cg, const int32_t* prod_dhw, int cp,

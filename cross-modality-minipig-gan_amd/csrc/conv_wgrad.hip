@@ -17,40 +17,9 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#include "wgrad_pipe.h"
+
 namespace mpgan {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct WgradParams {
-  const float* dense;
-  const float* gath;
-  float* partial;  // [split][Cd][T*Cg]
-  float* bias_partial;  // [split][Cd] column sums of the dense operand (fused bias gradient) or null
-  Pro pro;         // prologue on the gathered operand
-  int ldd, Cd, ldg, Cg;
-  int N, Mz, My, Mx;  // coarse grid
-  int Gz, Gy, Gx;     // gathered tensor spatial dims
-  int Kz, Ky, Kx;
-  int sz, sy, sx, pz, py, px;
-  int nsplit;
-  long chunk;  // pixels per split (multiple of 32)
-  int dense_bf16;  // thin kernel only: `dense` points at bf16 data (dy of D.conv1 in the bf16 path)
-  int tiles_c, tiles_d;  // 1-D launch of tiles_c*tiles_d*nsplit blocks, XCD-remapped, column tile fastest
-  FastDiv fMx, fMy, fMz;
-};
-
-struct WBlockId { int tc, td, split; };
-__device__ __forceinline__ WBlockId wgrad_block_id(const WgradParams& p) {
-  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
-  WBlockId b;
-  b.tc = (int)(w % (unsigned)p.tiles_c);
-  const unsigned q = w / (unsigned)p.tiles_c;
-  b.td = (int)(q % (unsigned)p.tiles_d);
-  b.split = (int)(q / (unsigned)p.tiles_d);
-  return b;
-}
-
-constexpr int WBK = 32;
 
 // KW = 1: the 4 waves tile the BD x BG block (WM x WN waves of TM x TN tiles).
 // KW = 4: small block (<= 64x32): every wave owns the whole tile and a quarter
@@ -286,278 +255,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------
-// Software-pipelined variant (both operands 16-byte vectorisable, coarse grid
-// at least 32 wide, BatchNorm-or-no prologue): the K-step is one basic block;
-// tile kt+2 is loaded under the MFMAs of group 0, tile kt+1 goes to LDS under
-// group 3 (two register stages), exactly as gather_conv_pipe_kernel does.
-// ---------------------------------------------------------------------------
-template <int BD, int BG, int TM, int TN, int WN, int PRO, bool PAD>
-__global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int STAGE = WBK * (BD + BG);
-  constexpr int DCH = BD / 4, GCH = BG / 4;
-  constexpr int DLOADS = (WBK * DCH) / 256, GLOADS = (WBK * GCH) / 256;
-  constexpr int DROWSTEP = 256 / DCH, GROWSTEP = 256 / GCH;
-  constexpr int NMF = 4 * TM * TN;
-  // Row table (2 x 32 entries behind the two tile stages): for each of the 32 pixels of a
-  // K-step, the byte offset of its tap-(0,0,0) gathered pixel and (PAD) its gathered
-  // coordinates / (!PAD) its validity.  Filled once per row and K-step under the MFMAs of
-  // group 1; the 256 loaders then need one LDS read, one add and one mask per address.
-  int4* rtab = reinterpret_cast<int4*>(lds + 2 * STAGE);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
-  const int li = lane & 31, lh = lane >> 5;
-  const int wm = wid / WN, wn = wid % WN;
-  const int T = p.Kz * p.Ky * p.Kx;
-  const int NC = T * p.Cg;
-  const WBlockId bid = wgrad_block_id(p);
-  const int c0 = bid.tc * BG;
-  const int d0 = bid.td * BD;
-  const long M = (long)p.N * p.Mz * p.My * p.Mx;
-  const long mbeg = (long)bid.split * p.chunk;
-  const long mend = mbeg + p.chunk < M ? mbeg + p.chunk : M;
-  const int nk = mbeg < mend ? (int)((mend - mbeg + WBK - 1) / WBK) : 0;
-  const float slope = PRO ? pro_slope(p.pro) : 1.f;
-  const int act = p.pro.act;
-  const char* __restrict__ gdb = reinterpret_cast<const char*>(p.dense);   // base + unsigned 32-bit byte offsets
-  const char* __restrict__ ggb = reinterpret_cast<const char*>(p.gath);    // (host: operands < 4 GiB)
-  const int ldd = p.ldd, ldg = p.ldg, Gz = p.Gz, Gy = p.Gy, Gx = p.Gx;
-
-  // gathered operand: this thread's column chunk (tap, channel) is fixed for the block
-  const int gcc = tid % GCH, grow0 = tid / GCH;
-  int gci, gkz, gky, gkx, gokm;
-  {
-    const int col = c0 + gcc * 4;
-    gokm = col < NC ? -1 : 0;
-    const int t = gokm ? col / p.Cg : 0;
-    gci = gokm ? col - t * p.Cg : 0;
-    gkx = t % p.Kx;
-    const int q = t / p.Kx;
-    gky = q % p.Ky;
-    gkz = q / p.Ky;
-  }
-  const unsigned tapB = (unsigned)(((gkz * Gy + gky) * Gx + gkx) * ldg + gci) * 4u;
-  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (PRO != 0) {          // per-channel scale/shift of this thread's channels: loaded once
-    psc = *reinterpret_cast<const float4*>(p.pro.scale + gci);
-    psh = *reinterpret_cast<const float4*>(p.pro.shift + gci);
-  }
-  const int dcc = tid % DCH, drow0 = tid / DCH;
-  const int dcol = d0 + dcc * 4;
-  const int dokm = dcol < p.Cd ? -1 : 0;
-  const int imend = (int)mend;
-  int mrow = (int)mbeg;              // first pixel of the tile being loaded (32-bit: M < 2^31)
-  unsigned dB = (unsigned)(((int)mbeg + drow0) * ldd + dcol) * 4u;
-  const unsigned dstepB = (unsigned)(WBK * ldd) * 4u, drowB = (unsigned)(DROWSTEP * ldd) * 4u;
-
-  auto fill_table = [&](int buf, int mt) {
-    const int r = tid & 31;          // 8 threads write the same entry with the same value
-    const unsigned m = (unsigned)(mt + r);
-    unsigned q, ux, uy, uz;
-    fdivmod_nb(m, p.fMx, q, ux);
-    fdivmod_nb(q, p.fMy, q, uy);
-    fdivmod_nb(q, p.fMz, q, uz);
-    const int iz0 = (int)uz * p.sz - p.pz, iy0 = (int)uy * p.sy - p.py, ix0 = (int)ux * p.sx - p.px;
-    const bool valid = (int)m < imend;
-    int4 e;
-    e.x = (int)((unsigned)((((int)q * Gz + iz0) * Gy + iy0) * Gx + ix0) * (unsigned)ldg * 4u);
-    if constexpr (PAD) {
-      e.y = valid ? iz0 : -(1 << 28);
-      e.z = iy0;
-      e.w = ix0;
-    } else {
-      e.y = valid ? -1 : 0;
-      e.z = 0;
-      e.w = 0;
-    }
-    rtab[buf * 32 + r] = e;
-  };
-
-  struct Stage {
-    float4 rd[DLOADS], rg[GLOADS];
-    unsigned gmask, dmask;
-  };
-  Stage SX, SY;
-  float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  auto issue_loads = [&](Stage& S, int buf) {
-    unsigned dm = 0;
-#pragma unroll
-    for (int i = 0; i < DLOADS; ++i) {
-      const int ok = (mrow + drow0 + DROWSTEP * i) < imend ? dokm : 0;
-      S.rd[i] = *reinterpret_cast<const float4*>(gdb + ((dB + (unsigned)i * drowB) & (unsigned)ok));
-      dm |= ((unsigned)ok & 1u) << i;
-    }
-    unsigned gm = 0;
-#pragma unroll
-    for (int i = 0; i < GLOADS; ++i) {
-      const int4 e = rtab[buf * 32 + grow0 + GROWSTEP * i];
-      int ok;
-      if constexpr (PAD) {
-        const int iz = e.y + gkz, iy = e.z + gky, ix = e.w + gkx;
-        ok = ((unsigned)iz < (unsigned)Gz ? gokm : 0) & ((unsigned)iy < (unsigned)Gy ? -1 : 0) &
-             ((unsigned)ix < (unsigned)Gx ? -1 : 0);
-      } else {
-        ok = e.y & gokm;
-      }
-      S.rg[i] = *reinterpret_cast<const float4*>(ggb + (((unsigned)e.x + tapB) & (unsigned)ok));
-      gm |= ((unsigned)ok & 1u) << i;
-    }
-    S.gmask = gm;
-    S.dmask = dm;
-    dB += dstepB;
-    mrow += WBK;
-  };
-
-  auto store_tile = [&](int buf, const Stage& S) {
-    float* Ds = lds + buf * STAGE;
-    float* Gs = Ds + WBK * BD;
-#pragma unroll
-    for (int i = 0; i < DLOADS; ++i) {
-      float4 v = S.rd[i];
-      const bool ok = (S.dmask >> i) & 1u;       // rows past the chunk / channels past Cd
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      bacc.x += v.x; bacc.y += v.y; bacc.z += v.z; bacc.w += v.w;
-      *reinterpret_cast<float4*>(Ds + (drow0 + DROWSTEP * i) * BD + dcc * 4) = v;
-    }
-#pragma unroll
-    for (int i = 0; i < GLOADS; ++i) {
-      float4 v = S.rg[i];
-      if constexpr (PRO == 3) {          // LeakyReLU, host-known slope in [0, 1]: max(y, slope*y), exact
-        v.x = v.x * psc.x + psh.x; v.y = v.y * psc.y + psh.y; v.z = v.z * psc.z + psh.z; v.w = v.w * psc.w + psh.w;
-        v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
-        v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
-      } else if constexpr (PRO == 1) {
-        v.x = act_apply(v.x * psc.x + psh.x, act, slope);
-        v.y = act_apply(v.y * psc.y + psh.y, act, slope);
-        v.z = act_apply(v.z * psc.z + psh.z, act, slope);
-        v.w = act_apply(v.w * psc.w + psh.w, act, slope);
-      }
-      const bool ok = (S.gmask >> i) & 1u;
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      *reinterpret_cast<float4*>(Gs + (grow0 + GROWSTEP * i) * BG + gcc * 4) = v;
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  int mtab = (int)mbeg + 3 * WBK;     // tile whose table entry the next K-step writes
-  if (nk > 0) {
-    fill_table(0, (int)mbeg);
-    fill_table(1, (int)mbeg + WBK);
-    __syncthreads();
-    issue_loads(SX, 0);
-    store_tile(0, SX);
-    issue_loads(SX, 1);
-    __syncthreads();                  // table 0 has been read by everyone
-    fill_table(0, (int)mbeg + 2 * WBK);
-  }
-  __syncthreads();
-
-  // K-step kt (LDS buffer cb = kt & 1): loads tile kt+2 through table[cb], writes the table of
-  // tile kt+3 into table[cb ^ 1] (last read one barrier ago).
-  auto step = [&](int cb, Stage& Sn, const Stage& Sp) {
-    const float* Ds = lds + cb * STAGE + wm * TM * 32 + li;
-    const float* Gs = lds + cb * STAGE + WBK * BD + wn * TN * 32 + li;
-    float a[2][4][TM], b[2][4][TN];
-    auto read_group = [&](int g, int slot) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kk = 2 * (4 * g + q) + lh;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) a[slot][q][tm] = Ds[kk * BD + tm * 32];
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) b[slot][q][tn] = Gs[kk * BG + tn * 32];
-      }
-    };
-    read_group(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int sl = g & 1;
-      if (g < 3) read_group(g + 1, sl ^ 1);
-      if (g == 0) issue_loads(Sn, cb);
-      if (g == 1) { fill_table(cb ^ 1, mtab); mtab += WBK; }
-      if (g == 3) store_tile(cb ^ 1, Sp);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][q][tm], b[sl][q][tn], acc[tm][tn], 0, 0, 0);
-      if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
-      if (g == 0) {
-#pragma unroll
-        for (int i = 0; i < NMF; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-      } else if (g == 1) {
-#pragma unroll
-        for (int i = 0; i < NMF; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);                     // row-table arithmetic
-        }
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      } else if (g == 3) {
-#pragma unroll
-        for (int i = 0; i < NMF; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x006, 9, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-      } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  for (int kt = 0; kt < nk; kt += 2) {
-    step(0, SY, SX);
-    __syncthreads();
-    if (kt + 1 < nk) {
-      step(1, SX, SY);
-      __syncthreads();
-    }
-  }
-  // tiles past the chunk were stored (as zeros) once more than consumed: bacc saw only zeros there
-
-  if (p.bias_partial != nullptr && bid.tc == 0) {
-    float* red = lds;
-    *reinterpret_cast<float4*>(red + drow0 * BD + dcc * 4) = bacc;
-    __syncthreads();
-    if (tid < BD && d0 + tid < p.Cd) {
-      float t = 0.f;
-      for (int r = 0; r < DROWSTEP; ++r) t += red[r * BD + tid];
-      p.bias_partial[(long)bid.split * p.Cd + d0 + tid] = t;
-    }
-  }
-  float* out = p.partial + (long)bid.split * p.Cd * NC;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int col = c0 + (wn * TN + tn) * 32 + li;
-      if (col >= NC) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cd = d0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (cd < p.Cd) out[(long)cd * NC + col] = acc[tm][tn][r];
-      }
-    }
-}
-
 // dW[cd][cg][t] = beta*dW + sum_split partial[split][cd][t*Cg+cg]
 // block = 32 consecutive elements x 8 split lanes; lanes sum their splits in
 // order, then the 8 lane sums are added in order: deterministic.  The trailing
@@ -760,30 +457,43 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p) {
     }
   }
   const int W = p.Cd * T + p.Cd;                 // floats per lane row: [c][t] then bias[c]
-  if (pl < PL) {
+  // The lane rows are folded in `fold_rounds` rounds over PL / rounds LDS rows (round 0 stores, the others add their
+  // own element: one owner per element and round, fixed order), so that 27-tap layers with 16 / 32 dense channels
+  // (3-D: 64 x 448 / 32 x 896 floats = 112 KiB of lane rows) stay within 64 KiB and two blocks per CU.
+  const int NR = p.fold_rounds > 1 ? p.fold_rounds : 1;
+  const int PLr = PL / NR;
+  for (int r = 0; r < NR; ++r) {
+    if (pl < PLr * NR && pl / PLr == r) {
+      const int row = pl - r * PLr;
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      if (c + e >= p.Cd) break;
+      for (int e = 0; e < V; ++e) {
+        if (c + e >= p.Cd) break;
 #pragma unroll
-      for (int t = 0; t < T; ++t) red[pl * W + (c + e) * T + t] = acc[t][e];
-      red[pl * W + p.Cd * T + c + e] = bsum[e];
+        for (int t = 0; t < T; ++t) {
+          float* dst = red + row * W + (c + e) * T + t;
+          *dst = r == 0 ? acc[t][e] : *dst + acc[t][e];
+        }
+        float* db = red + row * W + p.Cd * T + c + e;
+        *db = r == 0 ? bsum[e] : *db + bsum[e];
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
+  const int PLf = PLr;                           // rows left to fold
   float* out = p.partial + (long)blockIdx.x * p.Cd * T;
   // fold the PL lane rows: narrow rows (few channels) are first folded by G row groups in parallel
   const int G = W < 128 ? 256 / W : 1;
   if (G > 1) {
     const int i = threadIdx.x % W, g = threadIdx.x / W;
-    const int GR = G < PL ? G : PL;
+    const int GR = G < PLf ? G : PLf;
     float s1 = 0.f;
     if (g < GR)
-      for (int r = g; r < PL; r += GR) s1 += red[r * W + i];
+      for (int r = g; r < PLf; r += GR) s1 += red[r * W + i];
     __syncthreads();
     if (g < GR) red[g * W + i] = s1;
     __syncthreads();
   }
-  const int rows = G > 1 ? (G < PL ? G : PL) : PL;
+  const int rows = G > 1 ? (G < PLf ? G : PLf) : PLf;
   for (int i = threadIdx.x; i < W; i += 256) {
     float s2 = 0.f;
     for (int r = 0; r < rows; ++r) s2 += red[r * W + i];
@@ -885,7 +595,11 @@ static void launch_thin_rows(const WgradParams& p, int T, int blocks, hipStream_
 constexpr int WP3_TZ = 2, WP3_TY = 8, WP3_TX = 8, WP3_PY = 10, WP3_PX = 10, WP3_PROWS = 400, WP3_BLOCKS = 512;
 struct WP3Grid { int tiles_z, tiles_y, tiles_x; };
 
-template <bool HAS_PRO>
+//   MM16 (MPGAN_CONV_MM_BF16): v_mfma_f32_16x16x32_bf16 contracts 32 pixels per instruction; lane (channel ln, quarter kq)
+//   reads the 8 pixels 32 jj + 8 kq + j of its channel (as many ds_read_b32 as the fp32 form's 4-pixel steps), rounds
+//   them to bf16: 28 instead of 224 MFMAs per tile and wave.  The bias gradient (column sums of dy) is summed from the
+//   UNROUNDED values on the vector ALUs (the contract rounds matrix operands only).
+template <bool HAS_PRO, bool MM16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_patch3d_c16_kernel(const WgradParams p, const WP3Grid tg) {
   __shared__ __attribute__((aligned(16))) float patch[WP3_PROWS * 16];   // [patch pixel][ci]
   __shared__ __attribute__((aligned(16))) float dyt[128 * 16];           // [tile pixel][co]
@@ -981,6 +695,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch3d_c16_kernel(const WgradPa
   // contraction over the tile's 128 pixels, four at a time (k = pixel 4 j + g): branch-free bodies, one per wave kind
   auto contract = [&](auto bias_tag) {
     constexpr bool BIAS = decltype(bias_tag)::value;
+    if constexpr (MM16) {
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        bf16x8 af;
+        int pb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int q = 32 * jj + 8 * g + e;                     // k = pixel q of the tile
+          const float dv_ = dyt[q * 16 + ln];
+          if constexpr (BIAS) accb[0] += dv_;                    // (MM16: accb[0] is this lane's running column sum)
+          af[e] = (__bf16)dv_;
+          pb[e] = ((((q >> 6) * WP3_PY) + ((q >> 3) & 7)) * WP3_PX + (q & 7)) * 16 + ln;
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+          if (BIAS && k == 6) break;
+          bf16x8 bf;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bf[e] = (__bf16)patch[pb[e] + toff[k]];
+          acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[k], 0, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll 4
     for (int j = 0; j < 32; ++j) {
       const int q = 4 * j + g;
@@ -1011,9 +750,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch3d_c16_kernel(const WgradPa
 #pragma unroll
       for (int i = 0; i < 4; ++i) out[(4 * g + i) * 432 + tap * 16 + ln] = acc[k][i];
   }
-  if (wid == 3 && p.bias_partial && ln == 0)
+  if constexpr (MM16) {
+    if (wid == 3 && p.bias_partial) {                          // lanes (co = ln, quarter g): fold the four quarters, fixed order
+      float s = accb[0];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (g == 0) p.bias_partial[(long)blockIdx.x * 16 + ln] = s;
+    }
+  } else {
+    if (wid == 3 && p.bias_partial && ln == 0)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) p.bias_partial[(long)blockIdx.x * 16 + 4 * g + i] = accb[i];
+      for (int i = 0; i < 4; ++i) p.bias_partial[(long)blockIdx.x * 16 + 4 * g + i] = accb[i];
+  }
 }
 
 static bool wgrad_p3_geom_ok(const mpgan_conv_geom* g) {
@@ -1282,7 +1030,7 @@ static int launch_wgrad_p2(const WgradParams& p, const WP2Plan& pl, hipStream_t 
   return check_launch("wgrad_patch2d");
 }
 
-struct ThinWgradPlan { int blocks; long chunk; bool ok; };
+struct ThinWgradPlan { int blocks; long chunk; bool ok; int rounds; };
 static ThinWgradPlan plan_thin_wgrad(int Cd, int Cg, int T, long M, bool has_pro, long lds_cap = 64 * 1024) {
   ThinWgradPlan t;
   t.ok = Cg == 1 && !has_pro && Cd <= 64 && (T == 1 || T == 9 || T == 27);   // kernel shape checked by the caller
@@ -1298,7 +1046,9 @@ static ThinWgradPlan plan_thin_wgrad(int Cd, int Cg, int T, long M, bool has_pro
   const int V = Cd % 4 == 0 ? 4 : 1;
   const int CQ = (Cd + V - 1) / V;
   const int PL = 256 / CQ;
-  if ((long)PL * (Cd * T + Cd) * 4 > lds_cap) t.ok = false;
+  t.rounds = 1;                                  // fold rounds of the lane rows (thin_wgrad_kernel): halve the LDS rows until they fit
+  while (t.rounds < 4 && (PL / t.rounds) % 2 == 0 && (long)(PL / t.rounds) * (Cd * T + Cd) * 4 > lds_cap) t.rounds *= 2;
+  if ((long)(PL / t.rounds) * (Cd * T + Cd) * 4 > lds_cap) t.ok = false;
   return t;
 }
 
@@ -1507,7 +1257,11 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
                     "conv_backward_weight: workspace too small for the 3-D patch form");
     p.bias_partial = dbias ? p.partial + pslab : nullptr;
     const WP3Grid tg{(p.Mz + WP3_TZ - 1) / WP3_TZ, (p.My + WP3_TY - 1) / WP3_TY, (p.Mx + WP3_TX - 1) / WP3_TX};
-    if (p.pro.scale) hipLaunchKernelGGL(wgrad_patch3d_c16_kernel<true>, dim3(nb), dim3(256), 0, st0, p, tg);
+    static const bool no_mm16 = getenv("MPGAN_DBG_NO_MM16") != nullptr;
+    if ((g->flags & MPGAN_CONV_MM_BF16) && !no_mm16) {
+      if (p.pro.scale) hipLaunchKernelGGL((wgrad_patch3d_c16_kernel<true, true>), dim3(nb), dim3(256), 0, st0, p, tg);
+      else hipLaunchKernelGGL((wgrad_patch3d_c16_kernel<false, true>), dim3(nb), dim3(256), 0, st0, p, tg);
+    } else if (p.pro.scale) hipLaunchKernelGGL(wgrad_patch3d_c16_kernel<true>, dim3(nb), dim3(256), 0, st0, p, tg);
     else hipLaunchKernelGGL(wgrad_patch3d_c16_kernel<false>, dim3(nb), dim3(256), 0, st0, p, tg);
     int rcp = check_launch("wgrad_patch3d_c16");
     if (rcp) return rcp;
@@ -1549,7 +1303,12 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
       p.bias_partial = dbias ? p.partial + tslab : nullptr;
       const int V = v4 ? 4 : 1;
       const int CQ = (Cd + V - 1) / V, PL = 256 / CQ;
-      const size_t smem = (size_t)PL * (Cd * T + Cd) * sizeof(float);
+      // (the plan assumed V = 4 where Cd % 4 == 0; an unaligned operand walks scalar lanes: more lane rows, same rule)
+      int rounds = 1;
+      while (rounds < 8 && (PL / rounds) % 2 == 0 && (size_t)(PL / rounds) * (Cd * T + Cd) * sizeof(float) > 64 * 1024) rounds *= 2;
+      p.fold_rounds = rounds;
+      const size_t smem = (size_t)(PL / rounds) * (Cd * T + Cd) * sizeof(float);
+      MPGAN_UNSUPPORTED(smem > 64 * 1024, "conv_backward_weight: thin path lane rows exceed 64 KiB");
       dim3 grid(tp.blocks);
 #define THIN_LAUNCH(VV, TT) hipLaunchKernelGGL((thin_wgrad_kernel<VV, TT>), grid, dim3(256), smem, st0, p)
       if (thin_rows_ok(p, T)) launch_thin_rows<false>(p, T, tp.blocks, st0);
@@ -1573,7 +1332,9 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
   static const bool no_pipe = getenv("MPGAN_DBG_NO_PIPE") != nullptr;
   // the pipelined kernel addresses each operand as base + unsigned 32-bit byte offset
   const bool small = (long)M * p.ldd * 4 < (1L << 32) && (long)p.N * p.Gz * p.Gy * p.Gx * p.ldg * 4 < (1L << 32);
-  if (vd && vg && pl.kw == 1 && small && p.pro.n_stride == 0 && !no_pipe) {
+  if ((g->flags & MPGAN_CONV_MM_BF16) && vd && vg && pl.kw == 1 && small && p.pro.n_stride == 0)
+    rc = launch_wgrad_mm16(p, pl.BD, pl.BG, st, handled);                // bf16 matrix operands (conv_mm16.hip)
+  if (!handled && vd && vg && pl.kw == 1 && small && p.pro.n_stride == 0 && !no_pipe) {
     const bool fast_leaky = p.pro.scale && p.pro.act == MPGAN_ACT_LEAKY && !p.pro.slope_ptr && p.pro.slope >= 0.f &&
                             p.pro.slope <= 1.f;
     rc = !p.pro.scale ? dispatch_wgrad_pipe<0>(p, pl, st, handled)

@@ -15,9 +15,9 @@
 // an error status.  The product build has none of this.
 #ifdef MPGAN_DRYRUN
 namespace mpgan {
-int dry_note_launch(const char* kernel, dim3 grid, dim3 block, size_t lds);
+int dry_note_launch(const char* kernel, const char* where, dim3 grid, dim3 block, size_t lds);
 template <typename... A>
-inline void dry_launch(const char* kernel, dim3 grid, dim3 block, size_t lds, hipStream_t, A... args) {
+inline void dry_launch(const char* kernel, const char* where, dim3 grid, dim3 block, size_t lds, hipStream_t, A... args) {
   // the by-value copies above ARE the marshalling under test; touch every byte so ASan sees a short struct
   const volatile unsigned char* bytes[] = {reinterpret_cast<const volatile unsigned char*>(&args)...};
   const size_t sizes[] = {sizeof(args)...};
@@ -25,7 +25,7 @@ inline void dry_launch(const char* kernel, dim3 grid, dim3 block, size_t lds, hi
   for (size_t i = 0; i < sizeof...(A); ++i)
     for (size_t b = 0; b < sizes[i]; ++b) acc += bytes[i][b];
   (void)acc;
-  dry_note_launch(kernel, grid, block, lds);
+  dry_note_launch(kernel, where, grid, block, lds);
 }
 hipError_t dry_last_error();
 inline hipError_t dry_ok(...) { return hipSuccess; }
@@ -37,7 +37,7 @@ inline hipError_t dry_symbol_address(void** p) {
 }  // namespace mpgan
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \
-  ::mpgan::dry_launch(#kern, grid, block, lds, stream, __VA_ARGS__)
+  ::mpgan::dry_launch(#kern, __PRETTY_FUNCTION__, grid, block, lds, stream, __VA_ARGS__)
 #define hipFuncSetAttribute(...) ::mpgan::dry_ok(__VA_ARGS__)
 #define hipMemcpyToSymbol(...) ::mpgan::dry_ok(__VA_ARGS__)
 #define hipMemsetAsync(...) ::mpgan::dry_ok(__VA_ARGS__)

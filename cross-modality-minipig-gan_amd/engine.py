@@ -17,6 +17,7 @@ discriminator follows code/GAN/GAN_final.py:159-209.
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -785,12 +786,32 @@ def _t3(v, dims, fill):
     return (fill,) * (3 - dims) + tuple(v)
 
 
+_GEOM_DEFAULTS = dict(mm_bf16=False)
+
+
+class geom_defaults:
+    """Plan-wide geometry flags while a plan is being built: `with geom_defaults(mm_bf16=True):` makes every
+    conv_geom_of inside carry MPGAN_CONV_MM_BF16 (the C5 generator: bf16 matrix operands, fp32 storage)."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = dict(_GEOM_DEFAULTS)
+        _GEOM_DEFAULTS.update(self.kw)
+
+    def __exit__(self, *a):
+        _GEOM_DEFAULTS.clear()
+        _GEOM_DEFAULTS.update(self.saved)
+        return False
+
+
 def conv_geom_of(mod, n, in_dhw, dims) -> ConvGeom:
     """Geometry of an nn.ConvNd / nn.ConvTransposeNd module at a given input size."""
     tr = isinstance(mod, (nn.ConvTranspose2d, nn.ConvTranspose3d))
     k, s, p = _t3(mod.kernel_size, dims, 1), _t3(mod.stride, dims, 1), _t3(mod.padding, dims, 0)
     op = _t3(mod.output_padding, dims, 0) if tr else (0, 0, 0)
-    return ConvGeom(n, tuple(in_dhw), mod.in_channels, mod.out_channels, k, s, p, tr, op)
+    return ConvGeom(n, tuple(in_dhw), mod.in_channels, mod.out_channels, k, s, p, tr, op, **_GEOM_DEFAULTS)
 
 
 class Scratch:
@@ -912,7 +933,7 @@ class UNetPlan:
             if fuse:
                 zr = E(n, *sizes[l + 1], 2 * c)
                 z0, r = zr[..., :c], zr[..., c:]
-                gf = ConvGeom(g0.n, g0.in_dhw, g0.cin, 2 * c, g0.k, g0.stride, g0.pad)
+                gf = dataclasses.replace(g0, cout=2 * c)
                 reg(cv0), reg(ru.res)
                 fr = store.register_fused(cv0, ru.res)       # before any packed offset is taken (emit)
             else:
@@ -1147,7 +1168,10 @@ class GeneratorPlan:
     """CasNet: chain of U-Nets + Tanh (code/GAN/GAN_final.py:92-122)."""
 
     def __init__(self, gen, store: ParamStore, n: int, spatial: Sequence[int], *, want_backward: bool,
-                 want_input_grad: bool, instance: bool, training: bool = True):
+                 want_input_grad: bool, instance: bool, training: bool = True, mm_bf16: bool = False):
+        # mm_bf16: every MFMA-served conv of this plan rounds its matrix operands to bf16 (MPGAN_CONV_MM_BF16;
+        # config C5's generator): activations, weights, statistics and gradients in HBM stay fp32
+        self.mm_bf16 = mm_bf16
         unets = [m for m in gen.model if not isinstance(m, nn.Tanh)]
         dims = unets[0].dimensions
         dev = store.flat.device
@@ -1191,10 +1215,11 @@ class GeneratorPlan:
                 g = dict(gb[u % 2])
                 g["g_out"] = self.g_acts[u + 1]
                 g["g_x"] = self.g_acts[u] if (u > 0 or want_input_grad) else None
-            self.unet_plans.append(UNetPlan(unet, store, n, spatial, self.acts[u], self.acts[u + 1],
-                                            tanh_out=(u == nU - 1), instance=instance, want_backward=want_backward,
-                                            gbufs=g, scratch=self.scratch, training=training,
-                                            own_mark=marks[u], wait_mark=marks[u + 2] if u + 2 < nU else None))
+            with geom_defaults(mm_bf16=mm_bf16):
+                self.unet_plans.append(UNetPlan(unet, store, n, spatial, self.acts[u], self.acts[u + 1],
+                                                tanh_out=(u == nU - 1), instance=instance, want_backward=want_backward,
+                                                gbufs=g, scratch=self.scratch, training=training,
+                                                own_mark=marks[u], wait_mark=marks[u + 2] if u + 2 < nU else None))
         self.scratch.alloc()
         wants = [w for p in self.unet_plans for w in p.acc_wants]
         self.acc_all = None

@@ -208,8 +208,11 @@ class GAN(nn.Module):
         self.hparams = types.SimpleNamespace(latent_dim=latent_dim, g_lr=g_lr, d_lr=d_lr, b1=b1, b2=b2,
                                              batch_size=batch_size, one_sided_label_value=one_sided_label_value)
         data_shape = (channels, width, height) + ((depth,) if dimensions == 3 else ())
+        # storage_dtype="bf16" is config C5: the discriminator stores its activations in bf16 and the generator's
+        # matrix products take bf16 operands (fp32 storage: its launches are matrix-bound, not byte-bound)
         self.generator = CasNetGenerator(data_shape, n_unet_blocks, dimensions=dimensions, norm=norm,
-                                         channels=unet_channels, strides=unet_strides, device=device)
+                                         channels=unet_channels, strides=unet_strides, device=device,
+                                         matmul_dtype="bf16" if storage_dtype == "bf16" else "f32")
         self.discriminator = Discriminator(data_shape, dimensions=dimensions, device=device,
                                            storage_dtype=storage_dtype)
         self.logged: Dict[str, torch.Tensor] = {}

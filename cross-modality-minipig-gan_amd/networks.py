@@ -196,11 +196,13 @@ class _GenFn(torch.autograd.Function):
         need_bwd = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         spatial = _spatial(x, gen.dimensions)
         n = x.shape[0]
-        key = (n, spatial, need_bwd, bool(ctx.needs_input_grad[0]), gen.training)
+        mm = gen.matmul_dtype == "bf16"
+        key = (n, spatial, need_bwd, bool(ctx.needs_input_grad[0]), gen.training, mm)
         store = gen.store
         plan = gen._acquire(key, lambda: GeneratorPlan(gen, store, n, spatial, want_backward=need_bwd,
                                                       want_input_grad=bool(ctx.needs_input_grad[0]),
-                                                      instance=gen.norm.startswith("instance"), training=gen.training))
+                                                      instance=gen.norm.startswith("instance"), training=gen.training,
+                                                      mm_bf16=mm))
         lease = _Lease(plan)
         # C == 1: NC(D)HW and channels-last coincide, so the kernels read the caller's tensor and write the returned
         # one in place (engine.IoSlots); a misaligned or strided tensor goes through the plan's staging buffer.
@@ -252,10 +254,16 @@ class CasNetGenerator(_EngineModule):
     n_unet_blocks=4, channels=(32,64,128,256), strides=(2,2,2,2))."""
 
     def __init__(self, img_shape, n_unet_blocks=6, *, dimensions=3, norm="batch", channels=(16, 32, 64, 128),
-                 strides=(2, 2, 2), device=None):
+                 strides=(2, 2, 2), device=None, matmul_dtype="f32"):
         super().__init__()
+        if matmul_dtype not in ("f32", "bf16"):
+            raise ValueError(f"matmul_dtype must be 'f32' or 'bf16', got {matmul_dtype!r}")
         self.img_shape = img_shape
         self.dimensions, self.norm = dimensions, norm
+        # "bf16": the matrix products of the MFMA-served convs take bf16-rounded operands and accumulate in fp32
+        # (config C5); parameters, activations, statistics, gradients and Adam stay fp32.  May be switched on a
+        # live module: plans are keyed by it.
+        self.matmul_dtype = matmul_dtype
         nets = [UNet(dimensions, 1, 1, channels, strides, 2, norm) for _ in range(n_unet_blocks)]
         nets.append(nn.Tanh())
         self.model = nn.Sequential(*nets)

@@ -8,6 +8,7 @@ here computes: every function ends in exactly one C call.
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
@@ -63,6 +64,8 @@ class ConvGeom:
     pad: Tuple[int, int, int]
     transposed: bool = False
     out_pad: Tuple[int, int, int] = (0, 0, 0)
+    mm_bf16: bool = False      # MPGAN_CONV_MM_BF16: matrix operands rounded to bf16, fp32 storage and accumulation
+    min_blocks: int = 0        # launch size from which the big-tile forms serve this conv (0: the library's 1024)
 
     @property
     def out_dhw(self) -> Tuple[int, int, int]:
@@ -85,11 +88,12 @@ class ConvGeom:
         g.stride[:] = self.stride
         g.pad[:] = self.pad
         g.transposed = 1 if self.transposed else 0
+        g.flags = 1 if self.mm_bf16 else 0
+        g.min_blocks = int(self.min_blocks)
         return g
 
     def with_n(self, n: int) -> "ConvGeom":
-        return ConvGeom(n, self.in_dhw, self.cin, self.cout, self.k, self.stride, self.pad, self.transposed,
-                        self.out_pad)
+        return dataclasses.replace(self, n=n)
 
 
 @dataclass

@@ -54,7 +54,19 @@ typedef struct {
   int32_t stride[3];         /* per-dimension stride (1 in an unused depth dim) */
   int32_t pad[3];
   int32_t transposed;        /* 0: ConvNd, 1: ConvTransposeNd */
+  int32_t flags;             /* MPGAN_CONV_* bits below; 0 = the reference's fp32 arithmetic */
+  int32_t min_blocks;        /* launch size (in blocks) from which the big-tile forms serve this conv (the DMA-staged fp32
+                              * form, the wide bf16 forms); 0 = the library's default (1024).  It travels WITH the
+                              * geometry, so a sizing query (mpgan_conv_stats_rows*, mpgan_conv_variant*) and the launch
+                              * it sizes cannot disagree; the library keeps no mutable dispatch state. */
 } mpgan_conv_geom;
+
+/* flags: matrix operands of this conv are rounded to bf16 on their way into LDS and contracted on the bf16 matrix
+ * cores with fp32 accumulation (16x the fp32 matrix rate); tensors in HBM, the prologue's arithmetic, bias,
+ * residual and statistics stay fp32.  Honoured by the MFMA kernels (K-stepped and 3-D patch forms, forward /
+ * backward-data / backward-weight); the thin VALU kernels of 1-channel layers ignore it.  Statistics-row counts and
+ * workspace sizes do not depend on it.  Config C5's generator (BASELINE.json: "3D 128^3 ... bf16"). */
+#define MPGAN_CONV_MM_BF16 1
 
 /* Optional "normalise + activate on load" prologue applied to the operand that
  * is a raw (pre-norm) conv output: a = act(z*scale[c] + shift[c]).
@@ -484,13 +496,8 @@ int mpgan_norm_bwd_apply_bf16(const void* g, int32_t g_f32, int32_t ldg, const v
 int mpgan_debug_stamps(void* buf, int64_t launches, int64_t blocks_per_launch);
 int64_t mpgan_debug_stamps_used(void);
 int32_t mpgan_debug_clock_khz(void);
-/* Blocks from which the wide (128 x 64 per wave) forms of the bf16 K-stepped kernel serve a gather (default 1024;
- * tests set 1 to run small shapes through them).  Returns the previous value; blocks <= 0 only reads it.  The
- * statistics-row count of mpgan_conv_stats_rows_bf16 follows the choice. */
-int32_t mpgan_debug_bf16_wide_min_blocks(int32_t blocks);
-/* The same for the fp32 DMA-staged form of the K-stepped kernel (prologue-free gathers: the discriminator's
- * backward-data launches; mpgan_conv_variant reports it as 3000 + tile width). */
-int32_t mpgan_debug_f32_dma_min_blocks(int32_t blocks);
+/* (Rounds 2-3 had two process-wide setters here for the launch size from which the big-tile forms are used;
+ *  since ABI version 2 that threshold is the geometry's own `min_blocks` field: no mutable dispatch state.) */
 
 #ifdef __cplusplus
 }

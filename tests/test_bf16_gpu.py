@@ -23,10 +23,14 @@ pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 
 
+_MIN_BLOCKS = [0]       # the geometry's big-tile threshold for the geometries this module builds (fixture `wide_forms`)
+
+
 def _geom(n, spatial, cin, cout, k, s, p):
     from mpgan_amd import ops
     dims = len(spatial)
-    return ops.ConvGeom(n, t3(spatial, dims, 1), cin, cout, t3(k, dims, 1), t3(s, dims, 1), t3(p, dims, 0))
+    return ops.ConvGeom(n, t3(spatial, dims, 1), cin, cout, t3(k, dims, 1), t3(s, dims, 1), t3(p, dims, 0),
+                        min_blocks=_MIN_BLOCKS[0])
 
 
 def _sparse_int(shape, gen, density=0.06, lo=-2, hi=2):
@@ -136,11 +140,11 @@ WIDE_CASES = [  # shapes of CASES' classes that the wide (128 x 64 per wave) for
 
 @pytest.fixture
 def wide_forms():
-    """Run small shapes through gather_conv_bf16_wide_kernel (it otherwise serves launches of >= 1024 blocks)."""
-    from mpgan_amd._lib import lib
-    old = lib().mpgan_debug_bf16_wide_min_blocks(1)
+    """Run small shapes through gather_conv_bf16_wide_kernel (it otherwise serves launches of >= 1024 blocks): the
+    threshold travels with the geometry (mpgan_conv_geom.min_blocks), so sizing queries and launches agree."""
+    _MIN_BLOCKS[0] = 1
     yield
-    lib().mpgan_debug_bf16_wide_min_blocks(old)
+    _MIN_BLOCKS[0] = 0
 
 
 @pytest.mark.parametrize("n,spatial,cin,cout,k,s,p", WIDE_CASES, ids=lambda v: str(v))

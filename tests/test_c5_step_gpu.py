@@ -1,21 +1,24 @@
 """BASELINE config C5 as an ASSEMBLED step: the reference's true graph (3-D U-Net cascade + Conv3d discriminator,
 code/GAN/GAN_final.py:106-114,167-189,250-296) through `GAN(..., storage_dtype="bf16").fit_batch` -- the bf16-storage
-discriminator feeding its input gradient into the fp32 generator's backward, both optimizers, BatchNorm bookkeeping.
+discriminator feeding its input gradient into the generator's backward, both optimizers, BatchNorm bookkeeping.
+Since round 4 the generator's matrix products take bf16 operands too (fp32 storage; MPGAN_CONV_MM_BF16).
 
-Checker: oracle/refmodel.py (fp32, the generator) + oracle/bf16_emul.py (the discriminator under the bf16-storage
-contract of DESIGN.md section 3a).  Two implementations of a bf16-storage network agree on LOSSES and FORWARD values
-at the 1e-3 level but not on whole-network gradients (a rounding to bf16 turns an fp32-level difference into
-one-ulp flips that BatchNorm's backward amplifies: tests/test_bf16_gpu.py measures 2-10 %), so the gradient checks
-are arranged to be well-conditioned:
+Checker: oracle/mm16_emul.py (the generator under the bf16-operand contract) + oracle/bf16_emul.py (the discriminator
+under the bf16-storage contract of DESIGN.md section 3a), with oracle/refmodel.py in pure fp32 beside them as the
+measure of what each contract costs.  Two implementations of a network that rounds to bf16 inside agree on LOSSES
+and FORWARD values at the 1e-3 level but not on whole-network gradients (a rounding turns an fp32-level difference
+into one-ulp flips that BatchNorm's backward amplifies: tests/test_bf16_gpu.py measures 2-10 %).  The KERNELS are
+pinned elsewhere -- bit-exact on bf16-representable operands and to 2e-4 on random ones, op by op
+(tests/test_mm16_gpu.py, tests/test_bf16_gpu.py) -- and this file holds the assembly by ONE rule, fixed before any
+run: a quantity of ours may sit no further from the emulation than TWICE the emulation's own distance to pure fp32
+(the precision cost of the contract, printed beside every check) + 2e-2 relative L2 for gradients, + 1e-4 absolute
+for mean-absolute forward values; what has no cancellation yet (losses, D's head) is held to 5e-3 / 1e-2.
   * the generator's gradient is compared TEACHER-FORCED at the hand-off: the upstream gradient dL/dy our bf16
-    discriminator + L1 loss produced is fed to the fp32 oracle generator's backward, and every parameter gradient
-    must then agree at fp32 level (flat relative L2 2e-2; per tensor no further from an fp64 run of the same
-    backward than torch's own fp32 run is, times 3) -- this pins the g_x -> GeneratorPlan.backward wiring, the 3-D patch kernels
-    (gather_patch3d_c16 / wgrad_patch3d_c16 at a size where persistent blocks walk several tiles, with ragged
-    tiles) and all statistics rows;
-  * dL/dy itself and the discriminator's gradients are held against the emulation by the sanity bound of
-    test_bf16_gpu.py (within twice the emulation's own distance to pure fp32, + 2e-2), the head
-    (no cancellation yet) to 1e-2."""
+    discriminator + L1 loss produced is fed to the emulated generator's backward -- this pins the g_x ->
+    GeneratorPlan.backward wiring, the 3-D patch kernels (gather_patch3d_c16 / wgrad_patch3d_c16 at a size where
+    persistent blocks walk several tiles, with ragged tiles) and all statistics rows;
+  * the fp64 yardstick of the fp32 tests (err(ours, f64) vs err(torch f32, f64)) is printed as well, over the
+    emulation run in fp32 and in fp64."""
 import pytest
 import torch
 
@@ -45,6 +48,7 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
     from mpgan_amd import ops
     from mpgan_amd.gan import GAN
     from oracle import bf16_emul as E
+    from oracle import mm16_emul as M
     from oracle import refmodel as R
     S, n = 72, 2
     shape = (1, S, S, S)
@@ -82,10 +86,16 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
     # ---------------- G step on the oracle side ----------------
     import copy
     rg, rd = ref.generator, ref.discriminator
-    rg64 = copy.deepcopy(rg).double()
+    rg_pure = copy.deepcopy(rg)                                                   # the same generator without the contract
+    rg64 = M.apply_mm16(copy.deepcopy(rg).double())                               # (patch AFTER the copy: the hooks bind modules)
+    M.apply_mm16(rg)
     y_ref = rg(t1)
-    assert (captured["y"].cpu() - y_ref).abs().mean().item() < 1e-4              # fp32 generator: north_star's L1 bound
-    assert (captured["y"].cpu() - y_ref).abs().max().item() < 2e-3
+    y_pure = rg_pure(t1)
+    e_y, cost_y = (captured["y"].cpu() - y_ref).abs().mean().item(), (y_ref - y_pure).abs().mean().item()
+    print(f"G output L1: ours vs bf16-operand emulation {e_y:.3e}; emulation vs fp32 oracle (precision cost) {cost_y:.3e}; "
+          f"ours vs fp32 oracle {(captured['y'].cpu() - y_pure).abs().mean().item():.3e}")
+    assert e_y <= 2 * cost_y + 1e-4, (e_y, cost_y)
+    assert (captured["y"].cpu() - y_ref).abs().max().item() <= 2 * (y_ref - y_pure).abs().max().item() + 2e-3
     adv = E.disc_step(rd, y_ref.detach(), 1.0)
     g_recon = F.l1_loss(y_ref, t2)
     assert abs(log["g_recon_loss"] - g_recon.item()) <= 2e-3 * g_recon.item()
@@ -101,42 +111,42 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
     e_gy, cost_gy = _rel(gy, gy_emul), _rel(gy_emul, gy_f32)
     print(f"dL/dy: ours vs bf16 emulation {e_gy:.4f}; emulation vs fp32 oracle (precision cost) {cost_gy:.4f}")
     assert e_gy <= 2 * cost_gy + 2e-2, (e_gy, cost_gy)
-    # teacher-forced: OUR upstream gradient through the oracle generator's backward -- in fp32 and, as the
-    # yardstick, in fp64 (BatchNorm over the 9^3 x 2 values of the deepest level and PReLU-kink flips make single
-    # tensors of ANY fp32 backward differ by percents): err(ours, f64) <= 3 err(oracle f32, f64) + eps,
-    # eps = 1e-2 for every tensor and 2e-3 for at least 90 % of them
+    # teacher-forced: OUR upstream gradient through the emulated generator's backward (fp32), through the same
+    # generator without the contract (the precision cost), and through the emulation in fp64 (the yardstick, printed)
     y_ref.backward(gy)
+    y_pure.backward(gy)
     y64 = rg64(t1.double())
     y64.backward(gy.double())
     gg = tap.grads[id(ours.generator)]
-    rp, p64 = dict(rg.named_parameters()), dict(rg64.named_parameters())
+    rp, pp, p64 = dict(rg.named_parameters()), dict(rg_pure.named_parameters()), dict(rg64.named_parameters())
     gmax = max(p.grad.abs().max().item() for p in rp.values())
     errs, bad = {}, []
     for name, p in rp.items():
         if name.endswith("conv.bias") and (name[:-len("conv.bias")] + "adn.N.weight") in rp:
-            assert gg[name].abs().max().item() <= 1e-4 * gmax + 1e-6, name      # true gradient: zero
+            # true gradient: zero; what is left is summation noise of the (unrounded) dy column sums
+            assert gg[name].abs().max().item() <= 1e-4 * gmax + 1e-6, name
             continue
         if p.numel() == 1:
             continue
-        e_ours, e_32 = _rel(gg[name], p64[name].grad), _rel(p.grad, p64[name].grad)
-        errs[name] = (e_ours, e_32)
-        if e_ours > 3 * e_32 + 1e-2:             # eps: one PReLU-kink flip (tests/test_fullsize_gpu.py: YARD_EPS)
-            bad.append((name, e_ours, e_32))
-    tight = sum(a <= 3 * b + 2e-3 for a, b in errs.values())
-    assert tight >= 0.9 * len(errs), (tight, len(errs))
+        e_ours, cost, e_64, y_64 = (_rel(gg[name], p.grad), _rel(p.grad, pp[name].grad), _rel(gg[name], p64[name].grad),
+                                    _rel(p.grad, p64[name].grad))
+        errs[name] = (e_ours, cost, e_64, y_64)
+        if e_ours > 2 * cost + 2e-2:
+            bad.append((name, e_ours, cost))
     flat_o = torch.cat([gg[k].reshape(-1) for k in rp])
     flat_r = torch.cat([p.grad.reshape(-1) for p in rp.values()])
+    flat_p = torch.cat([pp[k].grad.reshape(-1) for k in rp])
     flat_64 = torch.cat([p64[k].grad.reshape(-1) for k in rp])
     worst = sorted(errs.items(), key=lambda kv: -kv[1][0])[:4]
-    print("G gradient, teacher-forced at dL/dy: flat rel-L2 vs f32", _rel(flat_o, flat_r), "vs f64", _rel(flat_o, flat_64),
-          "(oracle f32 vs f64:", _rel(flat_r, flat_64), ") worst tensors (ours, oracle f32)", worst)
+    print("G gradient, teacher-forced at dL/dy: flat rel-L2 ours vs emulation", _rel(flat_o, flat_r), "; emulation vs fp32 oracle",
+          "(precision cost)", _rel(flat_r, flat_p), "; yardstick: ours vs emulation-f64", _rel(flat_o, flat_64),
+          ", emulation-f32 vs -f64", _rel(flat_r, flat_64), "; worst tensors (ours vs emul, cost, ours vs f64, emul vs f64)", worst)
     assert not bad, sorted(bad, key=lambda r: -r[1])[:6]
-    assert _rel(flat_o, flat_r) <= 2e-2
-    assert _rel(flat_o, flat_64) <= 3 * _rel(flat_r, flat_64) + 2e-3
-    slopes = {k: (gg[k].item(), p.grad.item(), p64[k].grad.item()) for k, p in rp.items() if p.numel() == 1}
-    smax = max(abs(w64) for _, _, w64 in slopes.values())
-    for k, (gv, w32, w64) in slopes.items():
-        assert abs(gv - w64) <= 3 * abs(w32 - w64) + 2e-3 * smax, (k, gv, w32, w64)
+    assert _rel(flat_o, flat_r) <= 2 * _rel(flat_r, flat_p) + 2e-2
+    slopes = {k: (gg[k].item(), p.grad.item(), pp[k].grad.item()) for k, p in rp.items() if p.numel() == 1}
+    smax = max(abs(w) for _, w, _ in slopes.values())
+    for k, (gv, we, wp) in slopes.items():
+        assert abs(gv - we) <= 2 * abs(we - wp) + 2e-2 * smax, (k, gv, we, wp)
 
     # ---------------- D step: same generator weights on both sides ----------------
     with torch.no_grad():
@@ -172,8 +182,8 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
     for k, v in rg.state_dict().items():
         if k.endswith("num_batches_tracked"):
             assert int(sd_g[k]) == 2 == int(v), k
-        elif "running_" in k:
-            assert (sd_g[k].cpu() - v).abs().max().item() <= 1e-4 * v.abs().max().item() + 1e-5, k
+        elif "running_" in k:      # fp32 statistics of convs whose operands were rounded: the D bound below
+            assert (sd_g[k].cpu() - v).abs().max().item() <= 1e-2 * v.abs().max().item() + 1e-4, k
     for k, v in rd.state_dict().items():
         if k.endswith("num_batches_tracked"):
             assert int(sd_d[k]) == 3 == int(v), k
@@ -182,18 +192,23 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
 
 
 def test_c5_full_size_step_is_finite_deterministic_and_g_matches_oracle():
-    """Config C5 itself: 128^3, bs 4, bf16 storage in D.  The CPU oracle cannot check a whole step at this size in
-    test time, so: (a) the (16, 32, 64, 128) generator's forward on ONE 128^3 volume against the oracle (L1 < 1e-4);
+    """Config C5 itself: 128^3, bs 4, bf16 storage in D, bf16 matrix operands in G.  The CPU oracle cannot check a whole
+    step at this size in test time, so: (a) the (16, 32, 64, 128) generator's forward on ONE 128^3 volume against the
+    bf16-operand emulation (mean absolute difference within twice the emulation's own distance to the fp32 oracle + 1e-4);
     (b) a full `fit_batch` -- all four logged losses finite and in BCE / L1 range, every parameter and gradient
     finite, BatchNorm counters 2 (G) and 3 (D); (c) the same step with the second stream switched off is
     bit-identical (weight gradients beside the backward chain, no floating-point atomics anywhere)."""
     from mpgan_amd import engine
     from mpgan_amd.gan import GAN
+    from oracle import mm16_emul as M
     from oracle import refmodel as R
+    import copy
     S, n = 128, 4
     ref_g = R.CasNetGenerator((1, S, S, S), 6, dimensions=3)
     R.closed_form_fill_(ref_g)
     ref_g.train()
+    ref_pure = copy.deepcopy(ref_g)
+    M.apply_mm16(ref_g)
     sd_g = {k: v.clone() for k, v in ref_g.state_dict().items()}
     torch.manual_seed(0)
     shell_d = R.Discriminator((1, S, S, S), dimensions=3)
@@ -228,8 +243,12 @@ def test_c5_full_size_step_is_finite_deterministic_and_g_matches_oracle():
     m, log, y1 = run(False)
     with torch.no_grad():
         y_ref = ref_g(t1[:1])
-    l1 = (y1 - y_ref).abs().mean().item()
-    assert l1 < 1e-4 and (y1 - y_ref).abs().max().item() < 2e-3, (l1, (y1 - y_ref).abs().max().item())
+        y_pure = ref_pure(t1[:1])
+    l1, cost = (y1 - y_ref).abs().mean().item(), (y_ref - y_pure).abs().mean().item()
+    print(f"G output L1 at 128^3: ours vs bf16-operand emulation {l1:.3e}; emulation vs fp32 oracle (precision cost) {cost:.3e}; "
+          f"ours vs fp32 oracle {(y1 - y_pure).abs().mean().item():.3e}")
+    assert l1 <= 2 * cost + 1e-4, (l1, cost)
+    assert (y1 - y_ref).abs().max().item() <= 2 * (y_ref - y_pure).abs().max().item() + 2e-3
     for k in ("g_adv_loss", "g_recon_loss", "g_loss", "d_loss"):
         assert k in log and log[k] == log[k] and 0.0 <= log[k] <= 101.0, (k, log.get(k))      # BCE's -100 clamp bounds it
     assert 0.0 < log["g_recon_loss"] < 2.0

@@ -56,10 +56,13 @@ CONVT_CASES = [
 ]
 
 
+_MIN_BLOCKS = [0]       # the geometry's big-tile threshold for the geometries this module builds (fixture `dma_form`)
+
+
 def _geom(dims, n, cin, cout, k, s, p, spatial, transposed=False):
     from mpgan_amd.ops import ConvGeom
     return ConvGeom(n, t3(spatial, dims, 1), cin, cout, t3(k, dims, 1), t3(s, dims, 1), t3(p, dims, 0),
-                    transposed, t3(s - 1, dims, 0) if transposed else (0, 0, 0))
+                    transposed, t3(s - 1, dims, 0) if transposed else (0, 0, 0), min_blocks=_MIN_BLOCKS[0])
 
 
 def _conv(dims):
@@ -690,11 +693,11 @@ def test_patch2d_weight_gradient_prologue_slices_and_many_tiles(cd, cg, s, spati
 
 @pytest.fixture
 def dma_form():
-    """Run small shapes through gather_conv_dma_kernel (it otherwise serves prologue-free launches of >= 1024 blocks)."""
-    from mpgan_amd._lib import lib
-    old = lib().mpgan_debug_f32_dma_min_blocks(1)
+    """Run small shapes through gather_conv_dma_kernel (it otherwise serves prologue-free launches of >= 1024 blocks):
+    the threshold travels with the geometry (mpgan_conv_geom.min_blocks)."""
+    _MIN_BLOCKS[0] = 1
     yield
-    lib().mpgan_debug_f32_dma_min_blocks(old)
+    _MIN_BLOCKS[0] = 0
 
 
 DMA_CASES = [   # enough tiles for the 64- / 128-wide K-stepped variants (select_variant), prologue-free

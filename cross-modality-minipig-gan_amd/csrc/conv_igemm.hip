@@ -2493,17 +2493,28 @@ constexpr int P3_PY = P3_TY + 2, P3_PX = P3_TX + 2;
 constexpr int P3_PROWS = (P3_TZ + 2) * P3_PY * P3_PX;          // 400 patch pixels
 constexpr int P3_PA = 24, P3_PW = 20;                          // LDS pitches (floats) of a patch pixel / a weight row
 constexpr int P3_SMEM = (P3_PROWS * P3_PA + 27 * 16 * P3_PW + 4 * 2 * 16) * 4;
+constexpr int P3M_PXP = 16;                                    // MM16: pixels per patch row in LDS
+constexpr int P3M_PATCHB = (P3_TZ + 2) * P3_PY * P3M_PXP * 32, P3M_WB = 27 * 16 * 32;
+constexpr int P3M_SMEM = P3M_PATCHB + P3M_WB + 4 * 2 * 16 * 4;
 struct P3Grid { int tiles_z, tiles_y, tiles_x; };
 
 //   MM16 (MPGAN_CONV_MM_BF16): the contraction on v_mfma_f32_16x16x32_bf16 -- K = 32 is two taps x 16 channels; lane
-//   (row ln, k-quarter kq) reads the 8 channels 8 (kq & 1) .. + 7 of tap 2 t + (kq >> 1) from the fp32 patch / weight
-//   images, rounds them to bf16 and 14 MFMAs per 16-row block replace 108 (the 28th tap slot multiplies zeros).
+//   (row ln, k-quarter kq) holds the 8 channels 8 (kq & 1) .. + 7 of tap 2 t + (kq >> 1): 14 MFMAs per 16-row block
+//   replace 108 (the 28th tap slot multiplies zero weights).  Patch and weights are rounded to bf16 ONCE, on their way
+//   into LDS (a first version kept them fp32 and converted at fragment-read time: 336 conversions per lane and tile
+//   and 3-4-way bank conflicts of the per-lane tap offsets made it SLOWER than the fp32 kernel, 221 vs 165 us).
+//   Images: a pixel / weight row is 32 unpadded bytes, a patch row 16 pixels (10 used), so the ds_read_b128 of a
+//   16-lane group -- 8 lanes x channels 0-7 and 8 lanes x channels 8-15 over two patch rows -- covers 16 distinct
+//   16-byte slots: chunk index 2 (x + 16 y) + (kq & 1) mod 16.
 template <bool HAS_PRO, bool MM16 = false>
 __global__ __launch_bounds__(256, 2) void gather_patch3d_c16_kernel(const GatherConv p, const P3Grid tg) {
   extern __shared__ __attribute__((aligned(16))) float sm3[];
   float* patch = sm3;
   float* wl = sm3 + P3_PROWS * P3_PA;
-  float* st = wl + 27 * 16 * P3_PW;                             // [4 waves][2][16]
+  float* st = MM16 ? sm3 + (P3M_PATCHB + P3M_WB) / 4 : wl + 27 * 16 * P3_PW;   // [4 waves][2][16]
+  char* patchb = reinterpret_cast<char*>(sm3);                 // MM16 images (bf16)
+  char* wlb = patchb + P3M_PATCHB;
+  typedef __bf16 p3_bf16x4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const Phase& ph = p.ph[0];
   // Persistent blocks: the 27 taps' weights are staged once, then the block walks tiles (XCD-contiguous ranges).
@@ -2569,8 +2580,15 @@ __global__ __launch_bounds__(256, 2) void gather_patch3d_c16_kernel(const Gather
       const bool ok = (pok >> i) & 1u;                           // the conv's zero padding is a zero of the ACTIVATED tensor
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
       if (pzyx[i] >= 0) {
+        if constexpr (MM16) {
+          const int pr = ((pzyx[i] >> 16) * P3_PY + ((pzyx[i] >> 8) & 255)) * P3M_PXP + (pzyx[i] & 255);
+          p3_bf16x4 o;
+          o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+          *reinterpret_cast<p3_bf16x4*>(patchb + pr * 32 + 8 * c4) = o;
+        } else {
         const int pr = ((pzyx[i] >> 16) * P3_PY + ((pzyx[i] >> 8) & 255)) * P3_PX + (pzyx[i] & 255);
         *reinterpret_cast<float4*>(patch + pr * P3_PA + 4 * c4) = v;
+        }
       }
     }
   };
@@ -2593,7 +2611,13 @@ __global__ __launch_bounds__(256, 2) void gather_patch3d_c16_kernel(const Gather
       if (e < 27 * 16 * 4) {
         const int k4 = e & 3, row = e >> 2;                    // row = co * 27 + tap
         const int co = row / 27, tap = row - co * 27;
-        *reinterpret_cast<float4*>(wl + (tap * 16 + co) * P3_PW + 4 * k4) = wv[i];
+        if constexpr (MM16) {
+          p3_bf16x4 o;
+          o[0] = (__bf16)wv[i].x; o[1] = (__bf16)wv[i].y; o[2] = (__bf16)wv[i].z; o[3] = (__bf16)wv[i].w;
+          *reinterpret_cast<p3_bf16x4*>(wlb + (tap * 16 + co) * 32 + 8 * k4) = o;
+        } else {
+          *reinterpret_cast<float4*>(wl + (tap * 16 + co) * P3_PW + 4 * k4) = wv[i];
+        }
       }
     }
   }
@@ -2621,8 +2645,15 @@ __global__ __launch_bounds__(256, 2) void gather_patch3d_c16_kernel(const Gather
   const int fz = p.dstep[0] < 0 ? 2 : 0, fy = p.dstep[1] < 0 ? 2 : 0, fx = p.dstep[2] < 0 ? 2 : 0;
   if constexpr (MM16) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    const int kh = (g & 1) * 8;                                  // this lane's 8 channels
+    const int kb = (g & 1) * 16;                                 // byte offset of this lane's 8 channels in a 32-byte row
     const bool second = (g >> 1) != 0;                           // ... of the pair's second tap
+    int ab[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int q = wid * 32 + rb * 16 + ln;
+      ab[rb] = ((((q >> 6) * P3_PY) + ((q >> 3) & 7)) * P3M_PXP + (q & 7)) * 32 + kb;
+    }
+    const int wb = ln * 32 + kb;
 #pragma unroll
     for (int tp = 0; tp < 14; ++tp) {
       int offs[2], taps[2];
@@ -2630,24 +2661,18 @@ __global__ __launch_bounds__(256, 2) void gather_patch3d_c16_kernel(const Gather
       for (int e = 0; e < 2; ++e) {
         const int t = 2 * tp + e < 27 ? 2 * tp + e : 26;         // (slot 27: a valid address, its weights read as zeros)
         const int jz = t / 9, jy = (t / 3) % 3, jx = t % 3;
-        offs[e] = ((fz + p.dstep[0] * jz) * P3_PY + (fy + p.dstep[1] * jy)) * P3_PX + (fx + p.dstep[2] * jx);
-        taps[e] = ((ph.kz0 + p.kstep[0] * jz) * 3 + (ph.ky0 + p.kstep[1] * jy)) * 3 + (ph.kx0 + p.kstep[2] * jx);
+        offs[e] = (((fz + p.dstep[0] * jz) * P3_PY + (fy + p.dstep[1] * jy)) * P3M_PXP + (fx + p.dstep[2] * jx)) * 32;
+        taps[e] = (((ph.kz0 + p.kstep[0] * jz) * 3 + (ph.ky0 + p.kstep[1] * jy)) * 3 + (ph.kx0 + p.kstep[2] * jx)) * 16 * 32;
       }
-      const int off = second ? offs[1] : offs[0], tap = second ? taps[1] : taps[0];
-      const bool live = !(second && 2 * tp + 1 >= 27);
-      const float* wr = wl + (tap * 16 + ln) * P3_PW + kh;
-      float4 b0 = *reinterpret_cast<const float4*>(wr), b1 = *reinterpret_cast<const float4*>(wr + 4);
-      if (!live) { b0 = make_float4(0.f, 0.f, 0.f, 0.f); b1 = b0; }
-      bf16x8 bf;
-      bf[0] = (__bf16)b0.x; bf[1] = (__bf16)b0.y; bf[2] = (__bf16)b0.z; bf[3] = (__bf16)b0.w;
-      bf[4] = (__bf16)b1.x; bf[5] = (__bf16)b1.y; bf[6] = (__bf16)b1.z; bf[7] = (__bf16)b1.w;
+      const int off = second ? offs[1] : offs[0], tapb = second ? taps[1] : taps[0];
+      bf16x8 bf = *reinterpret_cast<const bf16x8*>(wlb + tapb + wb);
+      if (second && 2 * tp + 1 >= 27) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bf[e] = (__bf16)0.f;
+      }
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
-        const float* ar = patch + (abase[rb] + off) * P3_PA + kh;
-        const float4 a0 = *reinterpret_cast<const float4*>(ar), a1 = *reinterpret_cast<const float4*>(ar + 4);
-        bf16x8 af;
-        af[0] = (__bf16)a0.x; af[1] = (__bf16)a0.y; af[2] = (__bf16)a0.z; af[3] = (__bf16)a0.w;
-        af[4] = (__bf16)a1.x; af[5] = (__bf16)a1.y; af[6] = (__bf16)a1.z; af[7] = (__bf16)a1.w;
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(patchb + ab[rb] + off);
         acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[rb], 0, 0, 0);
       }
     }
@@ -2741,9 +2766,9 @@ static int launch_patch3d(const GatherConv& p, hipStream_t st) {
     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_patch3d_c16_kernel<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
     hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_patch3d_c16_kernel<true, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, P3M_SMEM);
     hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_patch3d_c16_kernel<false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, P3_SMEM);
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, P3M_SMEM);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
       set_error("gather_patch3d: hipFuncSetAttribute: %s",
                 hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : (e3 != hipSuccess ? e3 : e4))));
@@ -2756,8 +2781,8 @@ static int launch_patch3d(const GatherConv& p, hipStream_t st) {
   dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512));          // two resident blocks per CU, each walking its range of tiles
   static const bool no_mm16 = getenv("MPGAN_DBG_NO_MM16") != nullptr;
   if (p.mm16 && !no_mm16) {
-    if (p.pro.scale) hipLaunchKernelGGL((gather_patch3d_c16_kernel<true, true>), grid, dim3(256), P3_SMEM, st, p, tg);
-    else hipLaunchKernelGGL((gather_patch3d_c16_kernel<false, true>), grid, dim3(256), P3_SMEM, st, p, tg);
+    if (p.pro.scale) hipLaunchKernelGGL((gather_patch3d_c16_kernel<true, true>), grid, dim3(256), P3M_SMEM, st, p, tg);
+    else hipLaunchKernelGGL((gather_patch3d_c16_kernel<false, true>), grid, dim3(256), P3M_SMEM, st, p, tg);
   } else if (p.pro.scale) hipLaunchKernelGGL(gather_patch3d_c16_kernel<true>, grid, dim3(256), P3_SMEM, st, p, tg);
   else hipLaunchKernelGGL(gather_patch3d_c16_kernel<false>, grid, dim3(256), P3_SMEM, st, p, tg);
   return check_launch("gather_patch3d_c16");

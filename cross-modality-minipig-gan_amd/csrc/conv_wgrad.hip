@@ -1049,6 +1049,9 @@ static ThinWgradPlan plan_thin_wgrad(int Cd, int Cg, int T, long M, bool has_pro
   t.rounds = 1;                                  // fold rounds of the lane rows (thin_wgrad_kernel): halve the LDS rows until they fit
   while (t.rounds < 4 && (PL / t.rounds) % 2 == 0 && (long)(PL / t.rounds) * (Cd * T + Cd) * 4 > lds_cap) t.rounds *= 2;
   if ((long)(PL / t.rounds) * (Cd * T + Cd) * 4 > lds_cap) t.ok = false;
+  // measured at C5 (128^3, bs 4): 1 -> 16 stride 2 (16 dense channels, two rounds) 136 -> 110 us against the generic
+  // MFMA kernel, but ConvTranspose 32 -> 1 (32 dense channels: 108 accumulators over only 32 pixel lanes) 141 -> 187 us
+  if (t.rounds > 1 && Cd > 16) t.ok = false;
   return t;
 }
 

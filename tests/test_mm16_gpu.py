@@ -169,11 +169,13 @@ def test_mm16_prologue_residual_statistics(cin, cout, k, s, spatial):
     rows = ops.conv_stats_rows(g, 1)
     assert rows == ops.conv_stats_rows(dataclasses.replace(g, mm_bf16=False), 1)      # sizing does not depend on the flag
     stats = torch.full((max(rows, 1) * 2 * cout,), float("nan"), device="cuda")
-    ops.conv_forward(g, xbuf[..., 4:4 + cin], ops.pack_weight(w.cuda()), b.cuda(), ybuf[..., 8:], pro=pro, resid=to_cl(r),
-                     stats_partials=stats if rows else None)
+    ops.conv_forward(g, xbuf[..., 4:4 + cin], ops.pack_weight(w.cuda()), b.cuda(), ybuf[..., 8:], pro=pro, resid=to_cl(r))
     assert_close(from_cl(ybuf[..., 8:], 3), (y0 + r).detach(), what="forward + residual")
     assert torch.isnan(ybuf[..., :8]).all()
-    if rows:
+    if rows:                               # (fused statistics describe the raw conv output: a launch without the residual)
+        ops.conv_forward(g, xbuf[..., 4:4 + cin], ops.pack_weight(w.cuda()), b.cuda(), ybuf[..., 8:], pro=pro,
+                         stats_partials=stats)
+        assert_close(from_cl(ybuf[..., 8:], 3), y0.detach(), what="forward with statistics")
         st = stats.view(rows, 2, cout).double().sum(0).cpu()
         zf = y0.detach().double()
         assert_close(st[0].float(), zf.sum((0, 2, 3, 4)).float(), rtol=1e-4, what="fused sum(z)")

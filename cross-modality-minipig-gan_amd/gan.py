@@ -46,7 +46,7 @@ class _L1Fn(torch.autograd.Function):
         a, b = y_hat.contiguous(), y.contiguous()
         loss = torch.empty((), device=a.device)
         part = torch.empty(ops.l1_partials(), device=a.device)
-        grad = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        grad = torch.empty_like(a) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
         ops.l1_loss(a, b, part, loss, grad, 1.0)
         ctx.grad = grad
         return loss
@@ -55,7 +55,8 @@ class _L1Fn(torch.autograd.Function):
     def backward(ctx, gout):
         g = torch.empty_like(ctx.grad)          # a fresh tensor: a second backward (retain_graph) sees the unscaled sign
         ops.scale_by_device_scalar(ctx.grad, gout.contiguous(), g)
-        return g, None
+        gb = ops.axpby(g, -1.0, None, 0.0, torch.empty_like(g)) if ctx.needs_input_grad[1] else None   # d/dy = -d/dy_hat
+        return (g if ctx.needs_input_grad[0] else None), gb
 
 
 class _AxpbyFn(torch.autograd.Function):

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .gan import FusedAdam, adversarial_loss, reconstruction_loss
+from .gan import FusedAdam, adversarial_loss, reconstruction_loss, scalar_axpby
 from .networks import CasNetGenerator, PatchDiscriminator, TapDict, _EngineModule
 
 
@@ -121,10 +121,13 @@ def perceptual_loss(y_hat_activations, y_activations):
     if isinstance(y_hat_activations, TapDict) and isinstance(y_activations, TapDict):
         tf, tr = y_hat_activations.tapset, y_activations.tapset      # fused: the 16 taps are never materialised
         return _PerceptualFn.apply(tf.handle, tr.handle, tf, tr)
-    # any other mapping of tensors (e.g. taps a caller materialised or detached): the reference's own body
-    running_sum = torch.zeros(1, device=y_hat_activations[0].device, dtype=y_hat_activations[0].dtype)
+    # any other mapping of tensors (e.g. taps a caller materialised or detached): the reference's body statement by
+    # statement, through the library's own L1 and axpby kernels (no eager-torch arithmetic on the path)
+    first = next(iter(y_hat_activations.values()))
+    running_sum = torch.zeros(1, device=first.device, dtype=first.dtype)
     for key in y_activations.keys():
-        running_sum = running_sum + torch.nn.functional.l1_loss(y_activations[key], y_hat_activations[key]) / y_activations[key].numel()
+        term = reconstruction_loss(y_activations[key], y_hat_activations[key])              # F.l1_loss(y, y_hat), mean
+        running_sum = scalar_axpby(running_sum, 1.0, term.reshape(1), 1.0 / y_activations[key].numel())
     return running_sum
 
 

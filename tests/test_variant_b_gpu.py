@@ -242,3 +242,26 @@ def test_reference_perceptual_loss_body_runs_on_the_returned_dict():
     v3, _ = ours(x3)
     adversarial_loss(v3, torch.ones_like(v3)).backward()
     assert torch.isfinite(x3.grad).all()
+
+
+def test_perceptual_loss_on_plain_mappings_runs_through_the_library():
+    """`perceptual_loss` given anything but two TapDicts (taps a caller materialised, detached or re-keyed) restates the
+    reference's body (test_runs/GAN.py:288-298) over the library's own L1 / axpby kernels: same value as torch's
+    arithmetic on the same tensors, shape (1,), gradients to BOTH arguments (F.l1_loss is differentiable in both)."""
+    from mpgan_amd.gan_patch import perceptual_loss
+    gen = torch.Generator().manual_seed(4)
+    shapes = [(2, 8, 5, 5, 5), (2, 4, 3, 3, 3), (2, 7), (2, 1)]
+    fake = {k: (torch.rand(*s, generator=gen) * 2 - 1).cuda().requires_grad_(True) for k, s in enumerate(shapes)}
+    real = {k: (torch.rand(*s, generator=gen) * 2 - 1).cuda().requires_grad_(True) for k, s in enumerate(shapes)}
+    got = perceptual_loss(fake, real)
+    assert got.shape == (1,)
+    want = _reference_perceptual_loss({k: v.detach().cpu().requires_grad_(True) for k, v in fake.items()},
+                                      {k: v.detach().cpu().requires_grad_(True) for k, v in real.items()})
+    assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, what="value")
+    got.sum().backward()
+    fc = {k: v.detach().cpu().requires_grad_(True) for k, v in fake.items()}
+    rc = {k: v.detach().cpu().requires_grad_(True) for k, v in real.items()}
+    _reference_perceptual_loss(fc, rc).sum().backward()
+    for k in fake:
+        assert_close(fake[k].grad.cpu(), fc[k].grad, rtol=1e-5, atol=1e-12, what=f"d/d fake[{k}]")
+        assert_close(real[k].grad.cpu(), rc[k].grad, rtol=1e-5, atol=1e-12, what=f"d/d real[{k}]")

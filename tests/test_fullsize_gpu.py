@@ -301,11 +301,18 @@ def test_seven_level_generator_of_generator_test_matches_oracle():
       * backward of the random volume through an L1 + L2 loss.  At this shape the fp32 backward is not a stable
         function of its inputs: BatchNorm over 8 and 64 values per channel on levels 5-7 cancels the gradient to
         ~1e-8 of its terms, and the oracle's OWN fp32 gradient differs from its fp64 gradient by O(1) in every
-        tensor below level 3 (tools/debug_seven.py prints the table).  So the yardstick is the fp64 oracle, and
-        each tensor of ours must be as close to it as the fp32 oracle is: err(ours, f64) <= 3 err(f32, f64) + 2e-3
-        in relative L2 (only finiteness where the fp32 oracle itself is >= 30 % off: two draws of O(1) noise).  The well-conditioned tensors (up path, levels 1-3: 1e-5 .. 1e-2) are held tightly by
-        that; for the chaotic ones it only says "no worse than torch".  The wide layers' kernels are checked
-        exactly in test_conv_gpu.py (512-channel cases)."""
+        tensor below level 3.  The yardstick is therefore the fp64 oracle, and the measure of "how far may a correct
+        fp32 evaluation sit from it" is taken from torch itself, in this very run: the fp32 oracle is evaluated FOUR
+        times -- on the input and on three copies of it with every element moved by -1 / 0 / +1 ulp -- and its
+        per-tensor error against fp64 moves by 2-8x between those draws (measured: the tensor that failed a 10x bound
+        in round 3 with 12.9 reads 4.1 / 9.3 / 20.0 / 7.9 over the four draws).  Rule, fixed before the run:
+          - a tensor whose median draw is < 30 % off: err(ours, f64) <= 3 max_draws err(f32, f64) + 2e-3;
+          - the others ("chaotic"): err(ours, f64) <= 3 S median_draws + 2e-3, S = the largest excursion of any
+            oracle draw above its tensor's median (the oracle's own spread, typically 3-5), AND the geometric mean over
+            those tensors of err(ours) / median_draws <= 3: a systematic loss of accuracy (a wrong summation, a kink
+            handled differently) moves the whole population, one unlucky draw does not;
+          - deep running statistics: the same two conditions with eps 1e-3.
+        The wide layers' kernels are checked exactly in test_conv_gpu.py (512-channel cases)."""
     import copy
     from mpgan_amd.gan import reconstruction_loss
     from mpgan_amd.networks import CasNetGenerator
@@ -321,6 +328,7 @@ def test_seven_level_generator_of_generator_test_matches_oracle():
     assert n_params == sum(p.numel() for p in ref.parameters()) == 129_425_400
 
     ref64 = copy.deepcopy(ref).double()
+    ref_state = copy.deepcopy(ref.state_dict())          # before any forward: the perturbed oracle draws start here
     ones = torch.ones(1, 1, 128, 128, 128)
     with torch.no_grad():
         y_ref1 = ref(ones)
@@ -340,7 +348,22 @@ def test_seven_level_generator_of_generator_test_matches_oracle():
         loss.backward()
         return y.detach(), loss.item()
 
+    # three more draws of the fp32 oracle on one-ulp perturbations of both inputs, each from the initial state
+    def perturbed_draw(seed):
+        m = copy.deepcopy(ref)
+        m.load_state_dict(ref_state)
+        for p in m.parameters():
+            p.grad = None
+        gp = torch.Generator().manual_seed(seed)
+        f = 1 + torch.randint(-1, 2, ones.shape, generator=gp).float() * 2.0 ** -23
+        with torch.no_grad():
+            m(ones * f)
+        xp = (x.detach() * f).requires_grad_(True)
+        run_ref(m, xp, t)
+        return {k: p.grad for k, p in m.named_parameters()}, xp.grad, m.state_dict()
+
     y_ref, loss_ref = run_ref(ref, x, t)
+    draws = [perturbed_draw(s) for s in (101, 102, 103)]
     x64 = x.detach().double().requires_grad_(True)
     y64, _ = run_ref(ref64, x64, t.double())
     xc = x.detach().cuda().requires_grad_(True)
@@ -352,40 +375,53 @@ def test_seven_level_generator_of_generator_test_matches_oracle():
     assert abs(loss.item() - loss_ref) <= 1e-4 * abs(loss_ref)
     loss.backward()
 
-    def held(name, got, g32, g64):
-        e_ours, e_32 = _rel_l2(got, g64), _rel_l2(g32, g64)
-        if e_32 >= 0.3:
-            # torch's own fp32 result is >= 30 % off its fp64 run: this tensor is not a stable function of its inputs
-            # at fp32 precision, and two fp32 evaluations are two draws from a heavy-tailed error distribution (any
-            # change of a summation order moves them by O(1); observed on one build: 12.9 against the oracle's 1.25) --
-            # nothing beyond "finite and not absurd" can be asked of such a tensor; the well-conditioned ones carry the test
-            assert e_ours == e_ours and e_ours <= 1e3, (name, e_ours, e_32)
-        else:
-            assert e_ours <= 3 * e_32 + 2e-3, (name, e_ours, e_32)
-        return e_ours, e_32
+    def oracle_errs(pick, g32, g64):
+        """err(f32, f64) of the four oracle draws for one tensor."""
+        return [_rel_l2(g32, g64)] + [_rel_l2(pick(d), g64) for d in draws]
 
-    held("dL/dx", xc.grad.cpu(), x.grad, x64.grad)
     p32, p64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
     gmax = max(p.grad.abs().max().item() for p in p64.values())
-    tight = 0
+    table = {"dL/dx": (_rel_l2(xc.grad.cpu(), x64.grad), oracle_errs(lambda d: d[1], x.grad, x64.grad))}
     for name, p in ours.named_parameters():
         if name.endswith("conv.bias") and (name[:-len("conv.bias")] + "adn.A.weight") in p32:
             assert p.grad.abs().max().item() <= 1e-4 * gmax + 1e-6, name      # true gradient: zero
             continue
         if p.numel() == 1:
-            g, g32, g64 = p.grad.item(), p32[name].grad.item(), p64[name].grad.item()
-            chaotic = abs(g32 - g64) >= 0.3 * abs(g64)               # the fp32 oracle itself misses by >= 30 % (see held())
-            assert abs(g - g64) <= (1e3 if chaotic else 3) * abs(g32 - g64) + 2e-3 * gmax, (name, g, g32, g64)
             continue
-        e_ours, e_32 = held(name, p.grad.cpu(), p32[name].grad, p64[name].grad)
-        tight += e_ours < 2e-2
+        table[name] = (_rel_l2(p.grad.cpu(), p64[name].grad), oracle_errs(lambda d, n=name: d[0][n], p32[name].grad, p64[name].grad))
+
+    def judge(table, eps, what):
+        """The rule of the docstring over {name: (err_ours, [err of each oracle draw])}."""
+        med = {k: float(np.median(v[1])) for k, v in table.items()}
+        chaotic = [k for k in table if med[k] >= 0.3]
+        spread = max([max(table[k][1]) / med[k] for k in chaotic], default=1.0)
+        bad = []
+        for k, (e_ours, es) in table.items():
+            bound = (3 * spread * med[k] if k in chaotic else 3 * max(es)) + eps
+            if not (e_ours == e_ours and e_ours <= bound):
+                bad.append((k, e_ours, es))
+        ratios = [table[k][0] / med[k] for k in chaotic]
+        gm = float(np.exp(np.mean(np.log(np.maximum(ratios, 1e-30))))) if ratios else 0.0
+        print(f"{what}: {len(table)} tensors, {len(chaotic)} chaotic; oracle's own spread S = {spread:.2f}; geometric mean of "
+              f"ours / oracle-median over the chaotic ones {gm:.2f}; worst ratio {max(ratios, default=0.0):.2f}")
+        assert not bad, (what, bad[:6])
+        assert gm <= 3.0, (what, gm)
+        return chaotic
+
+    chaotic = judge(table, 2e-3, "gradients")
+    tight = sum(1 for k, (e_ours, _) in table.items() if k not in chaotic and e_ours < 2e-2)
     assert tight >= 12, tight            # the up path and the top levels ARE well-conditioned, and match
+    smax = max(abs(p.grad.item()) for p in p64.values() if p.numel() == 1)
+    for name, p in ours.named_parameters():
+        if p.numel() == 1:               # PReLU slopes: scalars, absolute against the largest slope gradient
+            g, g64 = p.grad.item(), p64[name].grad.item()
+            es = [abs(p32[name].grad.item() - g64)] + [abs(d[0][name].item() - g64) for d in draws]
+            assert abs(g - g64) <= 3 * 5.0 * float(np.median(es)) + 2e-3 * smax, (name, g, g64, es)   # (5: a typical S above)
     # Running statistics (two train-mode forwards).  The reference's all-ones volume leaves near-constant fields
     # on the deep levels (batch variance ~ eps or below), where each BatchNorm amplifies fp32 rounding up to 300x
-    # into the next layer: levels 1-3 are held tightly against the fp32 oracle, the deeper ones by the same
-    # fp64 yardstick as the gradients.
+    # into the next layer: levels 1-3 are held tightly against the fp32 oracle, the deeper ones by the rule above.
     sd, sr, s64 = ours.state_dict(), ref.state_dict(), ref64.state_dict()
-    deep_ratios = []
+    deep = {}
     for k in sr:
         if "running_" not in k:
             continue
@@ -395,10 +431,8 @@ def test_seven_level_generator_of_generator_test_matches_oracle():
             else:
                 assert _rel_l2(sd[k].cpu(), sr[k]) < 1e-4, k
         else:
-            # one draw of amplified rounding noise each (a changed summation order in a statistics kernel moves a
-            # single tensor between 1x and 16x of the oracle's error from build to build): every tensor within two
-            # orders of magnitude of the fp32 oracle's own error, the median tensor within one
-            e_ours, e_32 = _rel_l2(sd[k].cpu(), s64[k]), _rel_l2(sr[k], s64[k])
-            assert e_ours <= 100 * e_32 + 1e-3, (k, e_ours, e_32)
-            deep_ratios.append(e_ours / (e_32 + 1e-4))
-    assert len(deep_ratios) >= 8 and float(np.median(deep_ratios)) <= 10, sorted(deep_ratios)
+            deep[k] = (_rel_l2(sd[k].cpu(), s64[k]), [_rel_l2(sr[k], s64[k])] + [_rel_l2(d[2][k], s64[k]) for d in draws])
+    assert len(deep) >= 8
+    # (none of these is >= 30 % off in the median: the "chaotic" class is empty and the bound is 3 max_draws + 1e-3 --
+    #  the spread of the oracle's draws, 2-10x per tensor, is what the max carries)
+    judge(deep, 1e-3, "deep running statistics")

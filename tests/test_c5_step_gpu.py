@@ -172,18 +172,28 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
         errs[name], cost[name] = _rel(gd[name], want), _rel(want, p.grad)
     print("D gradients, ours vs bf16 emulation:", {k: round(e, 4) for k, e in errs.items()})
     print("bf16 emulation vs fp32 oracle (precision cost):", {k: round(e, 4) for k, e in cost.items()})
-    # (ours vs the emulation is one more draw of the perturbation whose size `cost` measures.  Rounding noise that enters
-    #  at one layer travels through every BatchNorm backward below it, so a tensor's OWN cost can be small by luck while
-    #  its neighbours' is not -- round 4's first run: model_conv.4.weight 0.268 against its own cost 0.118, the layers
-    #  around it at 0.33 / 0.43: the yardstick of a tensor is the larger of its own and the whole network's cost.)
-    conv_keys = [k for k in errs if k.startswith("model_conv")]
-    flat = lambda d: torch.cat([d[k].reshape(-1).double() for k in conv_keys])
-    want_all = {k: 0.5 * (real["grads"][k] + fake["grads"][k]).reshape(dict(rd.named_parameters())[k].shape) for k in conv_keys}
-    cost_net = _rel(flat(want_all), flat({k: dict(rd.named_parameters())[k].grad for k in conv_keys}))
-    print("whole-network precision cost of D's conv-stack gradient:", round(cost_net, 4))
+    # Ours vs the emulation is one more draw of a perturbation that bf16 storage amplifies; `cost` (emulation vs fp32)
+    # measures its size only loosely -- round 4's first run had model_conv.4.weight at 0.268 against its own cost
+    # 0.118 while the layers around it cost 0.33 / 0.43.  The yardstick that measures exactly this: the emulation
+    # against ITSELF on inputs moved by one fp32 ulp (three draws; every difference enters through bf16 rounding
+    # flips, as ours does).  Rule: err(ours, emulation) <= 3 max_draws err(emulation_k, emulation) + 2e-2 per tensor,
+    # where a tensor's draws are floored by the median over the conv stack (noise entering at one layer reaches all
+    # below it); the head, which has no cancellation, stays at 1e-2.
+    def emul_grads(seed):
+        gp = torch.Generator().manual_seed(seed)
+        fr = 1 + torch.randint(-1, 2, t2.shape, generator=gp).float() * 2.0 ** -23
+        ff = 1 + torch.randint(-1, 2, y2.shape, generator=gp).float() * 2.0 ** -23
+        r_, f_ = E.disc_step(rd, t2 * fr, 0.9), E.disc_step(rd, y2 * ff, 0.0)
+        return {k: 0.5 * (r_["grads"][k] + f_["grads"][k]) for k in r_["grads"]}
+    base = {k: 0.5 * (real["grads"][k] + fake["grads"][k]) for k in real["grads"]}
+    draws = [emul_grads(s) for s in (201, 202, 203)]
+    spread = {k: max(_rel(d[k], base[k]) for d in draws) for k in errs}
+    floor = float(torch.tensor([spread[k] for k in errs if k.startswith("model_conv")]).median())
+    print("bf16 emulation vs itself under one-ulp input changes (max of 3 draws):", {k: round(v, 4) for k, v in spread.items()},
+          "median over the conv stack", round(floor, 4))
     for name, e in errs.items():
         tight = name.startswith("model_linear") or name == "model_conv.10.weight"
-        assert e <= (1e-2 if tight else 2 * max(cost[name], cost_net) + 2e-2), (name, e, cost[name], cost_net)
+        assert e <= (1e-2 if tight else 3 * max(spread[name], floor) + 2e-2), (name, e, spread[name], floor, cost[name])
 
     # ---------------- BatchNorm bookkeeping: G saw 2 forwards, D 3 ----------------
     sd_g, sd_d = ours.generator.state_dict(), ours.discriminator.state_dict()

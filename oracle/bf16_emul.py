@@ -20,11 +20,22 @@ def rb(t: torch.Tensor) -> torch.Tensor:
     return t.to(BF).float()
 
 
-def disc_step(disc, x: torch.Tensor, target: float, eps: float = 1e-5, slope: float = 0.2):
+def disc_step(disc, x: torch.Tensor, target: float, eps: float = 1e-5, slope: float = 0.2, acc64: bool = False):
     """disc: an oracle.refmodel.Discriminator (fp32 parameters; BatchNorm running statistics are left alone).
-    Returns dict(validity, loss, grad_x, grads{name: tensor}) of loss = BCE(D(x), target) (mean)."""
+    Returns dict(validity, loss, grad_x, grads{name: tensor}) of loss = BCE(D(x), target) (mean).
+    acc64: every convolution (forward, backward-data, backward-weight) accumulates in fp64 and is rounded to fp32 ONCE
+    -- the same contract with another summation order.  Two correct fp32 implementations differ by their accumulation
+    order (1e-5 .. 1e-4 of a conv output through the cancellation of a 1,700 - 6,900-term sum), which moves a few per
+    cent of the stored elements across a bf16 rounding boundary; BatchNorm's backward amplifies that like any other
+    bf16-sized perturbation.  The distance between the acc64 run and the plain one is the yardstick the step test
+    holds the HIP path to (a one-ulp change of the INPUT is 100 x smaller than that and under-states it)."""
     dims = x.dim() - 2
-    conv = F.conv2d if dims == 2 else F.conv3d
+    conv_ = F.conv2d if dims == 2 else F.conv3d
+    if acc64:
+        def conv(a, w, b, stride):
+            return conv_(a.double(), w.double(), None if b is None else b.double(), stride=stride).float()
+    else:
+        conv = conv_
     convs = [disc.model_conv[i] for i in (0, 3, 6, 9)]
     bns = [disc.model_conv[i] for i in (1, 4, 7, 10)]
     lin = disc.model_linear[1]
@@ -66,10 +77,11 @@ def disc_step(disc, x: torch.Tensor, target: float, eps: float = 1e-5, slope: fl
         grads[f"model_conv.{3 * i + 1}.bias"] = s1
         dz = rb(scale.view(shp) * (gy - (s1 / cnt).view(shp) - zh * (s2 / cnt).view(shp)))
         grads[f"model_conv.{3 * i}.bias"] = dz.sum(red)
-        a_req = a_in.clone().requires_grad_(True)
-        w_req = w.clone().requires_grad_(True)
-        out = conv(a_req, w_req, None, stride=cv.stride)
-        ga, gw = torch.autograd.grad(out, (a_req, w_req), dz)
+        a_req = (a_in.double() if acc64 else a_in).clone().requires_grad_(True)
+        w_req = (w.double() if acc64 else w).clone().requires_grad_(True)
+        out = conv_(a_req, w_req, None, stride=cv.stride)
+        ga, gw = torch.autograd.grad(out, (a_req, w_req), dz.double() if acc64 else dz)
+        ga, gw = ga.float(), gw.float()
         grads[f"model_conv.{3 * i}.weight"] = gw
         g = ga if i == 0 else rb(ga)
     return {"validity": prob, "loss": loss, "grad_x": g, "grads": grads, "zs": [sv[2] for sv in saved]}

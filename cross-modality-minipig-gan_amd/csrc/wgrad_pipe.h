@@ -2,6 +2,7 @@
 // instantiates the fp32-MFMA forms, conv_mm16.hip the forms with bf16 matrix operands (MPGAN_CONV_MM_BF16).
 #pragma once
 #include "mpgan_common.h"
+#include <type_traits>
 
 namespace mpgan {
 
@@ -113,17 +114,42 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
   unsigned dB = (unsigned)(((int)mbeg + drow0) * ldd + dcol) * 4u;
   const unsigned dstepB = (unsigned)(WBK * ldd) * 4u, drowB = (unsigned)(DROWSTEP * ldd) * 4u;
 
+  // The tables are filled for consecutive tiles (mbeg, mbeg + 32, ...), so the entry of row r is carried as a cursor
+  // -- coarse coordinates + byte offset, decoded with divisions ONCE -- and advanced by 32 pixels per fill with
+  // compares and wave-uniform increments (the coarse grid is at least 32 wide: one wrap per dimension at most):
+  // 17 vector instructions per K-step instead of the 38 of three multiply-high divisions.
+  int tx, ty, tz;
+  unsigned toff;
+  {
+    unsigned q, ux, uy, uz;
+    fdivmod((unsigned)((int)mbeg + (tid & 31)), p.fMx, q, ux);
+    fdivmod(q, p.fMy, q, uy);
+    fdivmod(q, p.fMz, q, uz);
+    tx = (int)ux; ty = (int)uy; tz = (int)uz;
+    toff = (unsigned)((((int)q * Gz + tz * p.sz - p.pz) * Gy + ty * p.sy - p.py) * Gx + tx * p.sx - p.px) * (unsigned)ldg * 4u;
+  }
+  const unsigned incX = (unsigned)(WBK * p.sx * ldg) * 4u;
+  const unsigned wrapX = (unsigned)((p.sy * Gx - p.Mx * p.sx) * ldg) * 4u;
+  const unsigned wrapY = (unsigned)((p.sz * Gy * Gx - p.My * p.sy * Gx) * ldg) * 4u;
+  const unsigned wrapZ = (unsigned)((Gz * Gy * Gx - p.Mz * p.sz * Gy * Gx) * ldg) * 4u;
   auto fill_table = [&](int buf, int mt) {
     const int r = tid & 31;          // 8 threads write the same entry with the same value
-    const unsigned m = (unsigned)(mt + r);
-    unsigned q, ux, uy, uz;
-    fdivmod_nb(m, p.fMx, q, ux);
-    fdivmod_nb(q, p.fMy, q, uy);
-    fdivmod_nb(q, p.fMz, q, uz);
-    const int iz0 = (int)uz * p.sz - p.pz, iy0 = (int)uy * p.sy - p.py, ix0 = (int)ux * p.sx - p.px;
-    const bool valid = (int)m < imend;
+    const int iz0 = tz * p.sz - p.pz, iy0 = ty * p.sy - p.py, ix0 = tx * p.sx - p.px;
+    const bool valid = mt + r < imend;
     int4 e;
-    e.x = (int)((unsigned)((((int)q * Gz + iz0) * Gy + iy0) * Gx + ix0) * (unsigned)ldg * 4u);
+    e.x = (int)toff;
+    {                                // advance the cursor to the next tile
+      tx += WBK;
+      const bool cx = tx >= p.Mx;
+      tx -= cx ? p.Mx : 0;
+      ty += cx ? 1 : 0;
+      const bool cy = ty >= p.My;
+      ty = cy ? 0 : ty;
+      tz += cy ? 1 : 0;
+      const bool cz = tz >= p.Mz;
+      tz = cz ? 0 : tz;
+      toff += incX + (cx ? wrapX : 0u) + (cy ? wrapY : 0u) + (cz ? wrapZ : 0u);
+    }
     if constexpr (PAD) {
       e.y = valid ? iz0 : -(1 << 28);
       e.z = iy0;
@@ -172,14 +198,22 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
     mrow += WBK;
   };
 
-  auto store_tile = [&](int buf, const Stage& S) {
+  // FULL: the tile is known to lie wholly inside the block's pixel range (every K-step but the last two of a chunk):
+  // the zero selects of both operands (32 v_cndmask + the mask bits of a K-step's 217 vector instructions, ISA count
+  // of round 3's <128,128,..,3,false>) are dropped.  What they guarded is harmless there: a channel / column past
+  // the operand's extent was LOADED from offset 0 (finite data) and only feeds result rows / columns the epilogue
+  // discards; pad-free convs have no padding zeros to form.  Padded convs (PAD) keep the gathered operand's select.
+  auto store_tile = [&](int buf, const Stage& S, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
     float* Ds = lds + buf * STAGE;
     float* Gs = Ds + WBK * BD;
 #pragma unroll
     for (int i = 0; i < DLOADS; ++i) {
       float4 v = S.rd[i];
-      const bool ok = (S.dmask >> i) & 1u;       // rows past the chunk / channels past Cd
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if constexpr (!FULL) {
+        const bool ok = (S.dmask >> i) & 1u;     // rows past the chunk / channels past Cd
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      }
       bacc.x += v.x; bacc.y += v.y; bacc.z += v.z; bacc.w += v.w;
       *reinterpret_cast<float4*>(Ds + (drow0 + DROWSTEP * i) * BD + dcc * 4) = v;
     }
@@ -196,11 +230,15 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
         v.z = act_apply(v.z * psc.z + psh.z, act, slope);
         v.w = act_apply(v.w * psc.w + psh.w, act, slope);
       }
-      const bool ok = (S.gmask >> i) & 1u;
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if constexpr (!FULL || PAD) {
+        const bool ok = (S.gmask >> i) & 1u;
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      }
       *reinterpret_cast<float4*>(Gs + (grow0 + GROWSTEP * i) * BG + gcc * 4) = v;
     }
   };
+  constexpr std::integral_constant<bool, true> FULL_TILE{};
+  constexpr std::integral_constant<bool, false> EDGE_TILE{};
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -216,7 +254,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
     fill_table(1, (int)mbeg + WBK);
     __syncthreads();
     issue_loads(SX, 0);
-    store_tile(0, SX);
+    store_tile(0, SX, EDGE_TILE);
     issue_loads(SX, 1);
     __syncthreads();                  // table 0 has been read by everyone
     fill_table(0, (int)mbeg + 2 * WBK);
@@ -225,7 +263,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
 
   // K-step kt (LDS buffer cb = kt & 1): loads tile kt+2 through table[cb], writes the table of
   // tile kt+3 into table[cb ^ 1] (last read one barrier ago).
-  auto step = [&](int cb, Stage& Sn, const Stage& Sp) {
+  auto step = [&](int cb, Stage& Sn, const Stage& Sp, auto full_tag) {
     const float* Ds = lds + cb * STAGE + wm * TM * 32 + li;
     const float* Gs = lds + cb * STAGE + WBK * BD + wn * TN * 32 + li;
     if constexpr (MM16) {
@@ -250,7 +288,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][tm], fb[0][tn], acc[tm][tn], 0, 0, 0);
-      store_tile(cb ^ 1, Sp);
+      store_tile(cb ^ 1, Sp, full_tag);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -277,7 +315,7 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
       if (g < 3) read_group(g + 1, sl ^ 1);
       if (g == 0) issue_loads(Sn, cb);
       if (g == 1) { fill_table(cb ^ 1, mtab); mtab += WBK; }
-      if (g == 3) store_tile(cb ^ 1, Sp);
+      if (g == 3) store_tile(cb ^ 1, Sp, full_tag);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -314,11 +352,20 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
     }
   };
 
-  for (int kt = 0; kt < nk; kt += 2) {
-    step(0, SY, SX);
+  // K-step kt stores tile kt + 1: tiles 1 .. nk - 2 lie wholly inside the chunk (only the last tile can be ragged,
+  // and the one behind it is stored as zeros nobody reads), so steps 0 .. nk - 3 store without selects
+  int kt = 0;
+  for (; kt + 3 < nk; kt += 2) {
+    step(0, SY, SX, FULL_TILE);
+    __syncthreads();
+    step(1, SX, SY, FULL_TILE);
+    __syncthreads();
+  }
+  for (; kt < nk; kt += 2) {
+    step(0, SY, SX, EDGE_TILE);
     __syncthreads();
     if (kt + 1 < nk) {
-      step(1, SX, SY);
+      step(1, SX, SY, EDGE_TILE);
       __syncthreads();
     }
   }

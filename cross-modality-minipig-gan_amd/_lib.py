@@ -112,6 +112,7 @@ SIGNATURES = {
     "mpgan_conv_forward_bf16": (_I, [_G, _P, _I, _P, _P, _P, _P, _I, _P]),
     "mpgan_conv_backward_data_bf16": (_I, [_G, _P, _I, _P, _P, _I, _P]),
     "mpgan_conv_wgrad_workspace_bf16": (_L, [_G]),
+    "mpgan_conv_wgrad_variant_bf16": (_I, [_G]),
     "mpgan_conv_backward_weight_bf16": (_I, [_G, _P, _I, _P, _I, _P, _F, _P, _L, _P]),
     "mpgan_conv_forward_f32_to_bf16": (_I, [_G, _P, _I, _P, _P, _P, _P, _I, _P]),
     "mpgan_conv_backward_data_bf16_to_f32": (_I, [_G, _P, _I, _P, _P, _I, _P]),

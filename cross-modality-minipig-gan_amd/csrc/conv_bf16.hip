@@ -415,7 +415,7 @@ static int hb_launch(const GatherConv& p, long maxM, hipStream_t st) {
   }
   static int dbg_set = -1;
   if (dbg_set < 0) {
-    const char* e = getenv("MPGAN_DBG_HB");
+    const char* e = dev_env("MPGAN_DBG_HB");
     dbg_set = e ? atoi(e) : 0;
     if (dbg_set) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hb_dbg), &dbg_set, sizeof(int));
   }
@@ -831,7 +831,7 @@ static bool hw_pairs_congruent(const GatherConv& p) {
 static int hw_choice(const GatherConv& p, bool with_stats) {
   static int forced = -2;
   if (forced == -2) {
-    const char* e = getenv("MPGAN_DBG_HB_WIDE");
+    const char* e = dev_env("MPGAN_DBG_HB_WIDE");
     forced = e ? atoi(e) : -1;
   }
   if (forced == 0) return 0;
@@ -871,7 +871,7 @@ static int hw_launch(const GatherConv& p, long maxM, hipStream_t st) {
   }
   static int dbg_set = -1;
   if (dbg_set < 0) {
-    const char* e = getenv("MPGAN_DBG_HB");
+    const char* e = dev_env("MPGAN_DBG_HB");
     dbg_set = e ? atoi(e) : 0;
     if (dbg_set) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hb_dbg), &dbg_set, sizeof(int));
   }
@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
 }
 
 static bool hp_ok(const GatherConv& p) {
-  static const bool off = getenv("MPGAN_DBG_NO_HB_PATCH") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_HB_PATCH") != nullptr;
   if (off || p.nphase != 1) return false;
   const Phase& ph = p.ph[0];
   if (!(ph.nz == 3 && ph.ny == 3 && ph.nx == 3 && p.Kz == 3 && p.Ky == 3 && p.Kx == 3)) return false;
@@ -1186,7 +1186,7 @@ static int hp_launch(const GatherConv& p, hipStream_t st) {
   }
   static int dbg_set = -1;
   if (dbg_set < 0) {
-    const char* e = getenv("MPGAN_DBG_HB");
+    const char* e = dev_env("MPGAN_DBG_HB");
     dbg_set = e ? atoi(e) : 0;
     if (dbg_set) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hb_dbg), &dbg_set, sizeof(int));
   }
@@ -1219,13 +1219,13 @@ static int hb_dispatch(const GatherConv& p, hipStream_t st, const char* what) {
                       "(operand beyond the 32-bit offset range of the wide form): pass a compact tensor", what);
   }
   if (wide == 3) return mask ? hw_launch<2, 4, true, true, true>(p, maxM, st) : hw_launch<2, 4, false, true, true>(p, maxM, st);
-  static const bool no_ring = getenv("MPGAN_DBG_HB_NO_RING") != nullptr;     // development: two whole stages instead
+  static const bool no_ring = dev_env("MPGAN_DBG_HB_NO_RING") != nullptr;     // development: two whole stages instead
   if (wide == 1 && no_ring) return mask ? hw_launch<2, 4, true, false>(p, maxM, st) : hw_launch<2, 4, false, false>(p, maxM, st);
   if (wide == 1) return mask ? hw_launch<2, 4, true>(p, maxM, st) : hw_launch<2, 4, false>(p, maxM, st);
   if (wide == 2) return mask ? hw_launch<4, 2, true>(p, maxM, st) : hw_launch<4, 2, false>(p, maxM, st);
   static int nw = 0;
   if (!nw) {
-    const char* e = getenv("MPGAN_DBG_HB_NW");      // development: force four or eight waves per block
+    const char* e = dev_env("MPGAN_DBG_HB_NW");      // development: force four or eight waves per block
     nw = e ? atoi(e) : 8;
   }
   if (nw == 4) {
@@ -1676,7 +1676,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_wide_kernel(const WgradHb p
 struct WgradHbPlan { int nsplit, tiles_c, tiles_d, wide; long chunk; };
 static WgradHbPlan plan_wgrad_hb(int Cd, int NC, long M) {
   WgradHbPlan pl;
-  static const bool no_wide = getenv("MPGAN_DBG_HB_WIDE") && atoi(getenv("MPGAN_DBG_HB_WIDE")) == 0;
+  static const bool no_wide = dev_env("MPGAN_DBG_HB_WIDE") && atoi(dev_env("MPGAN_DBG_HB_WIDE")) == 0;
   pl.wide = (Cd > WH_BD && !no_wide) ? 1 : 0;             // 256 x 256 tiles (wgrad_bf16_wide_kernel)
   pl.tiles_c = (NC + WH_BG - 1) / WH_BG;
   pl.tiles_d = (Cd + (pl.wide ? WW_B : WH_BD) - 1) / (pl.wide ? WW_B : WH_BD);
@@ -1811,7 +1811,7 @@ __global__ __launch_bounds__(256, 2) void thin_cout1_mfma_bf16_kernel(const Gath
 
 // Serves this launch?  (64 bf16 channels -> one fp32 channel, stride 1, one phase, at most 3 taps per dimension.)
 bool thin_cout1_mfma_bf16_ok(const GatherConv& p) {
-  static const bool off = getenv("MPGAN_DBG_NO_TC_MFMA") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_TC_MFMA") != nullptr;
   if (off || !p.in_bf16 || p.Cout != 1 || p.Cin != 64 || p.nphase != 1 || p.bias || p.resid || p.tanh_out || p.stats ||
       p.pro.scale || p.ldi % 8 != 0 || (reinterpret_cast<uintptr_t>(p.in) & 15))
     return false;
@@ -2098,6 +2098,16 @@ static void wgrad_hb_dims(const mpgan_conv_geom* g, int& Cd, int& Cg, int& T, lo
   M = (long)g->n * g->out_dhw[0] * g->out_dhw[1] * g->out_dhw[2];
 }
 
+// Which kernel serves this layer's bf16 weight gradient (profiling labels): 0 = wgrad_bf16_kernel (128 x 256 tiles),
+// 1 = wgrad_bf16_wide_kernel (256 x 256).
+extern "C" int32_t mpgan_conv_wgrad_variant_bf16(const mpgan_conv_geom* g) {
+  if (!g) return -1;
+  int Cd, Cg, T;
+  long M;
+  wgrad_hb_dims(g, Cd, Cg, T, M);
+  return plan_wgrad_hb(Cd, T * Cg, M).wide;
+}
+
 extern "C" int64_t mpgan_conv_wgrad_workspace_bf16(const mpgan_conv_geom* g) {
   if (!g) return -1;
   int Cd, Cg, T;
@@ -2141,7 +2151,7 @@ extern "C" int mpgan_conv_backward_weight_bf16(const mpgan_conv_geom* g, const v
   p.fMx = make_fastdiv(p.Mx); p.fMy = make_fastdiv(p.My); p.fMz = make_fastdiv(p.Mz);
   static int nw = 0;
   if (!nw) {
-    const char* e = getenv("MPGAN_DBG_HB_NW");      // development: force four or eight waves per block
+    const char* e = dev_env("MPGAN_DBG_HB_NW");      // development: force four or eight waves per block
     nw = (e && atoi(e) == 4) ? 4 : 8;
     hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<4>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, WH_SMEM);

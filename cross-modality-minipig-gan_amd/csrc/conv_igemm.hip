@@ -982,7 +982,7 @@ __global__ __launch_bounds__(256) void convt_oct_cout1_kernel(const GatherConv p
 }
 
 static bool convt_oct_ok(const GatherConv& p) {
-  static const bool off = getenv("MPGAN_DBG_NO_CONVT_OCT") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_CONVT_OCT") != nullptr;
   const int lanes = p.Cin / 4;
   if (off || !(p.Cout == 1 && !p.pro.scale && !p.stats && !p.stats_acc && p.Cin % 4 == 0 && p.ldi % 4 == 0 &&
                (lanes == 4 || lanes == 8 || lanes == 16) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0)))
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(256) void thin_c1c1_rows4_kernel(const GatherConv p
 }
 
 static bool thin_c1c1_ok(const GatherConv& p) {
-  static const bool off = getenv("MPGAN_DBG_NO_THIN_ROWS") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_THIN_ROWS") != nullptr;
   if (off || !(p.Cin == 1 && p.Cout == 1 && p.ldi == 1 && p.ldo == 1 && (!p.resid || p.ldr == 1) && p.nphase == 1 &&
                !p.pro.scale && !p.stats && !p.stats_acc && !p.in_bf16 && !p.out_bf16 && p.Ky == 3 && p.Kx == 3 &&
                (p.Kz == 3 || p.Kz == 1)))
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256) void thin_cin1_rows_kernel(const GatherConv p)
 }
 
 static bool thin_cin1_rows_ok(const GatherConv& p) {
-  static const bool off = getenv("MPGAN_DBG_NO_THIN_ROWS") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_THIN_ROWS") != nullptr;
   const int T = p.Kz * p.Ky * p.Kx;
   const Phase& ph = p.ph[0];
   return !off && p.Cin == 1 && p.Cout == 64 && p.ldi == 1 && p.nphase == 1 && !p.pro.scale && !p.resid && !p.tanh_out &&
@@ -2075,7 +2075,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
 
 // Geometry test for the patch kernel (pointer alignment is checked at launch).
 static bool patch_plan(const GatherConv& p, PatchLaunch* out, int* smem_bytes) {
-  static const bool off = getenv("MPGAN_DBG_NO_PATCH") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_PATCH") != nullptr;
   if (off) return false;
   if (p.Di != 1 || p.Do != 1 || p.Kz != 1) return false;
   if (!(p.Cin == 16 || p.Cin == 32 || p.Cin == 64)) return false;
@@ -2106,7 +2106,7 @@ static bool patch_plan(const GatherConv& p, PatchLaunch* out, int* smem_bytes) {
   const long bytes = ((long)patch_floats + (long)maxtaps * p.Cout * PC) * 4;
   if (bytes > 96 * 1024) return false;
   // merged form: one block per tile walks every phase (see MERGE on the kernel)
-  static const bool no_merge = getenv("MPGAN_DBG_NO_MERGE") != nullptr;
+  static const bool no_merge = dev_env("MPGAN_DBG_NO_MERGE") != nullptr;
   bool merged = p.nphase > 1 && !p.pro.scale && !no_merge;
   int ylo = 1 << 20, yhi = -(1 << 20), xlo = 1 << 20, xhi = -(1 << 20);
   long mbytes = 0;
@@ -2214,7 +2214,7 @@ static int launch_patch_persist_cin(const GatherConv& p, const PatchLaunch& pl, 
 // that does not fit one register round, LDS).
 static bool patch_persist_plan(const GatherConv& p, const PatchLaunch& pl, PatchLaunch* out, int* smem, int* ntiles,
                                int* grid) {
-  static const bool off = getenv("MPGAN_DBG_NO_PERSIST") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_PERSIST") != nullptr;
   if (off) return false;
   if (p.nphase != 1 && !pl.merged) return false;
   const int PC = p.Cin + 4, CQ = p.Cin / 4;
@@ -2245,9 +2245,9 @@ static bool patch_persist_plan(const GatherConv& p, const PatchLaunch& pl, Patch
   {
     out->fTx = make_fastdiv((unsigned)pl.tiles_x);
     out->fTy = make_fastdiv((unsigned)pl.tiles_y);
-    static const int dbg_skip = getenv("MPGAN_DBG_PATCH_SKIP") ? atoi(getenv("MPGAN_DBG_PATCH_SKIP")) : 0;
+    static const int dbg_skip = dev_env("MPGAN_DBG_PATCH_SKIP") ? atoi(dev_env("MPGAN_DBG_PATCH_SKIP")) : 0;
     out->dbg = dbg_skip;
-    static const int stag = getenv("MPGAN_DBG_PATCH_STAGGER") ? atoi(getenv("MPGAN_DBG_PATCH_STAGGER")) : 0;
+    static const int stag = dev_env("MPGAN_DBG_PATCH_STAGGER") ? atoi(dev_env("MPGAN_DBG_PATCH_STAGGER")) : 0;
     out->stagger = stag;
     static void* zp = nullptr;          // address of the device-side zero page, looked up once
     if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_patch_zero_page)) != hipSuccess) { zp = nullptr; return false; }
@@ -2267,7 +2267,7 @@ static bool patch_persist_plan(const GatherConv& p, const PatchLaunch& pl, Patch
   if (bytes > 150 * 1024) return false;
   *smem = (int)bytes;
   *ntiles = pl.tiles_x * pl.tiles_y * p.N;
-  static const int bpc_env = getenv("MPGAN_DBG_PATCH_BPC") ? atoi(getenv("MPGAN_DBG_PATCH_BPC")) : 0;
+  static const int bpc_env = dev_env("MPGAN_DBG_PATCH_BPC") ? atoi(dev_env("MPGAN_DBG_PATCH_BPC")) : 0;
   int bpc = (int)((160L * 1024) / bytes);
   if (bpc > 3) bpc = 3;
   if (bpc < 1) bpc = 1;
@@ -2304,7 +2304,7 @@ static int launch_patch(const GatherConv& p, const PatchLaunch& pl, int smem, hi
 template <int BN, int TM, int TN, int WN, bool SCALAR>
 static int launch_variant(const GatherConv& p, long maxM, hipStream_t st) {
   auto kern = gather_conv_kernel<BN, TM, TN, WN, SCALAR>;
-  static const int lds_pad = getenv("MPGAN_DBG_LDS_PAD") ? atoi(getenv("MPGAN_DBG_LDS_PAD")) : 0;
+  static const int lds_pad = dev_env("MPGAN_DBG_LDS_PAD") ? atoi(dev_env("MPGAN_DBG_LDS_PAD")) : 0;
   const int smem = 2 * (BM + BN) * PITCH * (int)sizeof(float) + lds_pad;
   static bool attr_set = false;
   if (!attr_set) {
@@ -2339,7 +2339,7 @@ static int select_variant(const GatherConv& p, long maxM, bool thin1, bool thin2
   // matrix pipe ~85 % fed from ONE resident block, while narrow tiles (16 MFMAs per K-step
   // and wave) cannot cover their own load/store/barrier overhead.
   const long mtiles = (maxM + BM - 1) / BM * p.nphase;
-  static const int force_bn = getenv("MPGAN_DBG_BN") ? atoi(getenv("MPGAN_DBG_BN")) : 0;   // experiments
+  static const int force_bn = dev_env("MPGAN_DBG_BN") ? atoi(dev_env("MPGAN_DBG_BN")) : 0;   // experiments
   if (force_bn == 32 || force_bn == 64 || force_bn == 128) return force_bn;
   int bn = 32;
   if (p.Cout > 64 && mtiles * ((p.Cout + 127) / 128) >= 256) bn = 128;
@@ -2351,7 +2351,7 @@ static int select_variant(const GatherConv& p, long maxM, bool thin1, bool thin2
 template <int BN, int TM, int TN, int WN, int WRAPS, int PRO, bool FAST = false, int KS = 1>
 static int launch_pipe_variant(const GatherConv& p, long maxM, hipStream_t st) {
   auto kern = gather_conv_pipe_kernel<BN, TM, TN, WN, WRAPS, PRO, FAST, KS>;
-  static const int lds_pad = getenv("MPGAN_DBG_LDS_PAD") ? atoi(getenv("MPGAN_DBG_LDS_PAD")) : 0;
+  static const int lds_pad = dev_env("MPGAN_DBG_LDS_PAD") ? atoi(dev_env("MPGAN_DBG_LDS_PAD")) : 0;
   const int smem = KS * 2 * (BM + BN) * PITCH * (int)sizeof(float) + lds_pad;
   static bool attr_set = false;
   if (!attr_set) {
@@ -2375,7 +2375,7 @@ static int launch_pipe_variant(const GatherConv& p, long maxM, hipStream_t st) {
 
 // every tap of every pixel in range and no partial channel tile: see FAST on gather_conv_pipe_kernel
 static bool fast_geometry(const GatherConv& p, int bn) {
-  static const bool off = getenv("MPGAN_DBG_NO_FAST") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_FAST") != nullptr;
   if (off || p.nphase != 1 || p.Cout % bn != 0 || p.Cin % 32 != 0 || p.ksplit > 1) return false;
   const Phase& ph = p.ph[0];
   if (ph.nz * ph.ny * ph.nx == 0) return false;
@@ -2392,7 +2392,7 @@ static bool fast_geometry(const GatherConv& p, int bn) {
 // In-block split-K (KS = 2 of gather_conv_pipe_kernel): when the output grid gives at most ~1.5 blocks per CU and
 // every K group still gets >= 4 K-steps.
 static bool pipe_wants_ksplit2(const GatherConv& p, int bn, long maxM) {
-  static const bool off = getenv("MPGAN_DBG_NO_KS2") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_KS2") != nullptr;
   if (off || p.ksplit > 1 || p.Cin % 32 != 0) return false;
   const long blocks = (maxM + BM - 1) / BM * ((p.Cout + bn - 1) / bn) * p.nphase;
   if (blocks > 384) return false;
@@ -2408,7 +2408,7 @@ static bool pipe_wants_ksplit2(const GatherConv& p, int bn, long maxM) {
 // several times over: the discriminator's backward-data launches.  MPGAN_DBG_NO_DMA=1 turns it off (A/B runs);
 // the threshold is the geometry's own `min_blocks` (tests pass 1 to run small shapes through it).
 static bool dma_form_ok(const GatherConv& p, int variant, long maxM) {
-  static const bool off = getenv("MPGAN_DBG_NO_DMA") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_DMA") != nullptr;
   if (off || p.pro.scale || p.ksplit > 1 || p.Cin % 32 != 0 || (variant != 128 && variant != 64 && variant != 32)) return false;
   if (p.stats_acc || p.fold.acc) return false;
   const long blocks = (maxM + BM - 1) / BM * ((p.Cout + variant - 1) / variant) * p.nphase;
@@ -2732,7 +2732,7 @@ __global__ __launch_bounds__(256, 2) void gather_patch3d_c16_kernel(const Gather
 // Geometry / launch-mode half of the 3-D patch kernel's predicate: what mpgan_conv_variant and
 // mpgan_conv_stats_rows can decide from the conv alone (the caller sizes its partial rows from it).
 static bool patch3d_geom_ok(const GatherConv& p) {
-  static const bool off = getenv("MPGAN_DBG_NO_PATCH3D") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_PATCH3D") != nullptr;
   if (off || !(p.Cin == 16 && p.Cout == 16 && p.nphase == 1 && p.Kz == 3 && p.Ky == 3 && p.Kx == 3 &&
                !p.tanh_out && !p.fold.acc && !p.stats_acc && !p.bwd.part && !p.in_bf16 && !p.out_bf16 && p.ksplit <= 1 &&
                p.pro.n_stride == 0))
@@ -2779,7 +2779,7 @@ static int launch_patch3d(const GatherConv& p, hipStream_t st) {
   const P3Grid tg = patch3d_grid(p);
   const long ntiles = (long)p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x;
   dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512));          // two resident blocks per CU, each walking its range of tiles
-  static const bool no_mm16 = getenv("MPGAN_DBG_NO_MM16") != nullptr;
+  static const bool no_mm16 = dev_env("MPGAN_DBG_NO_MM16") != nullptr;
   if (p.mm16 && !no_mm16) {
     if (p.pro.scale) hipLaunchKernelGGL((gather_patch3d_c16_kernel<true, true>), grid, dim3(256), P3M_SMEM, st, p, tg);
     else hipLaunchKernelGGL((gather_patch3d_c16_kernel<false, true>), grid, dim3(256), P3M_SMEM, st, p, tg);
@@ -2847,7 +2847,7 @@ static int launch_gather(const GatherConv& p, hipStream_t st) {
                    (!p.pro.scale || (((reinterpret_cast<uintptr_t>(p.pro.scale) |
                                        reinterpret_cast<uintptr_t>(p.pro.shift)) & 15) == 0 &&
                                      p.pro.n_stride % 4 == 0));
-  static const bool no_pipe = getenv("MPGAN_DBG_NO_PIPE") != nullptr;
+  static const bool no_pipe = dev_env("MPGAN_DBG_NO_PIPE") != nullptr;
   // the pipelined kernel addresses each operand as base + unsigned 32-bit byte offset
   const bool small = (long)p.N * p.Di * p.Hi * p.Wi * p.ldi * 4 < (1L << 32) &&
                      (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 4 < (1L << 32) &&

@@ -55,7 +55,7 @@ static int launch_mm16_bn(const GatherConv& p, int variant, bool ksplit2, long m
 // What the MM16 instances cover: 16-byte vector operands (the caller checked), Cin a multiple of 32 or exactly 16,
 // no prologue or a per-channel one (BatchNorm; InstanceNorm's per-sample vectors stay on the fp32 kernels).
 bool mm16_gather_ok(const GatherConv& p) {
-  static const bool off = getenv("MPGAN_DBG_NO_MM16") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_MM16") != nullptr;
   return !off && (p.Cin % 32 == 0 || p.Cin == 16) && (!p.pro.scale || p.pro.n_stride == 0) && !p.fold.acc &&
          !p.stats_acc && p.ksplit <= 1 && !p.in_bf16 && !p.out_bf16;
 }
@@ -105,7 +105,7 @@ static int dispatch_wgrad_mm16(const WgradParams& p, int BD, int BG, hipStream_t
 // The pipelined weight gradient with bf16 matrix operands; `handled` = false: this tile shape has no such instance
 // (the caller runs the fp32 kernel).  Same tiles, splits and slabs as the fp32 form: the reducer is unchanged.
 int launch_wgrad_mm16(const WgradParams& p, int BD, int BG, hipStream_t st, bool& handled) {
-  static const bool off = getenv("MPGAN_DBG_NO_MM16") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_MM16") != nullptr;
   handled = false;
   if (off) return MPGAN_OK;
   return p.pro.scale ? dispatch_wgrad_mm16<1>(p, BD, BG, st, handled) : dispatch_wgrad_mm16<0>(p, BD, BG, st, handled);

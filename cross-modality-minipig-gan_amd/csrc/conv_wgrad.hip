@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_rows_kernel(const WgradParams 
 }
 
 static bool thin_rows_ok(const WgradParams& p, int T) {
-  static const bool off = getenv("MPGAN_DBG_NO_THIN_ROWS") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_THIN_ROWS") != nullptr;
   return !off && p.Cd == 64 && p.Cg == 1 && p.ldg == 1 && !p.pro.scale && (T == 9 || T == 27) && p.Kx == 3 && p.Ky == 3 &&
          p.Kz == (T == 27 ? 3 : 1) && p.sz == 1 && p.sy == 1 && p.sx == 1 && p.pz == 0 && p.py == 0 && p.px == 0 && p.Mx >= 4 &&
          p.Gx == p.Mx + 2 && p.Gy == p.My + 2 && p.Gz == p.Mz + (T == 27 ? 2 : 0);
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch3d_c16_kernel(const WgradPa
 }
 
 static bool wgrad_p3_geom_ok(const mpgan_conv_geom* g) {
-  static const bool off = getenv("MPGAN_DBG_NO_PATCH3D") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_PATCH3D") != nullptr;
   if (off || g->transposed || g->cin != 16 || g->cout != 16) return false;
   for (int d = 0; d < 3; ++d)
     if (g->k[d] != 3 || g->stride[d] != 1 || g->pad[d] < 0 || g->pad[d] > 1) return false;
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch2d_kernel(const WgradParams
 struct WP2Plan { int inst, blocks, tiles_y, tiles_x, ntiles, Cd, Cg; };
 static WP2Plan wgrad_p2_plan(const mpgan_conv_geom* g) {
   WP2Plan pl{};
-  static const bool off = getenv("MPGAN_DBG_NO_WPATCH2D") != nullptr;
+  static const bool off = dev_env("MPGAN_DBG_NO_WPATCH2D") != nullptr;
   if (off || g->k[0] != 1 || g->k[1] != 3 || g->k[2] != 3 || g->in_dhw[0] != 1 || g->out_dhw[0] != 1) return pl;
   if (g->pad[1] != 1 || g->pad[2] != 1 || g->stride[1] != g->stride[2] || g->stride[1] < 1 || g->stride[1] > 2) return pl;
   const int S = g->stride[1];
@@ -996,7 +996,7 @@ static WP2Plan wgrad_p2_plan(const mpgan_conv_geom* g) {
   else if (S == 1 && Cd == 32 && Cg == 32) { inst = 2; cap = 128; }
   else if (S == 2 && Cd == 32 && Cg == 16) { inst = 3; cap = 256; }
   else if (S == 2 && Cd == 64 && Cg == 16) { inst = 5; tx = 8; cap = 128; }
-  static const int cap_env = getenv("MPGAN_DBG_WPATCH2D_BLOCKS") ? atoi(getenv("MPGAN_DBG_WPATCH2D_BLOCKS")) : 0;
+  static const int cap_env = dev_env("MPGAN_DBG_WPATCH2D_BLOCKS") ? atoi(dev_env("MPGAN_DBG_WPATCH2D_BLOCKS")) : 0;
   if (cap_env > 0) cap = cap_env;
   if (!inst || My < 4 || Mx < 4) return pl;
   pl.tiles_y = (My + WP2_TY - 1) / WP2_TY;
@@ -1260,7 +1260,7 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
                     "conv_backward_weight: workspace too small for the 3-D patch form");
     p.bias_partial = dbias ? p.partial + pslab : nullptr;
     const WP3Grid tg{(p.Mz + WP3_TZ - 1) / WP3_TZ, (p.My + WP3_TY - 1) / WP3_TY, (p.Mx + WP3_TX - 1) / WP3_TX};
-    static const bool no_mm16 = getenv("MPGAN_DBG_NO_MM16") != nullptr;
+    static const bool no_mm16 = dev_env("MPGAN_DBG_NO_MM16") != nullptr;
     if ((g->flags & MPGAN_CONV_MM_BF16) && !no_mm16) {
       if (p.pro.scale) hipLaunchKernelGGL((wgrad_patch3d_c16_kernel<true, true>), dim3(nb), dim3(256), 0, st0, p, tg);
       else hipLaunchKernelGGL((wgrad_patch3d_c16_kernel<false, true>), dim3(nb), dim3(256), 0, st0, p, tg);
@@ -1295,7 +1295,7 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
   {
     ThinWgradPlan tp = plan_thin_wgrad(Cd, Cg, T, M, p.pro.scale != nullptr);
     const bool v4 = (p.Cd % 4 == 0) && (p.ldd % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.dense) & 15) == 0);
-    static const bool no_thin = getenv("MPGAN_DBG_NO_THIN") != nullptr;
+    static const bool no_thin = dev_env("MPGAN_DBG_NO_THIN") != nullptr;
     const bool kshape = (T == 1) || (T == 9 && p.Kz == 1 && p.Ky == 3 && p.Kx == 3) ||
                         (T == 27 && p.Kz == 3 && p.Ky == 3 && p.Kx == 3);
     if (tp.ok && kshape && !no_thin) {
@@ -1332,7 +1332,7 @@ extern "C" int mpgan_conv_backward_weight(const mpgan_conv_geom* g, const float*
   hipStream_t st = (hipStream_t)stream;
   int rc = MPGAN_OK;
   bool handled = false;
-  static const bool no_pipe = getenv("MPGAN_DBG_NO_PIPE") != nullptr;
+  static const bool no_pipe = dev_env("MPGAN_DBG_NO_PIPE") != nullptr;
   // the pipelined kernel addresses each operand as base + unsigned 32-bit byte offset
   const bool small = (long)M * p.ldd * 4 < (1L << 32) && (long)p.N * p.Gz * p.Gy * p.Gx * p.ldg * 4 < (1L << 32);
   if ((g->flags & MPGAN_CONV_MM_BF16) && vd && vg && pl.kw == 1 && small && p.pro.n_stride == 0)

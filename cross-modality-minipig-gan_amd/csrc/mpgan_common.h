@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include "mpgan_hip.h"
 
 // ---- host dry-run build (development only: `make DRYRUN=1` -> libmpgan_hip_dry.so) -----------------------------
@@ -48,6 +49,15 @@ inline hipError_t dry_symbol_address(void** p) {
 namespace mpgan {
 
 void set_error(const char* fmt, ...);
+
+// Development switches (MPGAN_DBG_* and friends: A/B runs, what-if builds, forced kernel forms) exist only in the
+// development build (`make DEV=1` -> libmpgan_hip_dev.so, loaded through MPGAN_LIB_PATH): the product library reads
+// no environment variable at all -- its dispatch depends on the arguments of a call and on nothing else.
+#ifdef MPGAN_DEV_SWITCHES
+inline const char* dev_env(const char* name) { return getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#endif
 
 #define MPGAN_CHECK_ARG(cond, ...)                         \
   do {                                                     \

@@ -1406,10 +1406,9 @@ def _bf16_kernel_name(g: ConvGeom, backward_data: bool) -> str:
 
 
 def _bf16_wgrad_kernel_name(g: ConvGeom) -> str:
-    """rocprofv3's name of the bf16 weight-gradient kernel of this layer (csrc/conv_bf16.hip: plan_wgrad_hb -- layers with
-    more than 128 dense channels run on 256 x 256 tiles)."""
-    wide = g.cout > 128 and os.environ.get("MPGAN_DBG_HB_WIDE", "") != "0"
-    return "wgrad_bf16_wide_kernel" if wide else "wgrad_bf16_kernel<8>"
+    """rocprofv3's name of the bf16 weight-gradient kernel of this layer, asked of the library that makes the choice."""
+    gc = g.c()
+    return "wgrad_bf16_wide_kernel" if lib().mpgan_conv_wgrad_variant_bf16(C.byref(gc)) == 1 else "wgrad_bf16_kernel<8>"
 
 
 class DiscPlanBF16:

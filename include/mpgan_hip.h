@@ -453,6 +453,8 @@ int32_t mpgan_conv_variant_bf16(const mpgan_conv_geom* g, int32_t backward_data)
 /* dx (bf16) = conv_backward_data(dy (bf16)); w_packed_bwd: bf16, layout 1 of mpgan_pack_weights_bf16. */
 int mpgan_conv_backward_data_bf16(const mpgan_conv_geom* g, const void* dy, int32_t lddy, const void* w_packed_bwd,
                                   void* dx, int32_t lddx, void* stream);
+/* kernel label of the bf16 weight gradient of this layer: 0 = 128 x 256 tiles, 1 = 256 x 256 (profiling only) */
+int32_t mpgan_conv_wgrad_variant_bf16(const mpgan_conv_geom* g);
 /* dW (fp32, torch layout) = beta*dW + sum over pixels of dy (bf16) x gathered x (bf16): pad-free ConvNd. */
 int64_t mpgan_conv_wgrad_workspace_bf16(const mpgan_conv_geom* g);
 int mpgan_conv_backward_weight_bf16(const mpgan_conv_geom* g, const void* x, int32_t ldx, const void* dy, int32_t lddy,

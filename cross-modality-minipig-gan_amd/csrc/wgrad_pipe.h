@@ -115,9 +115,10 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
   const unsigned dstepB = (unsigned)(WBK * ldd) * 4u, drowB = (unsigned)(DROWSTEP * ldd) * 4u;
 
   // The tables are filled for consecutive tiles (mbeg, mbeg + 32, ...), so the entry of row r is carried as a cursor
-  // -- coarse coordinates + byte offset, decoded with divisions ONCE -- and advanced by 32 pixels per fill with
-  // compares and wave-uniform increments (the coarse grid is at least 32 wide: one wrap per dimension at most):
-  // 17 vector instructions per K-step instead of the 38 of three multiply-high divisions.
+  // -- coarse coordinates + byte offset, decoded with divisions ONCE -- and advanced by 32 pixels per fill as a
+  // mixed-radix addition: 32 = dx0 + Mx (dy0 + My (dz0 + Mz dn0)) with block-uniform digits, one carry compare per
+  // dimension (digit + carry stays below twice the radix), wave-uniform offset increments: 20 vector instructions
+  // per K-step instead of the 38 of three multiply-high divisions, for any grid extent.
   int tx, ty, tz;
   unsigned toff;
   {
@@ -128,7 +129,12 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
     tx = (int)ux; ty = (int)uy; tz = (int)uz;
     toff = (unsigned)((((int)q * Gz + tz * p.sz - p.pz) * Gy + ty * p.sy - p.py) * Gx + tx * p.sx - p.px) * (unsigned)ldg * 4u;
   }
-  const unsigned incX = (unsigned)(WBK * p.sx * ldg) * 4u;
+  unsigned dq, udx0, udy0, udz0;
+  fdivmod((unsigned)WBK, p.fMx, dq, udx0);
+  fdivmod(dq, p.fMy, dq, udy0);
+  fdivmod(dq, p.fMz, dq, udz0);
+  const int dx0 = (int)udx0, dy0 = (int)udy0, dz0 = (int)udz0;     // (dq: whole samples per 32 pixels)
+  const unsigned incX = (unsigned)((dx0 * p.sx + (dy0 * p.sy + (dz0 * p.sz + (int)dq * Gz) * Gy) * Gx) * ldg) * 4u;
   const unsigned wrapX = (unsigned)((p.sy * Gx - p.Mx * p.sx) * ldg) * 4u;
   const unsigned wrapY = (unsigned)((p.sz * Gy * Gx - p.My * p.sy * Gx) * ldg) * 4u;
   const unsigned wrapZ = (unsigned)((Gz * Gy * Gx - p.Mz * p.sz * Gy * Gx) * ldg) * 4u;
@@ -139,15 +145,15 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(const WgradParams p) {
     int4 e;
     e.x = (int)toff;
     {                                // advance the cursor to the next tile
-      tx += WBK;
+      tx += dx0;
       const bool cx = tx >= p.Mx;
       tx -= cx ? p.Mx : 0;
-      ty += cx ? 1 : 0;
+      ty += dy0 + (cx ? 1 : 0);
       const bool cy = ty >= p.My;
-      ty = cy ? 0 : ty;
-      tz += cy ? 1 : 0;
+      ty -= cy ? p.My : 0;
+      tz += dz0 + (cy ? 1 : 0);
       const bool cz = tz >= p.Mz;
-      tz = cz ? 0 : tz;
+      tz -= cz ? p.Mz : 0;
       toff += incX + (cx ? wrapX : 0u) + (cy ? wrapY : 0u) + (cz ? wrapZ : 0u);
     }
     if constexpr (PAD) {

@@ -757,13 +757,16 @@ def emit_norm_bwd(prog, g, z, nb: NormBuf, pro: Prologue, dz, partials, dgamma, 
     assert g.shape == z.shape and dz.shape == z.shape
     c = z.shape[-1]
     chunks = ops.stats_chunks(P, c)
-    assert partials.numel() >= n * chunks * (3 * c + 1) + c          # [3][C] rows + one slope scalar per row
+    assert partials.numel() >= n * chunks * (3 * c + 1)              # [3][C] rows + one slope scalar per row (ops.norm_bwd_reduce)
     L = lib()
     pc = pro.c()
     pe = peer.c() if peer is not None else None
     pe_ref = C.byref(pe) if pe is not None else None
     if reduced_rows:
         assert peer is None and not nb.instance and partials.numel() >= reduced_rows * 3 * c
+        # rows left by mpgan_conv_backward_data_stats carry no per-row slope scalars (include/mpgan_hip.h): a learnable
+        # PReLU slope needs the stand-alone reduce pass
+        assert dslope is None, "fused norm-backward rows cannot feed a slope gradient"
         prog.add("norm_bwd_finalize", L.mpgan_norm_bwd_finalize, partials.data_ptr(), 1, reduced_rows, c, n * P, 0,
                  _p(dgamma), _p(dbeta), _p(dslope), nb.c1.data_ptr(), nb.c2.data_ptr(), keep=(dgamma, dbeta, dslope))
         prog.add("norm_bwd_apply", L.mpgan_norm_bwd_apply, g.data_ptr(), _ld(g), z.data_ptr(), ldz, C.byref(pc),

@@ -8,6 +8,10 @@ namespace mpgan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Phases of a gather: the 2^d sub-grids of a strided transposed gather (<= 8), or the 3^d border classes of a
+// stride-1 transposed gather on a small map (build_transposed).
+constexpr int MAX_PHASES = 27;
+
 struct Phase {
   FastDiv fMx, fMy, fMz;
   int Mz, My, Mx;     // extents of the m-grid of this phase
@@ -57,7 +61,7 @@ struct GatherConv {
   int mm16;              // MPGAN_CONV_MM_BF16: matrix operands rounded to bf16 into LDS, bf16 MFMA, fp32 accumulation
   int min_blocks;        // the geometry's big-tile threshold (0: default), see mpgan_conv_geom
   MPGAN_STAMP_FIELD      // development builds only (mpgan_common.h)
-  Phase ph[8];
+  Phase ph[MAX_PHASES];
 };
 
 struct BlockId { int mt, nt, phase, split; };
@@ -154,6 +158,71 @@ inline void build_transposed(GatherConv& p, int n, const int32_t* gath_dhw, int 
   p.Do = prod_dhw[0]; p.Ho = prod_dhw[1]; p.Wo = prod_dhw[2]; p.Cout = cp;
   p.Kz = k[0]; p.Ky = k[1]; p.Kx = k[2];
   for (int d = 0; d < 3; ++d) { p.ostride[d] = s[d]; p.istride[d] = 1; p.kstep[d] = s[d]; p.dstep[d] = -1; }
+  // Stride 1 on a SMALL map (the backward-data of a valid k^3 conv: produced extent = gathered extent + k - 1): the
+  // border rows of the produced grid have fewer real taps than k -- on the 10^3 map of variant B's 256 -> 512 conv
+  // only (8/10)^3 = 51 % of the (tap, pixel) pairs are real, the others multiply masked zeros.  Split each
+  // dimension into <= 3 classes of produced coordinates -- left border, interior, right border -- that share a tap
+  // RANGE, and make each combination a phase (ostride = 1, the class start as the phase's output offset, its tap range
+  // as (k0, n)): border classes issue 2 of 3 taps, 79 % of the issued pairs are real.  Taps that are still out of
+  // range for single rows of a border class are masked exactly as before: the result is unchanged.
+  if (s[0] == 1 && s[1] == 1 && s[2] == 1) {
+    int nc[3], lo[3][3], hi[3][3], k0c[3][3], njc[3][3];
+    double real = 1.0, issued = 1.0, issued_cls = 1.0;
+    for (int d = 0; d < 3; ++d) {
+      const int G = gath_dhw[d], P = prod_dhw[d], K = k[d], pd = pad[d];
+      // produced o reads gathered o + pd - kk: left border o < K - 1 - pd (tap K-1 out of range), right border
+      // o > G - 1 + pd - ... i.e. o + pd > G - 1 (tap 0 out of range)
+      int a = K - 1 - pd;            // first interior coordinate
+      int b = G - pd;                // first right-border coordinate
+      if (a < 0) a = 0;
+      if (b > P) b = P;
+      if (b < a) { a = 0; b = P; }   // the borders overlap (map smaller than the kernel): one class, all taps
+      nc[d] = 0;
+      const int bounds[4] = {0, a, b, P};
+      long pairs_cls = 0, pairs_real = 0;
+      for (int c = 0; c < 3; ++c) {
+        const int l = bounds[c], h = bounds[c + 1];
+        if (h <= l) continue;
+        int kmin = l + pd - (G - 1) > 0 ? l + pd - (G - 1) : 0;          // smallest tap any row of the class can use
+        int kmax = (h - 1) + pd < K - 1 ? (h - 1) + pd : K - 1;          // largest
+        if (kmax < kmin) { kmin = 0; kmax = -1; }
+        lo[d][nc[d]] = l; hi[d][nc[d]] = h; k0c[d][nc[d]] = kmin; njc[d][nc[d]] = kmax - kmin + 1;
+        pairs_cls += (long)(h - l) * (kmax - kmin + 1);
+        nc[d] += 1;
+      }
+      for (int o = 0; o < P; ++o)
+        for (int kk = 0; kk < K; ++kk) pairs_real += (o + pd - kk >= 0 && o + pd - kk < G) ? 1 : 0;
+      real *= (double)pairs_real; issued *= (double)P * K; issued_cls *= (double)pairs_cls;
+    }
+    // worth it when a fifth or more of the single-phase form's pairs are padding and the classes remove most of it
+    if (real < 0.8 * issued && issued_cls < 0.9 * issued && nc[0] * nc[1] * nc[2] <= MAX_PHASES) {
+      for (int d = 0; d < 3; ++d) p.ostride[d] = 1;
+      int np = 0;
+      for (int cz = 0; cz < nc[0]; ++cz)
+        for (int cy = 0; cy < nc[1]; ++cy)
+          for (int cx = 0; cx < nc[2]; ++cx) {
+            Phase& ph = p.ph[np++];
+            const int ci[3] = {cz, cy, cx};
+            int M[3], nj[3], k0[3], d0[3], o0[3];
+            for (int d = 0; d < 3; ++d) {
+              M[d] = hi[d][ci[d]] - lo[d][ci[d]];
+              nj[d] = njc[d][ci[d]];
+              k0[d] = k0c[d][ci[d]];
+              o0[d] = lo[d][ci[d]];
+              d0[d] = o0[d] + pad[d] - k0[d];            // gathered coordinate of tap j: m + d0 - j
+            }
+            ph.Mz = M[0]; ph.My = M[1]; ph.Mx = M[2];
+            ph.fMx = make_fastdiv(M[2]); ph.fMy = make_fastdiv(M[1]); ph.fMz = make_fastdiv(M[0]);
+            ph.oz = o0[0]; ph.oy = o0[1]; ph.ox = o0[2];
+            ph.nz = nj[0]; ph.ny = nj[1]; ph.nx = nj[2];
+            ph.kz0 = k0[0]; ph.ky0 = k0[1]; ph.kx0 = k0[2];
+            ph.dz0 = d0[0]; ph.dy0 = d0[1]; ph.dx0 = d0[2];
+            if (nj[0] <= 0 || nj[1] <= 0 || nj[2] <= 0) { ph.nz = 0; ph.ny = 1; ph.nx = 1; }
+          }
+      p.nphase = np;
+      return;
+    }
+  }
   int np = 0;
   for (int pz = 0; pz < s[0]; ++pz)
     for (int py = 0; py < s[1]; ++py)

@@ -2078,6 +2078,7 @@ static bool patch_plan(const GatherConv& p, PatchLaunch* out, int* smem_bytes) {
   static const bool off = dev_env("MPGAN_DBG_NO_PATCH") != nullptr;
   if (off) return false;
   if (p.Di != 1 || p.Do != 1 || p.Kz != 1) return false;
+  if (p.nphase > 8) return false;                             // (PatchLaunch's per-phase tables; border-class phases: conv_geom.h)
   if (!(p.Cin == 16 || p.Cin == 32 || p.Cin == 64)) return false;
   if (p.Cout < 2 || p.Cout > 32) return false;
   if (p.pro.scale && p.pro.n_stride % 4 != 0) return false;

@@ -181,3 +181,21 @@ def test_bench_launcher_starts_n_ranks_from_a_bare_shell():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"],
                        env=env_bad, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+def test_border_class_phases_cover_every_tap_pair_exactly_once(tmp_path):
+    """csrc/conv_geom.h splits a stride-1 transposed gather on a small map (the backward-data of variant B's valid 3^3
+    convs on 10^3 / 12^3 maps) into up to 27 border-class phases; tools/check_phase_classes.hip enumerates 100+
+    geometries on the host and requires every in-range (pixel, tap) pair to be issued exactly once."""
+    import shutil
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "check_phase_classes")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"), "-I",
+                    os.path.join(ROOT, "cross-modality-minipig-gan_amd", "csrc"),
+                    os.path.join(ROOT, "tools", "check_phase_classes.hip"), "-o", exe], check=True, capture_output=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert " 0 errors" in out and "geometries used classes" in out, out

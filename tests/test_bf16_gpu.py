@@ -423,3 +423,22 @@ def test_discriminator_128cubed_bf16_against_the_reference_fixture(golden_dir):
         dev[name] = abs(got - want) / abs(want)
         assert dev[name] <= (5e-2 if name.startswith("model_linear") else 0.25), (name, got, want)
     print("128^3 |grad|-sum deviation from the reference's fp32 fixture:", {k: round(e, 4) for k, e in dev.items()})
+
+
+@pytest.mark.parametrize("n,spatial,cin,cout", [(6, (10, 10, 10), 128, 256), (8, (9, 11), 64, 128)], ids=str)
+def test_small_map_backward_data_border_class_phases_bf16(n, spatial, cin, cout):
+    """The bf16 K-stepped kernel on the border-class phases of a small-map valid conv's backward-data (csrc/conv_geom.h):
+    sparse integers, bit-exact against torch fp32."""
+    from mpgan_amd import ops
+    dims = len(spatial)
+    gen = torch.Generator().manual_seed(17 + cin)
+    w = _sparse_int((cout, cin) + (3,) * dims, gen, density=0.1).requires_grad_(False)
+    g = _geom(n, spatial, cin, cout, 3, 1, 0)
+    out_sp = tuple(s - 2 for s in spatial)
+    gy = _sparse_int((n, cout) + out_sp, gen, density=0.2)
+    x = torch.zeros(n, cin, *spatial, requires_grad=True)
+    conv = torch.nn.functional.conv2d if dims == 2 else torch.nn.functional.conv3d
+    conv(x, w).backward(gy)
+    dx = torch.full((n, *g.in_dhw, cin), float("nan"), dtype=BF, device="cuda")
+    ops.conv_backward_data_bf16(g, to_cl(gy).to(BF), ops.pack_weight_bf16(w.cuda(), for_dgrad=True), dx)
+    assert torch.equal(from_cl(dx.float(), dims), x.grad)

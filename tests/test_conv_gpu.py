@@ -760,3 +760,20 @@ def test_dma_staged_form_serves_the_discriminator_backward_data_at_c3():
         g = _geom(2, 16, cin, cout, k, s, 0, (e, e))
         assert ops.conv_variant(g, True, 0) >= 3000, (cin, cout)
         assert ops.conv_variant(g, False, 3) < 3000            # the forward keeps its normalise-on-load prologue
+
+
+@pytest.mark.parametrize("case", [(3, 64, 128, 3, 1, 0, (10, 9, 12), 6), (2, 64, 64, 3, 1, 0, (9, 10), 8),
+                                  (3, 32, 64, 4, 1, 0, (7, 8, 9), 4), (3, 32, 32, 3, 1, 0, (5, 5, 5), 3)],
+                         ids=lambda c: "d{}_{}to{}_k{}s{}p{}".format(*c[:6]))
+@pytest.mark.parametrize("dma", [False, True], ids=["pipe", "dma"])
+def test_small_map_valid_conv_backward_data_runs_as_border_class_phases(case, dma):
+    """Backward-data of a pad-free stride-1 conv on a map only a few kernels wide (variant B's patch discriminator:
+    8^3 -> 10^3, 10^3 -> 12^3): csrc/conv_geom.h splits the produced grid into <= 27 border-class phases with their own
+    tap ranges (tools/check_phase_classes.hip checks the construction exhaustively on the host); here the K-stepped
+    kernels -- pipelined and DMA-staged -- run them: forward, backward-data and weight gradient against torch."""
+    saved = _MIN_BLOCKS[0]
+    _MIN_BLOCKS[0] = 1 if dma else 0
+    try:
+        test_conv_forward_dgrad_wgrad(case)
+    finally:
+        _MIN_BLOCKS[0] = saved

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_conv_bf16_kernel(const Gath
   const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
   const long m0 = (long)bid.mt * HB_BM;
   const int n0 = bid.nt * BN;
-  const int stats_row = bid.phase * p.mtiles + bid.mt;
+  const int stats_row = bid.row;
   const int Cout = p.Cout;
   if (m0 >= Mtot) {                                   // empty tile of a short phase (block-uniform)
     if (p.stats && tid < BN && n0 + tid < Cout) {
@@ -420,11 +420,11 @@ static int hb_launch(const GatherConv& p, long maxM, hipStream_t st) {
     if (dbg_set) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hb_dbg), &dbg_set, sizeof(int));
   }
   GatherConv q = p;
-  q.mtiles = (int)((maxM + HB_BM - 1) / HB_BM);
+  const long pairs = set_tile_grid(q, HB_BM);
   q.ntiles = (p.Cout + BN - 1) / BN;
   q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 2 > (3L << 20) ? 1 : 0;
   q.ksplit = 1;
-  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
+  dim3 grid((unsigned)(pairs * q.ntiles));
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, q);
   return check_launch("gather_conv_bf16");
 }
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
   const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
   const long m0 = (long)bid.mt * BM;
   const int n0 = PAIR ? 0 : bid.nt * BN;
-  const int stats_row = bid.phase * p.mtiles + bid.mt;
+  const int stats_row = bid.row;
   const int Cout = p.Cout;
   if (m0 >= Mtot) {                                   // empty tile of a short phase (block-uniform)
     if (!PAIR && p.stats && tid < BN && n0 + tid < Cout) {
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
 // turns them off (A/B runs).  mpgan_conv_stats_rows_bf16 follows the same choice (rows = phases x m-tiles).
 // (the threshold is the geometry's own `min_blocks`, include/mpgan_hip.h: sizing queries and launches see the same value)
 static bool hw_pairs_congruent(const GatherConv& p) {
-  if (p.nphase < 2 || p.nphase % 2) return false;
+  if (p.nphase < 2 || p.nphase % 2 || p.classes) return false;
   for (int i = 0; i < p.nphase; i += 2) {
     const Phase &a = p.ph[i], &b = p.ph[i + 1];
     if (a.Mz != b.Mz || a.My != b.My || a.Mx != b.Mx || a.nz != b.nz || a.ny != b.ny || a.nx != b.nx || a.dz0 != b.dz0 ||
@@ -841,7 +841,7 @@ static int hw_choice(const GatherConv& p, bool with_stats) {
   const long maxM = max_phase_pixels(p);
   const int g_hw_min_blocks = p.min_blocks > 0 ? p.min_blocks : FORM_MIN_BLOCKS_DEFAULT;
   if (p.Cout > 128) {
-    const long blocks = ((maxM + 255) / 256) * ((p.Cout + 255) / 256) * p.nphase;
+    const long blocks = phase_tile_rows(p, 256) * ((p.Cout + 255) / 256);
     return (blocks >= g_hw_min_blocks || forced == 1) ? 1 : 0;
   }
   if (p.Cout == 128 && !with_stats && !p.bias && hw_pairs_congruent(p) && forced != 2) {   // 3 = 256 x 256 over phase pairs
@@ -849,7 +849,7 @@ static int hw_choice(const GatherConv& p, bool with_stats) {
     if (blocks >= g_hw_min_blocks || forced == 3) return 3;
   }
   if (p.Cout > 64) {
-    const long blocks = ((maxM + 511) / 512) * p.nphase;
+    const long blocks = phase_tile_rows(p, 512);
     return (blocks >= g_hw_min_blocks || forced == 2) ? 2 : 0;
   }
   return 0;
@@ -876,12 +876,19 @@ static int hw_launch(const GatherConv& p, long maxM, hipStream_t st) {
     if (dbg_set) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hb_dbg), &dbg_set, sizeof(int));
   }
   GatherConv q = p;
-  q.mtiles = (int)((maxM + T::BM - 1) / T::BM);
+  long pairs;
+  if constexpr (PAIR) {                                // (congruent phases, never border classes: hw_pairs_congruent)
+    q.packed = 0;
+    q.mtiles = (int)((maxM + T::BM - 1) / T::BM);
+    q.nphase = p.nphase / 2;                           // (the kernel reads phases 2 i and 2 i + 1 of pair i)
+    pairs = (long)q.mtiles * q.nphase;
+  } else {
+    pairs = set_tile_grid(q, T::BM);
+  }
   q.ntiles = PAIR ? 1 : (p.Cout + T::BN - 1) / T::BN;
-  q.nphase = PAIR ? p.nphase / 2 : p.nphase;          // (the kernel reads phases 2 i and 2 i + 1 of pair i)
   q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 2 > (3L << 20) ? 1 : 0;
   q.ksplit = 1;
-  dim3 grid((unsigned)q.mtiles * q.ntiles * q.nphase);
+  dim3 grid((unsigned)(pairs * q.ntiles));
   hipLaunchKernelGGL(kern, grid, dim3(512), T::SMEM, st, q);
   return check_launch("gather_conv_bf16_wide");
 }
@@ -2036,7 +2043,7 @@ extern "C" int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g) {
   }
   p.ldi = p.Cin;
   const int bm = hw_bm(g->cin % HB_BK == 0 ? hw_choice(p, true) : 0);
-  return (int32_t)((max_phase_pixels(p) + bm - 1) / bm) * p.nphase;
+  return (int32_t)phase_tile_rows(p, bm);
 }
 
 // Which bf16 kernel serves this geometry (profiling labels): 0 = K-stepped gather_conv_bf16_kernel,

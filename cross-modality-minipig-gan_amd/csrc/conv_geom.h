@@ -60,14 +60,35 @@ struct GatherConv {
   int in_bf16, out_bf16; // thin (VALU) kernels of the bf16 path: `in` / `out` point at bf16 data (weights stay fp32)
   int mm16;              // MPGAN_CONV_MM_BF16: matrix operands rounded to bf16 into LDS, bf16 MFMA, fp32 accumulation
   int min_blocks;        // the geometry's big-tile threshold (0: default), see mpgan_conv_geom
+  int classes;           // the phases are border classes of unequal size (build_transposed): launchers pack the tile list
+  int packed;            // set by set_tile_grid: the grid holds only real (phase, m-tile) pairs, tile_start[] delimits the phases
   MPGAN_STAMP_FIELD      // development builds only (mpgan_common.h)
   Phase ph[MAX_PHASES];
+  int tile_start[MAX_PHASES + 1];   // packed: first work item of phase i (in m-tiles); entries past nphase = INT_MAX
 };
 
-struct BlockId { int mt, nt, phase, split; };
-__device__ __forceinline__ BlockId conv_block_id(const GatherConv& p) {
-  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
+// `row`: index of the block's (phase, m-tile) pair = its row of fused statistics / norm-backward partial sums.
+struct BlockId { int mt, nt, phase, split, row; };
+__host__ __device__ __forceinline__ BlockId decode_block(const GatherConv& p, const unsigned w) {   // w: position in the work order
   BlockId b;
+  if (p.packed) {
+    // Border-class phases differ in size by up to 27 x: a grid of nphase x max-tiles blocks would leave most of them
+    // empty AND (phases being contiguous ranges of the work order, which xcd_remap hands out in eighths) put a third
+    // of the work -- the interior class -- on one XCD (measured: variant B's 256 -> 512 backward-data 47.7 -> 79 ms).
+    // The work list therefore holds real tiles only, phase after phase; every XCD gets an equal contiguous share.
+    b.nt = (int)(w % (unsigned)p.ntiles);
+    unsigned q = w / (unsigned)p.ntiles;
+    const unsigned tot = (unsigned)p.mtiles;            // (packed: mtiles = all phases' tiles)
+    b.split = (int)(q / tot);
+    q -= (unsigned)b.split * tot;
+    int ph = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_PHASES; ++i) ph += q >= (unsigned)p.tile_start[i] ? 1 : 0;
+    b.phase = ph;
+    b.mt = (int)(q - (unsigned)p.tile_start[ph]);
+    b.row = (int)q;
+    return b;
+  }
   // n-tile fastest, then phase, then m-tile: the phases of a strided backward-data gather read the
   // SAME dy pixels (different taps), so they sit next to each other in the work order -- same XCD,
   // same time, one fetch into its L2 instead of one per phase.
@@ -86,7 +107,11 @@ __device__ __forceinline__ BlockId conv_block_id(const GatherConv& p) {
     b.mt = (int)(q % (unsigned)p.mtiles);
     b.split = (int)(q / (unsigned)p.mtiles);
   }
+  b.row = b.phase * p.mtiles + b.mt;
   return b;
+}
+__device__ __forceinline__ BlockId conv_block_id(const GatherConv& p) {
+  return decode_block(p, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 inline long max_phase_pixels(const GatherConv& p) {
@@ -96,6 +121,33 @@ inline long max_phase_pixels(const GatherConv& p) {
     if (m > maxM) maxM = m;
   }
   return maxM;
+}
+
+// (phase, m-tile) pairs of a launch with m-tiles of `bm` pixels = its blocks per n-tile and K split = its rows of fused
+// statistics: every phase's own tile count when the phases are border classes, nphase x the largest phase's otherwise.
+inline long phase_tile_rows(const GatherConv& p, int bm) {
+  if (!p.classes) return (max_phase_pixels(p) + bm - 1) / bm * p.nphase;
+  long t = 0;
+  for (int i = 0; i < p.nphase; ++i) t += ((long)p.N * p.ph[i].Mz * p.ph[i].My * p.ph[i].Mx + bm - 1) / bm;
+  return t;
+}
+// Launchers of the K-stepped kernels: q.mtiles / q.packed / q.tile_start for m-tiles of `bm` pixels; returns the
+// number of (phase, m-tile) pairs (grid = that x ntiles x ksplit).
+inline long set_tile_grid(GatherConv& q, int bm) {
+  q.packed = 0;
+  if (!q.classes) {
+    q.mtiles = (int)((max_phase_pixels(q) + bm - 1) / bm);
+    return (long)q.mtiles * q.nphase;
+  }
+  long t = 0;
+  for (int i = 0; i <= MAX_PHASES; ++i) {
+    q.tile_start[i] = i <= q.nphase ? (int)t : 0x7FFFFFFF;
+    if (i < q.nphase) t += ((long)q.N * q.ph[i].Mz * q.ph[i].My * q.ph[i].Mx + bm - 1) / bm;
+  }
+  for (int i = q.nphase + 1; i <= MAX_PHASES; ++i) q.tile_start[i] = 0x7FFFFFFF;
+  q.packed = 1;
+  q.mtiles = (int)t;
+  return t;
 }
 
 // conv_bf16.hip: MFMA form of the C -> 1 gather over bf16 data (D.conv1's backward-data in the bf16 path)
@@ -139,6 +191,7 @@ inline void build_forward(GatherConv& p, int n, const int32_t* gath_dhw, int cg,
                           const int32_t* k, const int32_t* s, const int32_t* pad) {
   p.N = n; p.Di = gath_dhw[0]; p.Hi = gath_dhw[1]; p.Wi = gath_dhw[2]; p.Cin = cg;
   p.Do = prod_dhw[0]; p.Ho = prod_dhw[1]; p.Wo = prod_dhw[2]; p.Cout = cp;
+  p.classes = 0; p.packed = 0;
   p.Kz = k[0]; p.Ky = k[1]; p.Kx = k[2];
   for (int d = 0; d < 3; ++d) { p.ostride[d] = 1; p.istride[d] = s[d]; p.kstep[d] = 1; p.dstep[d] = 1; }
   p.nphase = 1;
@@ -165,7 +218,10 @@ inline void build_transposed(GatherConv& p, int n, const int32_t* gath_dhw, int 
   // RANGE, and make each combination a phase (ostride = 1, the class start as the phase's output offset, its tap range
   // as (k0, n)): border classes issue 2 of 3 taps, 79 % of the issued pairs are real.  Taps that are still out of
   // range for single rows of a border class are masked exactly as before: the result is unchanged.
-  if (s[0] == 1 && s[1] == 1 && s[2] == 1) {
+  // Only where the K-stepped kernels serve the gather (>= 64 channels on both sides): the patch kernels stage the
+  // padding as zeros once per tile and need one phase.
+  p.classes = 0;
+  if (s[0] == 1 && s[1] == 1 && s[2] == 1 && cg >= 64 && cp >= 64) {
     int nc[3], lo[3][3], hi[3][3], k0c[3][3], njc[3][3];
     double real = 1.0, issued = 1.0, issued_cls = 1.0;
     for (int d = 0; d < 3; ++d) {
@@ -220,6 +276,7 @@ inline void build_transposed(GatherConv& p, int n, const int32_t* gath_dhw, int 
             if (nj[0] <= 0 || nj[1] <= 0 || nj[2] <= 0) { ph.nz = 0; ph.ny = 1; ph.nx = 1; }
           }
       p.nphase = np;
+      p.classes = 1;
       return;
     }
   }

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConv p) {
   const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
   const long m0 = (long)bid.mt * BM;
   const int n0 = bid.nt * BN;
-  const int stats_row = bid.phase * p.mtiles + bid.mt;
+  const int stats_row = bid.row;
   if (m0 >= Mtot) {
     if (p.stats && tid < BN && n0 + tid < p.Cout) {   // an empty tile of a short phase still owns a partial row
       float* row = p.stats + (long)stats_row * 2 * p.Cout;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void gather_conv_dma_kernel(const GatherConv p
   const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
   const long m0 = (long)bid.mt * BM;
   const int n0 = bid.nt * BN;
-  const int stats_row = bid.phase * p.mtiles + bid.mt;
+  const int stats_row = bid.row;
   if (m0 >= Mtot) {
     if (p.stats && tid < BN && n0 + tid < p.Cout) {
       float* row = p.stats + (long)stats_row * 2 * p.Cout;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void gather_conv_dma_kernel(const GatherConv p
   constexpr int NL = AP + BP;
   // wait until at most t tiles' worth of this wave's DMAs are outstanding (t < NST is block-uniform)
   auto wait_tiles = [&](int t) {
-    if (t <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t <= 0) asm volatile("s_waitcnt vmcnt(0) ; tail: the awaited tile is the only one in flight (two stages)" ::: "memory");   // (tools/check_isa.py)
     else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
     else if (t == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NL) : "memory");
@@ -2318,11 +2318,11 @@ static int launch_variant(const GatherConv& p, long maxM, hipStream_t st) {
     attr_set = true;
   }
   GatherConv q = p;
-  q.mtiles = (int)((maxM + BM - 1) / BM);
+  const long pairs = set_tile_grid(q, BM);
   q.ntiles = (p.Cout + BN - 1) / BN;
   q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 4 > (3L << 20) ? 1 : 0;
   q.ksplit = 1;
-  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
+  dim3 grid((unsigned)(pairs * q.ntiles));
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
   return check_launch("gather_conv");
 }
@@ -2339,7 +2339,7 @@ static int select_variant(const GatherConv& p, long maxM, bool thin1, bool thin2
   // Widest channel tile that still gives every CU a block: the pipelined kernel keeps the
   // matrix pipe ~85 % fed from ONE resident block, while narrow tiles (16 MFMAs per K-step
   // and wave) cannot cover their own load/store/barrier overhead.
-  const long mtiles = (maxM + BM - 1) / BM * p.nphase;
+  const long mtiles = phase_tile_rows(p, BM);
   static const int force_bn = dev_env("MPGAN_DBG_BN") ? atoi(dev_env("MPGAN_DBG_BN")) : 0;   // experiments
   if (force_bn == 32 || force_bn == 64 || force_bn == 128) return force_bn;
   int bn = 32;
@@ -2365,11 +2365,11 @@ static int launch_pipe_variant(const GatherConv& p, long maxM, hipStream_t st) {
     attr_set = true;
   }
   GatherConv q = p;
-  q.mtiles = (int)((maxM + BM - 1) / BM);
+  const long pairs = set_tile_grid(q, BM);
   q.ntiles = (p.Cout + BN - 1) / BN;
   q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 4 > (3L << 20) ? 1 : 0;
   if (q.ksplit < 1) q.ksplit = 1;
-  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase * q.ksplit);
+  dim3 grid((unsigned)(pairs * q.ntiles * q.ksplit));
   hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, st, q);
   return check_launch("gather_conv_pipe");
 }
@@ -2395,7 +2395,7 @@ static bool fast_geometry(const GatherConv& p, int bn) {
 static bool pipe_wants_ksplit2(const GatherConv& p, int bn, long maxM) {
   static const bool off = dev_env("MPGAN_DBG_NO_KS2") != nullptr;
   if (off || p.ksplit > 1 || p.Cin % 32 != 0) return false;
-  const long blocks = (maxM + BM - 1) / BM * ((p.Cout + bn - 1) / bn) * p.nphase;
+  const long blocks = phase_tile_rows(p, BM) * ((p.Cout + bn - 1) / bn);
   if (blocks > 384) return false;
   int min_nk = 1 << 30;
   for (int i = 0; i < p.nphase; ++i) {
@@ -2412,7 +2412,7 @@ static bool dma_form_ok(const GatherConv& p, int variant, long maxM) {
   static const bool off = dev_env("MPGAN_DBG_NO_DMA") != nullptr;
   if (off || p.pro.scale || p.ksplit > 1 || p.Cin % 32 != 0 || (variant != 128 && variant != 64 && variant != 32)) return false;
   if (p.stats_acc || p.fold.acc) return false;
-  const long blocks = (maxM + BM - 1) / BM * ((p.Cout + variant - 1) / variant) * p.nphase;
+  const long blocks = phase_tile_rows(p, BM) * ((p.Cout + variant - 1) / variant);
   if (blocks < (p.min_blocks > 0 ? p.min_blocks : FORM_MIN_BLOCKS_DEFAULT)) return false;
   for (int i = 0; i < p.nphase; ++i) {
     const int nt = p.ph[i].nz * p.ph[i].ny * p.ph[i].nx;
@@ -2437,11 +2437,11 @@ static int launch_dma_variant(const GatherConv& p, long maxM, hipStream_t st) {
     attr_set = true;
   }
   GatherConv q = p;
-  q.mtiles = (int)((maxM + BM - 1) / BM);
+  const long pairs = set_tile_grid(q, BM);
   q.ntiles = (p.Cout + BN - 1) / BN;
   q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 4 > (3L << 20) ? 1 : 0;
   q.ksplit = 1;
-  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
+  dim3 grid((unsigned)(pairs * q.ntiles));
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
   return check_launch("gather_conv_dma");
 }
@@ -2953,7 +2953,7 @@ extern "C" int32_t mpgan_conv_stats_rows(const mpgan_conv_geom* g, int32_t has_p
     const P3Grid tg = patch3d_grid(p);
     return (int32_t)(p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x);
   }
-  return (int32_t)((max_phase_pixels(p) + BM - 1) / BM) * p.nphase;
+  return (int32_t)phase_tile_rows(p, BM);
 }
 
 extern "C" int mpgan_conv_forward_fold(const mpgan_conv_geom* g, const float* x, int32_t ldx, const float* w_packed,
@@ -3100,7 +3100,7 @@ extern "C" int32_t mpgan_conv_bwd_stats_rows(const mpgan_conv_geom* g) {
   set_geom_flags(p, g);
   if (!g->transposed) build_transposed(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
   else build_forward(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
-  return (int32_t)((max_phase_pixels(p) + BM - 1) / BM) * p.nphase;
+  return (int32_t)phase_tile_rows(p, BM);
 }
 
 // mpgan_conv_backward_data + the reduce pass of the norm layer in front of this conv's input, in one launch:

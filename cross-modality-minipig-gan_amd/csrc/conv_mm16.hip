@@ -32,11 +32,11 @@ static int launch_mm16_variant(const GatherConv& p, long maxM, hipStream_t st) {
     attr_set = true;
   }
   GatherConv q = p;
-  q.mtiles = (int)((maxM + BM - 1) / BM);
+  const long pairs = set_tile_grid(q, BM);
   q.ntiles = (p.Cout + BN - 1) / BN;
   q.phase_outer = (long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx * 4 > (3L << 20) ? 1 : 0;
   q.ksplit = 1;
-  dim3 grid((unsigned)q.mtiles * q.ntiles * p.nphase);
+  dim3 grid((unsigned)(pairs * q.ntiles));
   hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, st, q);
   return check_launch("gather_conv_pipe (bf16 operands)");
 }

@@ -26,7 +26,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
   const int Cout = p.Cout;
-  const int ksplit_id = p.ksplit > 1 ? (int)(xcd_remap(blockIdx.x, gridDim.x) / (unsigned)(p.ntiles * p.mtiles * p.nphase)) : 0;
+  const int ksplit_id = p.ksplit > 1 ? (int)(xcd_remap(blockIdx.x, gridDim.x) / (unsigned)(p.ntiles * p.mtiles * (p.packed ? 1 : p.nphase))) : 0;
   // ---- epilogue: row -> output pixel map through LDS, then bias/resid/tanh ----
   int* rowpix = reinterpret_cast<int*>(lds);
   if (active && tid < BM) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256 * KS) void gather_conv_pipe_kernel(const Gather
   const long Mtot = (long)p.N * ph.Mz * ph.My * ph.Mx;
   const long m0 = (long)bid.mt * BM;
   const int n0 = bid.nt * BN;
-  const int stats_row = bid.phase * p.mtiles + bid.mt;
+  const int stats_row = bid.row;
   if (m0 >= Mtot) {
     if (p.stats && kg == 0 && tid < BN && n0 + tid < p.Cout) {
       float* row = p.stats + (long)stats_row * 2 * p.Cout;

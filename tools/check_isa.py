@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build-time check of the bf16 kernels' K loops (run by __graft_entry__.build()): the LDS-DMA pipeline only
+"""Build-time check of the LDS-DMA kernels' K loops (bf16: conv_bf16; fp32: gather_conv_dma_kernel in conv_igemm) (run by __graft_entry__.build()): the LDS-DMA pipeline only
 works if the loop body waits with the COUNTED vmcnt it was written with.  hipcc inserts `s_waitcnt vmcnt(0)`
 in front of any LDS access it thinks may alias an LDS-DMA in flight, silently serialising the pipeline; this
 script reads the device assembly hipcc leaves beside the object (-save-temps=obj) and fails if the innermost
@@ -7,6 +7,12 @@ loop of a pipelined kernel holds a vmcnt(0), scratch traffic, or fewer MFMAs / D
 import re
 import sys
 
+MFMA_BF16, MFMA_F32 = "v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x2_f32"
+KERNELS_F32 = {   # conv_igemm: the DMA-staged fp32 form <BN, TM, TN, WN, NST> (64 fp32 MFMAs per 128 x 128 K-step and wave)
+    "gather_conv_dma_kernelILi128ELi2ELi2ELi2ELi2": (64, 4),
+    "gather_conv_dma_kernelILi64ELi1ELi2ELi1ELi2": (32, 3),
+    "gather_conv_dma_kernelILi32ELi1ELi1ELi1ELi2": (16, 2),
+}
 KERNELS = {   # mangled-name fragment -> (min MFMAs, min LDS-DMA loads) in the K loop
     "gather_conv_bf16_kernelILi128ELb0ELi4": (32, 12),
     "gather_conv_bf16_kernelILi128ELb1ELi4": (32, 12),
@@ -33,7 +39,8 @@ KERNELS = {   # mangled-name fragment -> (min MFMAs, min LDS-DMA loads) in the K
 def main(path):
     text = open(path).read()
     bad = []
-    for frag, (min_mfma, min_dma) in KERNELS.items():
+    table, MFMA = (KERNELS_F32, MFMA_F32) if "conv_igemm" in path else (KERNELS, MFMA_BF16)
+    for frag, (min_mfma, min_dma) in table.items():
         m = re.search(r"^(_ZN5mpgan\w*%s\w*):[^\n]*\n" % re.escape(frag), text, re.M)
         if not m:
             bad.append(f"{frag}: kernel not found in {path}")
@@ -62,7 +69,7 @@ def main(path):
         is_dma = lambda l: "global_load_lds_dwordx4" in l or ("buffer_load_dwordx4" in l and " lds" in l)
         for hdr, bl in loops.items():      # the smallest loop (with its nested ones) that holds both MFMAs and LDS-DMA loads
             lines = [l for b in bl for l in b["lines"]]
-            if any("v_mfma_f32_32x32x16_bf16" in l for l in lines) and any(is_dma(l) for l in lines) and \
+            if any(MFMA in l for l in lines) and any(is_dma(l) for l in lines) and \
                     (best is None or len(lines) < len(best)):
                 best = lines
         if best is None:
@@ -72,11 +79,15 @@ def main(path):
         if not any(re.search(r"s_waitcnt vmcnt\((?!0\))\d+\)", l) for l in body):
             bad.append(f"{frag}: no counted vmcnt wait in the kernel")
             continue
-        n_mfma = sum("v_mfma_f32_32x32x16_bf16" in l for l in loop)
+        n_mfma = sum(MFMA in l for l in loop)
         n_dma = sum("global_load_lds_dwordx4" in l or ("buffer_load_dwordx4" in l and " lds" in l) for l in loop)
         # (the kernel's own drain in front of its LAST tile carries a "; tail" comment)
         drains = [l.strip() for l in loop if "vmcnt(0)" in l and "; tail" not in l]
         scratch = [l.strip() for l in loop if l.strip().startswith("scratch_")]
+        tail = text[m.end():text.index(".end_amdhsa_kernel", m.end())]
+        priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", tail)
+        if priv and int(priv.group(1)) != 0:
+            bad.append(f"{frag}: {priv.group(1)} bytes of scratch per lane (a dynamically indexed kernel argument or a spill)")
         if drains:
             bad.append(f"{frag}: vmcnt(0) inside the K loop ({len(drains)}x): the LDS-DMA pipeline is serialised")
         if scratch:
@@ -92,4 +103,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1]))
+    sys.exit(max(main(p) for p in sys.argv[1:]))

@@ -15,7 +15,7 @@ int main() {
     int P = G + K - 1 - 2 * pd; if (P < 1) continue;
     int32_t gd[3] = {G, G + 1, G + 2}, pdh[3] = {P, P + 1, P + 2}, k[3] = {K, K, K}, s[3] = {1, 1, 1}, pad[3] = {pd, pd, pd};
     GatherConv p{};
-    build_transposed(p, 1, gd, 4, pdh, 4, k, s, pad);
+    build_transposed(p, 1, gd, 64, pdh, 64, k, s, pad);
     if (p.nphase > 1) used++;
     // every (produced pixel, tap) pair with an in-range gathered coordinate must be issued exactly once
     std::map<std::tuple<int,int,int,int,int,int>, int> seen;
@@ -31,6 +31,25 @@ int main() {
           if (iz != oz + pd - kz || iy != oy + pd - ky || ix != ox + pd - kx) bad++;
           seen[{oz, oy, ox, kz, ky, kx}]++;
         }
+    }
+    if (p.classes) {
+      // the packed work list (set_tile_grid + decode_block): every (phase, m-tile, n-tile, split) exactly once, rows dense
+      for (int bm : {128, 256, 512}) {
+        GatherConv q = p;
+        q.N = 3;
+        const long pairs = set_tile_grid(q, bm);
+        q.ntiles = 2; q.ksplit = 2;
+        if (pairs != phase_tile_rows(q, bm) || !q.packed) bad++;
+        std::map<std::tuple<int,int,int,int>, int> hit;
+        for (unsigned w = 0; w < (unsigned)(pairs * q.ntiles * q.ksplit); ++w) {
+          const BlockId b = decode_block(q, w);
+          const long tiles = ((long)q.N * q.ph[b.phase].Mz * q.ph[b.phase].My * q.ph[b.phase].Mx + bm - 1) / bm;
+          if (b.phase < 0 || b.phase >= q.nphase || b.mt < 0 || b.mt >= tiles || b.nt < 0 || b.nt >= 2 || b.split < 0 || b.split >= 2 ||
+              b.row != q.tile_start[b.phase] + b.mt || b.row >= pairs) bad++;
+          hit[{b.phase, b.mt, b.nt, b.split}]++;
+        }
+        if ((long)hit.size() != pairs * 4) bad++;
+      }
     }
     long want = 0;
     for (int oz = 0; oz < pdh[0]; ++oz) for (int oy = 0; oy < pdh[1]; ++oy) for (int ox = 0; ox < pdh[2]; ++ox)

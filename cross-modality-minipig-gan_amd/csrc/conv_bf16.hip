@@ -30,6 +30,16 @@ __device__ uint4 g_zero_page[16];   // 256 B of zeros: what a masked LDS-DMA gat
 __device__ int g_hb_dbg;            // MPGAN_DBG_HB what-if bits (development): 1 = gathers confined to a 64 KiB window,
                                     // 2 = no MFMAs, 4 = no fragment reads either, 8 = weights confined to 16 KiB,
                                     // 16 = no LDS-DMA (the contraction runs on whatever the LDS holds), 32 = no epilogue
+// The what-if tests exist in `make DEV=1 WHATIF=1` builds only: in the product build (and in plain DEV=1 builds, which
+// only add the routing switches) HB_DBG is the constant 0, the
+// tests fold away and the K loops are single basic blocks again (a runtime test around the fragment reads and another
+// around the MFMAs had split every k-sub into three blocks, which kept hipcc from placing the next k-sub's address
+// arithmetic under the MFMAs).
+#ifdef MPGAN_HB_WHATIF
+#define HB_DBG g_hb_dbg
+#else
+#define HB_DBG 0
+#endif
 
 // ---------------------------------------------------------------------------
 // Epilogue of the eight-wave kernels straight from the accumulators (round 3; the first version wrote the whole fp32
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_conv_bf16_kernel(const Gath
     fdivmod(q, ph.fMz, q, umz);
     const int bz = (int)umz * p.istride[0], by = (int)umy * p.istride[1], bx = (int)umx * p.istride[2];
     rbB[i] = (unsigned)((((int)q * Di + bz) * Hi + by) * Wi + bx) * (unsigned)ldi * 2u;
-    if (g_hb_dbg & 1) rbB[i] &= 0xFF80u;
+    if (HB_DBG & 1) rbB[i] &= 0xFF80u;
     if constexpr (MASK) {
       unsigned mk = 0;
       int j = 0;
@@ -221,9 +231,9 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_conv_bf16_kernel(const Gath
     int co = n0 + r0 + PR * i;
     co = co < Cout ? co : Cout - 1;                   // clamped columns are computed and dropped
     wrowB[i] = (unsigned)co * Ktot2;
-    if (g_hb_dbg & 8) wrowB[i] &= 0x3F80u;
+    if (HB_DBG & 8) wrowB[i] &= 0x3F80u;
   }
-  const int dbg = g_hb_dbg;
+  const int dbg = HB_DBG;
 
   // K order: channel-chunk major, taps inner (the taps that re-read an input element are then adjacent K-steps).
   // The tap walk is wave-uniform and lives in scalar registers: the K loop makes NO LDS access besides the
@@ -586,7 +596,7 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
       voffB[i] = (unsigned)co * Ktot2 + (unsigned)ck * 16u;
     }
   }
-  const int dbg = g_hb_dbg;
+  const int dbg = HB_DBG;
 
   // K order: channel-chunk major, taps inner.  The walk is wave-uniform and INCREMENTAL: the gathered operand's byte
   // offset and the weight offset of the next tap are the previous ones plus one of three precomputed steps (x, x-wrap,
@@ -1006,7 +1016,7 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
   char* const patch = lds;
   char* const bring = lds + HP_PATCH;
 
-  const int dbg = g_hb_dbg;                           // what-if bits as in the K-stepped kernels (2, 4, 16, 32)
+  const int dbg = HB_DBG;                           // what-if bits as in the K-stepped kernels (2, 4, 16, 32)
   auto issue_patch = [&](int chunk) {
     const unsigned ciB = (unsigned)(chunk * HB_BK + pck * 8) * 2u;
     if (!(dbg & 16))
@@ -1173,6 +1183,22 @@ static bool hp_ok(const GatherConv& p) {
          ph.My >= 2 * HP_TY && ph.Mx >= 2 * HP_TX;
 }
 
+// Patch form or K-stepped form?  With 128 produced channels (D.conv2's forward at C5) the 512 x 128 wide K-stepped
+// kernel is the faster one since round 3 (4.33 -> 3.74 ms at 126^3 bs 4, same box, gpurun_out/r4/conv2_whatif.txt: the
+// patch kernel's 64 x 64 wave tiles read four fragments per four MFMAs and its one block per CU leaves every tile's
+// patch fill and epilogue exposed); with 64 produced channels (the backward-data) only the narrow K-stepped kernel
+// exists (6.5 ms) and a patch form stays (the big-patch kernel below where it applies).  Decided on the COMPACT geometry so that the statistics-row query
+// and the launch agree (hb_dispatch refuses a pitched operand that changes the wide form's availability).
+static bool hp8_use(const GatherConv& p, bool with_stats);
+static bool hp_use(const GatherConv& p, bool with_stats) {
+  if (p.Cin % HB_BK != 0 || !hp_ok(p)) return false;
+  static const bool always = dev_env("MPGAN_DBG_HB_PATCH_ALWAYS") != nullptr;   // (A/B runs, make DEV=1)
+  if (always) return true;
+  GatherConv c = p;
+  c.ldi = c.Cin;
+  return !(p.Cout > 64 && hw_choice(c, with_stats) == 2);
+}
+
 static HpGrid hp_grid(const GatherConv& p) {
   const Phase& ph = p.ph[0];
   return HpGrid{(ph.Mz + HP_TZ - 1) / HP_TZ, (ph.My + HP_TY - 1) / HP_TY, (ph.Mx + HP_TX - 1) / HP_TX};
@@ -1208,12 +1234,319 @@ static int hp_launch(const GatherConv& p, hipStream_t st) {
   return check_launch("gather_patch_bf16");
 }
 
+// ---------------------------------------------------------------------------
+// Big-patch form (round 4): the same idea on an 8 x 8 x 8 output tile with 32-channel chunks.
+// What the round-4 what-if runs of the 4 x 8 x 8 kernel above said (gpurun_out/r4/conv2_whatif.txt, D.conv2 at 126^3
+// bs 4): its fragment reads + MFMAs alone, no DMA and no epilogue, take 3.18 ms of the 4.33 ms forward -- 54 % of the
+// matrix rate with nothing to wait for -- because a 64 x 64 wave tile issues four ds_read_b128 per four MFMAs, and the
+// 512 x 128 K-stepped kernel (128 x 64 per wave: six reads per eight MFMAs) already beats it on the forward (3.74 ms)
+// although it stages 2.1 x the bytes per FLOP.  This kernel combines the two: 512 tile rows give eight waves of
+// 128 x 64 (BN = 128) or 64 x 64 (BN = 64), the 10 x 10 x 10 patch of ONE 32-channel chunk is 1000 rows of 64 B
+// (1040 with the plane pitch padded to 104 rows, 65 KiB), weights stream through a three-stage ring in groups of
+// TPS taps (one barrier per 48 / 32 MFMAs of a wave).  LDS rows are 64 B = four 16-byte chunks; chunk c of row r sits
+// at c ^ ((r >> 2) & 3), so the 16 rows of a ds_read_b128 lane group (distinct mod 16, as above) cover the 64 banks
+// once.  Both operands come by buffer-load LDS-DMA: a per-thread voffset computed once (out-of-image patch rows and
+// the pad rows carry HW_OOB and read zeros), the chunk / tap walk in the scalar soffset -- no vector instruction per
+// piece.  A piece is a half line (64 B per pixel); at 400 FLOP per staged byte the fill this kernel needs (10 GB/s per
+// CU at half the matrix rate) is a quarter of what half-line pieces were measured to deliver (39 GB/s, round 3).
+// ---------------------------------------------------------------------------
+constexpr int H8_T = 8, H8_P = H8_T + 2;
+constexpr int H8_PZ = 104;                                     // plane pitch in rows: 100 -> 104 (= 8 mod 16)
+constexpr int H8_PROWS = H8_P * H8_PZ;                         // 1040 rows
+constexpr int H8_ROWB = 64, H8_BK = 32;
+constexpr int H8_PATCH = H8_PROWS * H8_ROWB;                   // 66,560 B
+constexpr int H8_PPIECES = (H8_PROWS + 127) / 128;             // rounds of 8 waves x 16 rows: 9 (the last: wave 0 only)
+constexpr int H8_BM = H8_T * H8_T * H8_T;                      // 512
+
+template <int BN>
+struct H8Tile {
+  static constexpr int WM = BN == 128 ? 4 : 8, WN = 8 / WM;
+  static constexpr int TM = H8_BM / WM / 32, TN = BN / WN / 32;        // 4 x 2 or 2 x 2 MFMA tiles per wave
+  static constexpr int TPS = BN == 128 ? 3 : 4;                        // taps per ring stage and barrier
+  static constexpr int NG = (27 + TPS - 1) / TPS;                      // 9 / 7 groups (the last of BN = 64 holds 3 taps)
+  static constexpr int BTAP = BN * H8_ROWB;
+  static constexpr int BSTAGE = TPS * BTAP;                            // 24 / 16 KiB
+  static constexpr int GP = BSTAGE / 8192;                             // LDS-DMA instructions per wave and group: 3 / 2
+  static constexpr int NR = 3;
+  static constexpr int SMEM_LOOP = H8_PATCH + NR * BSTAGE;             // 137 / 113 KiB
+  static constexpr int EP_ROWPIX = 8 * HbSlab<TN>::WAVE;
+  static constexpr int EP_PART = EP_ROWPIX + H8_BM * 4;
+  static constexpr int SMEM_EPI = EP_PART + WM * 2 * BN * 4;
+  static constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
+  static_assert(BSTAGE % 8192 == 0 && (BN == 128 || BN == 64), "whole DMA passes per group");
+};
+
+template <int BN>
+__global__ __launch_bounds__(512, 1) void gather_patch8_bf16_kernel(const GatherConv p, const HpGrid tg) {
+  using T = H8Tile<BN>;
+  constexpr int TM = T::TM, TN = T::TN, WN = T::WN, TPS = T::TPS, NG = T::NG, GP = T::GP, NR = T::NR;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const BlockId bid = conv_block_id(p);
+  const Phase& ph = p.ph[0];
+  const int n0 = bid.nt * BN;
+  const int stats_row = bid.mt;
+  const int Cout = p.Cout, Cin = p.Cin, Di = p.Di, Hi = p.Hi, Wi = p.Wi, ldi = p.ldi;
+  int t = bid.mt;
+  const int tx = t % tg.tiles_x; t /= tg.tiles_x;
+  const int ty = t % tg.tiles_y; t /= tg.tiles_y;
+  const int tz = t % tg.tiles_z;
+  const int n = t / tg.tiles_z;
+  const int oz0 = tz * H8_T, oy0 = ty * H8_T, ox0 = tx * H8_T;
+  // patch origin in the gathered tensor: the smallest coordinate any tap of the tile's first pixel reads
+  const int mnz = ph.dz0 + (p.dstep[0] < 0 ? 2 * p.dstep[0] : 0), mny = ph.dy0 + (p.dstep[1] < 0 ? 2 * p.dstep[1] : 0),
+            mnx = ph.dx0 + (p.dstep[2] < 0 ? 2 * p.dstep[2] : 0);
+  const int pz0 = oz0 + mnz, py0 = oy0 + mny, px0 = ox0 + mnx;
+  const unsigned Ktot2 = (unsigned)(p.Kz * p.Ky * p.Kx * Cin) * 2u;
+  const unsigned bytesA = (unsigned)((((long)p.N * Di * Hi * Wi - 1) * ldi + Cin) * 2);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, (unsigned)Cout * Ktot2, 0x00020000);
+
+  // ---- this thread's pieces: LDS row (tid >> 2) + 128 i, physical chunk tid & 3 = logical chunk ck ----
+  const int r0 = tid >> 2;
+  const int ck = (tid & 3) ^ ((r0 >> 2) & 3);                  // (128 i and the column-block offsets drop out of (row >> 2) & 3)
+  unsigned ppB[H8_PPIECES];                                    // byte offset of (patch pixel, channel 8 ck) or HW_OOB
+#pragma unroll
+  for (int i = 0; i < H8_PPIECES; ++i) {
+    const int pr = r0 + 128 * i;
+    const int pz = pr / H8_PZ, rem = pr - pz * H8_PZ;
+    const int py = rem / H8_P, px = rem - py * H8_P;
+    const int iz = pz0 + pz, iy = py0 + py, ix = px0 + px;
+    const bool ok = pr < H8_PROWS && rem < H8_P * H8_P && (unsigned)iz < (unsigned)Di && (unsigned)iy < (unsigned)Hi &&
+                    (unsigned)ix < (unsigned)Wi;
+    ppB[i] = ok ? (unsigned)(((n * Di + iz) * Hi + iy) * Wi + ix) * (unsigned)ldi * 2u + (unsigned)ck * 16u : HW_OOB;
+  }
+  // weights: flat row fr = r0 + 128 i of a group = (tap-in-group fr / BN, column fr % BN)
+  unsigned wvoff;                                               // (the same column for every i: 128 % BN == 0)
+  {
+    int co = n0 + (r0 % BN);
+    co = co < Cout ? co : Cout - 1;                             // clamped columns are computed and dropped
+    wvoff = (unsigned)co * Ktot2 + (unsigned)ck * 16u;
+  }
+  const int tapsel0 = BN == 128 ? 0 : (wid >> 2);               // BN = 64: a pass covers two taps, waves 4-7 the second
+  const int nchunk = Cin / H8_BK;
+  char* const patch = lds;
+  char* const bring = lds + H8_PATCH;
+  const int wrow = __builtin_amdgcn_readfirstlane(wid * 16 * H8_ROWB);
+  const int dbg = HB_DBG;
+
+  auto issue_patch = [&](int chunk) {
+    if (dbg & 16) return;
+#pragma unroll
+    for (int i = 0; i < H8_PPIECES; ++i)
+      if (i < H8_PPIECES - 1 || wid == 0) BLDS16(rsA, patch + wrow + 128 * i * H8_ROWB, ppB[i], chunk * (H8_BK * 2));
+  };
+  auto tap_woff = [&](int T_) {                                 // byte offset of tap number T_ (walk order, x fastest) in a weight row
+    const int Tc = T_ < 27 ? T_ : 26;                           // (dummy taps of the last group re-read the last one)
+    const int jz = Tc / 9, r9 = Tc - 9 * jz, jy = r9 / 3, jx = r9 - 3 * jy;
+    const int kz = ph.kz0 + p.kstep[0] * jz, ky = ph.ky0 + p.kstep[1] * jy, kx = ph.kx0 + p.kstep[2] * jx;
+    return ((kz * p.Ky + ky) * p.Kx + kx) * Cin * 2;
+  };
+  int gi = 0, gstage = 0;                                       // next group to issue, its ring stage
+  auto issue_group = [&](int chunk) {
+    if (!(dbg & 16)) {
+#pragma unroll
+      for (int i = 0; i < GP; ++i) {
+        const int tsel = BN == 128 ? i : 2 * i + tapsel0;
+        BLDS16(rsB, bring + gstage * T::BSTAGE + wrow + 128 * i * H8_ROWB, wvoff, tap_woff(gi * TPS + tsel) + chunk * (H8_BK * 2));
+      }
+    }
+    gi += 1;
+    gstage = gstage == NR - 1 ? 0 : gstage + 1;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // A fragments: tile row of lane li in wave tile tm -> its patch row at tap offset (0, 0, 0)
+  int abase[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    int z, y, x;
+    hp_row_pixel(wm * TM + tm, li, z, y, x);
+    abase[tm] = (z * H8_PZ + y * H8_P + x) * H8_ROWB;          // in bytes
+  }
+  const int bsw = (li >> 2) & 3;
+  const int brow = (wn * (BN / WN) + li) * H8_ROWB;
+  const unsigned lds_base = lds_addr(lds);
+  const unsigned ring_base = lds_base + H8_PATCH;
+  const int sx = p.dstep[2] < 0 ? -1 : 1, sy = p.dstep[1] < 0 ? -1 : 1, sz = p.dstep[0] < 0 ? -1 : 1;
+  const int delta0 = (p.dstep[0] < 0 ? 2 : 0) * H8_PZ + (p.dstep[1] < 0 ? 2 : 0) * H8_P + (p.dstep[2] < 0 ? 2 : 0);
+
+  i32x4 fa[2][TM], fb[2][TN];
+  auto read_frags = [&](int delta, int stage, int slot, int s, int set) {
+    if (dbg & 4) return;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const unsigned u = (unsigned)(abase[tm] + delta * H8_ROWB);          // byte offset of the patch row (delta: wave-uniform)
+      fa[set][tm] = lds_read_b128(lds_base + u + (((2 * s + lh) ^ ((u >> 8) & 3)) << 4));   // (row >> 2) & 3 = bits 8-9 of 64 row
+    }
+    const unsigned Bs = ring_base + stage * T::BSTAGE + slot * T::BTAP + brow + (((2 * s + lh) ^ bsw) << 4);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) fb[set][tn] = lds_read_b128(Bs + tn * 32 * H8_ROWB);
+  };
+  auto mfmas = [&](int set) {
+    if (dbg & 2) return;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][tm]),
+                                                              __builtin_bit_cast(bf16x8, fb[set][tn]), acc[tm][tn], 0, 0, 0);
+  };
+
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    // every wave is done with the previous chunk's patch and ring
+    asm volatile("s_waitcnt vmcnt(0) ; tail: chunk boundary" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    issue_patch(chunk);
+    gi = 0; gstage = 0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) issue_group(chunk);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NR - 1) * GP) : "memory");      // the patch + group 0 landed (this wave's part)
+    asm volatile("s_barrier" ::: "memory");
+    int cstage = 0, tin = 0;                            // ring stage of the current tap, its slot in it
+    int kx_ = 0, ky_ = 0;
+    int delta = delta0;
+    read_frags(delta, 0, 0, 0, 0);
+    for (int tap = 0; tap < 27; ++tap) {
+      const int nstage = cstage == NR - 1 ? 0 : cstage + 1;
+      const bool group_end = tin == TPS - 1 || tap == 26;
+      // next tap's patch offset (wave-uniform walk, x fastest)
+      int ndelta = delta;
+      {
+        int nx = kx_ + 1, ny = ky_, carry_y = 0;
+        if (nx == 3) { nx = 0; ny += 1; }
+        if (ny == 3) { ny = 0; carry_y = 1; }
+        ndelta += sx * (nx - kx_) + sy * (ny - ky_) * H8_P + sz * carry_y * H8_PZ;
+        kx_ = nx; ky_ = ny;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int set = s;
+        lds_wait<TM, TN>(fa[set], fb[set]);
+        if (s == 0) {
+          read_frags(delta, cstage, tin, 1, 1);
+        } else if (tap < 26) {
+          // ONE read site for both cases (the next tap of this stage, or the first tap of the next stage behind the
+          // barrier): see gather_patch_bf16_kernel
+          if (group_end) {
+            // group g+1 must have landed; behind it in flight: the groups up to min(g + NR - 1, NG - 1)
+            const int g = tap / TPS;
+            const int behind = (g + NR - 1 < NG - 1 ? g + NR - 1 : NG - 1) - (g + 1);
+            if (behind >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) ; tail: the last group" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+          }
+          read_frags(ndelta, group_end ? nstage : cstage, group_end ? 0 : tin + 1, 0, 0);
+          if (group_end && gi < NG) issue_group(chunk);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(set);
+      }
+      if (group_end) { cstage = nstage; tin = 0; } else tin += 1;
+      delta = ndelta;
+    }
+  }
+  asm volatile("s_barrier" ::: "memory");
+  if (dbg & 32) return;                               // (what-if: no epilogue)
+
+  // ---- epilogue from the accumulators (hb_epilogue): wave (wm, wn) holds tile rows 32 TM wm .. = sub-tiles TM wm ..
+  //      (hp_row_pixel) and columns wn * BN / WN .. ----
+  int* rowpix = reinterpret_cast<int*>(lds + T::EP_ROWPIX);
+  {
+    int z, y, x;
+    hp_row_pixel(tid >> 5, tid & 31, z, y, x);         // tile row tid = sub-tile (tid >> 5), MFMA row (tid & 31)
+    const int oz = oz0 + z, oy = oy0 + y, ox = ox0 + x;
+    rowpix[tid] = (oz < ph.Mz && oy < ph.My && ox < ph.Mx) ? ((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox : -1;
+  }
+  __syncthreads();
+  hb_epilogue<TM, TN, T::WM, BN>(acc, reinterpret_cast<float*>(lds + wid * HbSlab<TN>::WAVE), rowpix,
+                                 reinterpret_cast<float*>(lds + T::EP_PART), wm * TM * 32, wn * (BN / WN), n0 + wn * (BN / WN), wm,
+                                 p.bias, p.stats ? p.stats + (long)stats_row * 2 * Cout : nullptr, n0, Cout,
+                                 reinterpret_cast<char*>(p.out), p.ldo, tid, lane);
+}
+
+// 8 x 8 x 8 tiles pay on maps of at least 16 pixels per dimension whose extent wastes little in the last tile
+static bool hp8_ok(const GatherConv& p) {
+  static const bool off = dev_env("MPGAN_DBG_NO_HB_PATCH8") != nullptr;
+  if (off || !hp_ok(p) || p.Cin % H8_BK != 0) return false;
+  const Phase& ph = p.ph[0];
+  if (ph.Mz < 2 * H8_T || ph.My < 2 * H8_T || ph.Mx < 2 * H8_T) return false;
+  if ((long)p.N * p.Di * p.Hi * p.Wi * p.ldi * 2 >= (long)HW_OOB || (long)p.Cout * p.Cin * 27 * 2 >= (long)HW_OOB) return false;
+  // the last tile of a dimension may be partly empty: at most 10 % of the issued rows in all
+  const double used = (double)ph.Mz * ph.My * ph.Mx /
+                      ((double)((ph.Mz + 7) / 8 * 8) * ((ph.My + 7) / 8 * 8) * ((ph.Mx + 7) / 8 * 8));
+  return used >= 0.9 || p.min_blocks == 1;                 // (min_blocks = 1: the tests' way of running small shapes through the big-tile forms)
+}
+static HpGrid hp8_grid(const GatherConv& p) {
+  const Phase& ph = p.ph[0];
+  return HpGrid{(ph.Mz + H8_T - 1) / H8_T, (ph.My + H8_T - 1) / H8_T, (ph.Mx + H8_T - 1) / H8_T};
+}
+
+template <int BN>
+static int hp8_launch(const GatherConv& p, hipStream_t st) {
+  auto kern = gather_patch8_bf16_kernel<BN>;
+  constexpr int smem = H8Tile<BN>::SMEM;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      set_error("gather_patch8_bf16: hipFuncSetAttribute(%d): %s", smem, hipGetErrorString(e));
+      return MPGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  static int dbg_set = -1;
+  if (dbg_set < 0) {
+    const char* e = dev_env("MPGAN_DBG_HB");
+    dbg_set = e ? atoi(e) : 0;
+    if (dbg_set) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hb_dbg), &dbg_set, sizeof(int));
+  }
+  const HpGrid tg = hp8_grid(p);
+  GatherConv q = p;
+  q.packed = 0;
+  q.mtiles = p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x;
+  q.ntiles = (p.Cout + BN - 1) / BN;
+  q.phase_outer = 0;
+  q.ksplit = 1;
+  dim3 grid((unsigned)q.mtiles * q.ntiles);
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, q, tg);
+  return check_launch("gather_patch8_bf16");
+}
+
+// Routing between the forms is decided on the COMPACT geometry (pitch = channels), like hp_use
+// Measured at D.conv2's size (126^3 bs 4, product code, same box, gpurun_out/r4/conv2_patch8_b.txt; ms): 128 produced
+// channels (forward): 512 x 128 K-stepped 3.85, big patch 4.14, 4 x 8 x 8 patch 4.25; 64 produced channels
+// (backward-data; no wide K-stepped form exists): big patch 4.08, 4 x 8 x 8 patch 4.57-4.63.
+static bool hp8_use(const GatherConv& p, bool with_stats) {
+  GatherConv c = p;
+  c.ldi = c.Cin;
+  if (!hp8_ok(c)) return false;
+  static const bool always = dev_env("MPGAN_DBG_HB_PATCH_ALWAYS") != nullptr;   // (A/B runs, make DEV=1)
+  return always || !(p.Cout > 64 && hw_choice(c, with_stats) == 2);
+}
+
 static int hb_dispatch(const GatherConv& p, hipStream_t st, const char* what) {
   int rc = hb_check(p, what);
   if (rc) return rc;
   const long maxM = max_phase_pixels(p);
   if (maxM == 0) return MPGAN_OK;
-  if (hp_ok(p)) return p.Cout > 64 ? hp_launch<128>(p, st) : hp_launch<64>(p, st);
+  if (hp8_use(p, p.stats != nullptr)) {
+    MPGAN_UNSUPPORTED(!hp8_ok(p), "%s: the channel pitch of this operand takes it beyond the 32-bit offset range of the patch form "
+                      "the statistics rows were sized for: pass a compact tensor", what);
+    return p.Cout > 64 ? hp8_launch<128>(p, st) : hp8_launch<64>(p, st);
+  }
+  if (hp_use(p, p.stats != nullptr)) return p.Cout > 64 ? hp_launch<128>(p, st) : hp_launch<64>(p, st);
   const bool mask = !hb_all_in_range(p);
   const int wide = hw_choice(p, p.stats != nullptr);
   if (p.stats) {
@@ -2031,13 +2364,34 @@ static inline int hb_ew_blocks(long total) {
 
 using namespace mpgan;
 
+// Geometry of a bf16 gather.  A stride-1 transposed gather (backward-data of a conv) is first built as ONE phase: the
+// patch kernels stage out-of-image rows as zeros once per tile and have no use for border classes; only when neither
+// patch form serves it is it rebuilt with them (conv_geom.h) for the K-stepped kernels.
+static void build_gather_bf16(GatherConv& p, const mpgan_conv_geom* g, bool backward_data) {
+  const bool fwd_type = backward_data ? g->transposed != 0 : g->transposed == 0;
+  const int32_t *gd = backward_data ? g->out_dhw : g->in_dhw, *pd = backward_data ? g->in_dhw : g->out_dhw;
+  const int cg = backward_data ? g->cout : g->cin, cp = backward_data ? g->cin : g->cout;
+  if (fwd_type) {
+    build_forward(p, g->n, gd, cg, pd, cp, g->k, g->stride, g->pad);
+    return;
+  }
+  build_transposed(p, g->n, gd, cg, pd, cp, g->k, g->stride, g->pad, false);
+  GatherConv c = p;
+  c.ldi = c.Cin;
+  if (c.Cin % HB_BK == 0 && (hp8_ok(c) || hp_ok(c))) return;
+  build_transposed(p, g->n, gd, cg, pd, cp, g->k, g->stride, g->pad, true);
+}
+
 extern "C" int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g) {
   if (check_geom(g)) return -1;
   GatherConv p{};
   set_geom_flags(p, g);
-  if (!g->transposed) build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
-  else build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
-  if (g->cin % HB_BK == 0 && hp_ok(p)) {     // patch form: one row per 4 x 8 x 8 tile
+  build_gather_bf16(p, g, false);
+  if (hp8_use(p, true)) {    // big-patch form: one row per 8 x 8 x 8 tile
+    const HpGrid tg = hp8_grid(p);
+    return p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x;
+  }
+  if (hp_use(p, true)) {     // patch form: one row per 4 x 8 x 8 tile
     const HpGrid tg = hp_grid(p);
     return p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x;
   }
@@ -2048,19 +2402,18 @@ extern "C" int32_t mpgan_conv_stats_rows_bf16(const mpgan_conv_geom* g) {
 
 // Which bf16 kernel serves this geometry (profiling labels): 0 = K-stepped gather_conv_bf16_kernel,
 // 1 = gather_patch_bf16_kernel (stride-1 3x3x3 gathers), 2 / 3 / 4 = gather_conv_bf16_wide_kernel 256 x 256 / 512 x 128 /
-// 256 x 256 over phase pairs.
+// 256 x 256 over phase pairs, 5 = gather_patch8_bf16_kernel (stride-1 3x3x3 gathers on maps of >= 16 pixels per dimension).
 extern "C" int32_t mpgan_conv_variant_bf16(const mpgan_conv_geom* g, int32_t backward_data) {
   if (check_geom(g)) return -1;
   GatherConv p{};
   set_geom_flags(p, g);
   if (!backward_data) {
-    if (!g->transposed) build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
-    else build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+    build_gather_bf16(p, g, false);
   } else {
-    if (!g->transposed) build_transposed(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
-    else build_forward(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
+    build_gather_bf16(p, g, true);
   }
-  if (p.Cin % HB_BK == 0 && hp_ok(p)) return 1;
+  if (hp8_use(p, !backward_data)) return 5;
+  if (hp_use(p, !backward_data)) return 1;
   p.ldi = p.Cin;
   const int wide = p.Cin % HB_BK == 0 ? hw_choice(p, !backward_data) : 0;
   return wide ? 1 + wide : 0;
@@ -2078,8 +2431,7 @@ extern "C" int mpgan_conv_forward_bf16(const mpgan_conv_geom* g, const void* x, 
   p.pro = make_pro(nullptr);
   p.ldi = ldx; p.ldo = ldy;
   set_geom_flags(p, g);
-  if (!g->transposed) build_forward(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
-  else build_transposed(p, g->n, g->in_dhw, g->cin, g->out_dhw, g->cout, g->k, g->stride, g->pad);
+  build_gather_bf16(p, g, false);
   return hb_dispatch(p, (hipStream_t)stream, "conv_forward_bf16");
 }
 
@@ -2094,8 +2446,7 @@ extern "C" int mpgan_conv_backward_data_bf16(const mpgan_conv_geom* g, const voi
   p.pro = make_pro(nullptr);
   p.ldi = lddy; p.ldo = lddx;
   set_geom_flags(p, g);
-  if (!g->transposed) build_transposed(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
-  else build_forward(p, g->n, g->out_dhw, g->cout, g->in_dhw, g->cin, g->k, g->stride, g->pad);
+  build_gather_bf16(p, g, true);
   return hb_dispatch(p, (hipStream_t)stream, "conv_backward_data_bf16");
 }
 

@@ -206,7 +206,7 @@ inline void build_forward(GatherConv& p, int n, const int32_t* gath_dhw, int cg,
 
 // transposed-type gather: produced[o] = sum_k gathered[(o + p - k)/s] * W[k]
 inline void build_transposed(GatherConv& p, int n, const int32_t* gath_dhw, int cg, const int32_t* prod_dhw, int cp,
-                             const int32_t* k, const int32_t* s, const int32_t* pad) {
+                             const int32_t* k, const int32_t* s, const int32_t* pad, bool classes_ok = true) {
   p.N = n; p.Di = gath_dhw[0]; p.Hi = gath_dhw[1]; p.Wi = gath_dhw[2]; p.Cin = cg;
   p.Do = prod_dhw[0]; p.Ho = prod_dhw[1]; p.Wo = prod_dhw[2]; p.Cout = cp;
   p.Kz = k[0]; p.Ky = k[1]; p.Kx = k[2];
@@ -221,7 +221,7 @@ inline void build_transposed(GatherConv& p, int n, const int32_t* gath_dhw, int 
   // Only where the K-stepped kernels serve the gather (>= 64 channels on both sides): the patch kernels stage the
   // padding as zeros once per tile and need one phase.
   p.classes = 0;
-  if (s[0] == 1 && s[1] == 1 && s[2] == 1 && cg >= 64 && cp >= 64) {
+  if (classes_ok && s[0] == 1 && s[1] == 1 && s[2] == 1 && cg >= 64 && cp >= 64) {
     int nc[3], lo[3][3], hi[3][3], k0c[3][3], njc[3][3];
     double real = 1.0, issued = 1.0, issued_cls = 1.0;
     for (int d = 0; d < 3; ++d) {

@@ -1402,6 +1402,8 @@ def _bf16_kernel_name(g: ConvGeom, backward_data: bool) -> str:
     v = lib().mpgan_conv_variant_bf16(C.byref(gc), int(backward_data))
     if v == 1:
         return f"gather_patch_bf16_kernel<{bn}>"
+    if v == 5:
+        return f"gather_patch8_bf16_kernel<{bn}>"
     if v in (2, 3, 4):
         masked = "true" if backward_data or any(g.pad) else "false"
         return f"gather_conv_bf16_wide_kernel<{'4, 2' if v == 3 else '2, 4'}, {masked}, true, {'true' if v == 4 else 'false'}>"

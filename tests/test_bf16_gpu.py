@@ -172,12 +172,48 @@ def test_wide_forms_backward_data_bf16(wide_forms, n, spatial, cin, cout, k, s, 
     test_conv_backward_data_and_weight_bf16(n, spatial, cin, cout, k, s, p)
 
 
+PATCH8_CASES = [  # stride-1 3x3x3 gathers on maps of >= 16 pixels per dimension: gather_patch8_bf16_kernel (8 x 8 x 8 tiles)
+    (1, (20, 22, 27), 64, 128, 3, 1, 0),      # produced 18 x 20 x 25: ragged last tile in every dimension; forward on 128 columns
+                                              # (two 32-channel chunks), backward-data on 64 columns (four chunks, reversed taps)
+    (2, (18, 17, 19), 128, 64, 3, 1, 1),      # padded: patch rows outside the image read zeros; two samples
+]
+
+
+@pytest.mark.parametrize("n,spatial,cin,cout,k,s,p", PATCH8_CASES, ids=lambda v: str(v))
+def test_big_patch_form_bf16(wide_forms, n, spatial, cin, cout, k, s, p):
+    """Forward (with fused statistics rows, one per tile), backward-data and -- for the pad-free case -- the weight gradient
+    of the same layer: exact on sparse integers (pins the 64-byte-row swizzle, the tap walk in both directions, the
+    group ring and the out-of-image zeros), 4e-3 on random bf16 data."""
+    from mpgan_amd._lib import lib
+    import ctypes as C
+    g = _geom(n, spatial, cin, cout, k, s, p)
+    gc = g.c()
+    # (with min_blocks = 1 the 512 x 128 K-stepped form takes the launches that produce 128 channels, as it does at D.conv2's size)
+    v = [lib().mpgan_conv_variant_bf16(C.byref(gc), b) for b in (0, 1)]
+    assert v == ([3, 5] if cout > 64 else [5, 3]), v
+    test_conv_forward_bf16_exact_and_random(n, spatial, cin, cout, k, s, p)
+    test_conv_backward_data_and_weight_bf16(n, spatial, cin, cout, k, s, p)
+
+
+def test_big_patch_form_128_columns_bf16():
+    """gather_patch8_bf16_kernel<128> (eight waves of 128 x 64): a forward whose 512-row tiles are too few for the wide
+    K-stepped form and waste nothing (16 x 16 x 24 produced pixels)."""
+    from mpgan_amd._lib import lib
+    import ctypes as C
+    case = (1, (18, 18, 26), 64, 128, 3, 1, 0)
+    gc = _geom(*case).c()
+    assert lib().mpgan_conv_variant_bf16(C.byref(gc), 0) == 5
+    test_conv_forward_bf16_exact_and_random(*case)
+
+
 def test_wide_forms_serve_config_c5_by_default():
     """D.conv3 / D.conv4 at 128^3 bs 4: forward of conv3 and backward-data of conv4 on 256 x 256 tiles, backward-data of
     conv3 (128 produced channels, eight congruent phases) on 256 x 256 tiles over phase pairs."""
     from mpgan_amd import ops
     from mpgan_amd._lib import lib
     import ctypes as C
+    g2 = ops.ConvGeom(4, (126, 126, 126), 64, 128, (3, 3, 3), (1, 1, 1), (0, 0, 0)).c()      # D.conv2: 512 x 128 K-stepped / big patch
+    assert [lib().mpgan_conv_variant_bf16(C.byref(g2), b) for b in (0, 1)] == [3, 5]
     for (cin, cout, e), want in (((128, 256, 124), (2, 4)), ((256, 256, 61), (None, 2))):
         g = ops.ConvGeom(4, (e, e, e), cin, cout, (4, 4, 4), (2, 2, 2), (0, 0, 0))
         gc = g.c()

@@ -133,8 +133,16 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
         e_ours, cost, e_64, y_64 = (_rel(gg[name], p.grad), _rel(p.grad, pp[name].grad), _rel(gg[name], p64[name].grad),
                                     _rel(p.grad, p64[name].grad))
         errs[name] = (e_ours, cost, e_64, y_64)
-        if e_ours > 2 * cost + 2e-2:
-            bad.append((name, e_ours, cost))
+        # Rule (round 4, second version): the fp64 yardstick of the fp32 tests -- ours no further from the contract
+        # evaluated with fp64 accumulation than torch's fp32 evaluation of the same contract, x 3.  The first version,
+        # err(ours, emulation) <= 2 cost + 2e-2 with cost = emulation vs the generator WITHOUT the contract, failed on
+        # one tensor when the discriminator's kernels changed their summation order (the bottom residual conv's bias
+        # of U-Net 4 -- a sum over 1,458 pixels of a gradient that nearly cancels: 0.3227 against 2 x 0.1478 + 0.02,
+        # profiles/r04_testlogs/t_all2.log; the generator's kernels and its forward, 5.0e-5 from the emulation, had
+        # not changed).  `cost` measures what rounding the OPERANDS costs, not how far two fp32 summation orders of the
+        # rounded operands may sit apart; err(emulation f32, emulation f64) measures exactly that.
+        if e_64 > 3 * y_64 + 2e-2:
+            bad.append((name, e_ours, cost, e_64, y_64))
     flat_o = torch.cat([gg[k].reshape(-1) for k in rp])
     flat_r = torch.cat([p.grad.reshape(-1) for p in rp.values()])
     flat_p = torch.cat([pp[k].grad.reshape(-1) for k in rp])
@@ -145,6 +153,7 @@ def test_c5_step_bf16_storage_against_emulation_and_oracle():
           ", emulation-f32 vs -f64", _rel(flat_r, flat_64), "; worst tensors (ours vs emul, cost, ours vs f64, emul vs f64)", worst)
     assert not bad, sorted(bad, key=lambda r: -r[1])[:6]
     assert _rel(flat_o, flat_r) <= 2 * _rel(flat_r, flat_p) + 2e-2
+    assert _rel(flat_o, flat_64) <= 1.5 * _rel(flat_r, flat_64) + 1e-2      # the whole gradient: as accurate as torch's fp32 run
     slopes = {k: (gg[k].item(), p.grad.item(), pp[k].grad.item()) for k, p in rp.items() if p.numel() == 1}
     smax = max(abs(w) for _, w, _ in slopes.values())
     for k, (gv, we, wp) in slopes.items():

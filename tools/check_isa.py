@@ -24,6 +24,8 @@ KERNELS = {   # mangled-name fragment -> (min MFMAs, min LDS-DMA loads) in the K
     "gather_conv_bf16_kernelILi64ELb1ELi8": (8, 5),
     "gather_patch_bf16_kernelILi128": (16, 2),            # patch form: weights only stream inside the tap loop
     "gather_patch_bf16_kernelILi64": (8, 1),
+    "gather_patch8_bf16_kernelILi128": (16, 3),           # big-patch form: a tap = two k-subs of 8 (4) MFMAs, one group of weights
+    "gather_patch8_bf16_kernelILi64": (8, 2),
     "gather_conv_bf16_wide_kernelILi2ELi4ELb0ELb1ELb0": (32, 8),   # wide form <WM, WN, MASK, RING, PAIR>: 128 x 64 per wave
     "gather_conv_bf16_wide_kernelILi2ELi4ELb1ELb1ELb0": (32, 8),
     "gather_conv_bf16_wide_kernelILi2ELi4ELb0ELb1ELb1": (32, 8),   # ... over phase pairs

@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
 PEAK_BF16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak
-DOMINANT = "gather_conv_pipe_kernel<128, 2, 2, 2, 1, 3, true, 1>"   # as rocprofv3 names it (D's dense layers, forward)
+DOMINANT = "gather_conv_pipe_kernel<128, 2, 2, 2, 1, 3, true, 1, false>"   # as rocprofv3 names it (D's dense layers, forward)
 DENSE_MIN_GFLOP = 20.0            # per launch: D's conv2/3/4 in all three directions, nothing of G
 HEAD_WEIGHT_SCALE = 0.02          # see main(): keeps the 952,576-input head out of sigmoid saturation
 

@@ -295,10 +295,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gather_conv_bf16_kernel(const Gath
   auto read_frags = [&](int stage, int s, int set) {
     const unsigned As = lds_base + stage * T::STAGE + arow;
     const unsigned Bs = lds_base + stage * T::STAGE + brow;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) fa[set][tm] = lds_read_b128(As + tm * 32 * HB_ROWB + foff[s]);
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) fb[set][tn] = lds_read_b128(Bs + tn * 32 * HB_ROWB + foff[s]);
+    lds_read_b128_n<TM, 32 * HB_ROWB>(fa[set], As + foff[s]);
+    lds_read_b128_n<TN, 32 * HB_ROWB>(fb[set], Bs + foff[s]);
   };
   if (nk > 0) issue();
   if (nk > 1) issue();
@@ -691,10 +689,8 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
   auto read_frags = [&](int unitA, int unitB, int s, int set) {
     const unsigned As = lds_base + unitA + arow + foff[s];
     const unsigned Bs = lds_base + unitB + brow + foff[s];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) fa[set][tm] = lds_read_b128(As + tm * 32 * HW_ROWB);
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) fb[set][tn] = lds_read_b128(Bs + tn * 32 * HW_ROWB);
+    lds_read_b128_n<TM, 32 * HW_ROWB>(fa[set], As);
+    lds_read_b128_n<TN, 32 * HW_ROWB>(fb[set], Bs);
   };
   auto mfmas = [&](int set) {
     if (!(dbg & 2))
@@ -1098,8 +1094,7 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
         fa[set][tm] = lds_read_b128(lds_base + pr * HB_ROWB + (((2 * s + lh) ^ ((pr >> 1) & 7)) << 4));
       }
       const unsigned Bs = ring_base + stage * T::BSTAGE + slot * T::BTAP + brow;
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) fb[set][tn] = lds_read_b128(Bs + tn * 32 * HB_ROWB + foff[s]);
+      lds_read_b128_n<TN, 32 * HB_ROWB>(fb[set], Bs + foff[s]);
     };
     int delta = tzo * HP_PZ + tyo * HP_PX + txo;
     read_frags(delta, 0, 0, 0, 0);
@@ -1383,16 +1378,24 @@ __global__ __launch_bounds__(512, 1) void gather_patch8_bf16_kernel(const Gather
   const int delta0 = (p.dstep[0] < 0 ? 2 : 0) * H8_PZ + (p.dstep[1] < 0 ? 2 : 0) * H8_P + (p.dstep[2] < 0 ? 2 : 0);
 
   i32x4 fa[2][TM], fb[2][TN];
+  unsigned acur[TM];                                   // this tap's A fragment addresses of k-sub 0
   auto read_frags = [&](int delta, int stage, int slot, int s, int set) {
     if (dbg & 4) return;
+    // k-sub 1's chunk is k-sub 0's with bit 1 flipped, and the swizzle is an XOR: its address is k-sub 0's ^ 32
+    // (one vector instruction per fragment instead of the four that form k-sub 0's)
+    if (s == 0) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const unsigned u = (unsigned)(abase[tm] + delta * H8_ROWB);          // byte offset of the patch row (delta: wave-uniform)
-      fa[set][tm] = lds_read_b128(lds_base + u + (((2 * s + lh) ^ ((u >> 8) & 3)) << 4));   // (row >> 2) & 3 = bits 8-9 of 64 row
+      for (int tm = 0; tm < TM; ++tm) {
+        const unsigned u = (unsigned)(abase[tm] + delta * H8_ROWB);        // byte offset of the patch row (delta: wave-uniform)
+        acur[tm] = lds_base + u + ((lh ^ ((u >> 8) & 3)) << 4);            // (row >> 2) & 3 = bits 8-9 of 64 row
+        fa[set][tm] = lds_read_b128(acur[tm]);
+      }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) fa[set][tm] = lds_read_b128(acur[tm] ^ 32u);
     }
     const unsigned Bs = ring_base + stage * T::BSTAGE + slot * T::BTAP + brow + (((2 * s + lh) ^ bsw) << 4);
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) fb[set][tn] = lds_read_b128(Bs + tn * 32 * H8_ROWB);
+    lds_read_b128_n<TN, 32 * H8_ROWB>(fb[set], Bs);
   };
   auto mfmas = [&](int set) {
     if (dbg & 2) return;

@@ -479,10 +479,8 @@ __global__ __launch_bounds__(256) void gather_conv_dma_kernel(const GatherConv p
   i32x4 fa[2][TM], fb[2][TN];
   auto read_group = [&](int stage, int g, int slot) {
     const unsigned As = lds_base + stage + arow + foff[g], Bs = lds_base + stage + brow + foff[g];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) fa[slot][tm] = lds_read_b128(As + tm * 32 * ROWB);
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) fb[slot][tn] = lds_read_b128(Bs + tn * 32 * ROWB);
+    lds_read_b128_n<TM, 32 * ROWB>(fa[slot], As);
+    lds_read_b128_n<TN, 32 * ROWB>(fb[slot], Bs);
   };
   constexpr int NL = AP + BP;
   // wait until at most t tiles' worth of this wave's DMAs are outstanding (t < NST is block-uniform)

@@ -22,6 +22,17 @@ __device__ __forceinline__ i32x4 lds_read_b128(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
   return v;
 }
+// N reads at addr, addr + STRIDE, ...: the stride goes into the instruction's 16-bit offset field, so the N addresses
+// cost one address register instead of N vector adds (the asm operand must be a register, and hipcc cannot fold an
+// addition into an asm statement's offset field by itself).
+template <int N, int STRIDE, int I = 0>
+__device__ __forceinline__ void lds_read_b128_n(i32x4 (&dst)[N], unsigned addr) {
+  static_assert((N - 1) * STRIDE < 65536, "ds_read_b128 offset field");
+  if constexpr (I < N) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[I]) : "v"(addr), "n"(I * STRIDE));
+    lds_read_b128_n<N, STRIDE, I + 1>(dst, addr);
+  }
+}
 __device__ __forceinline__ i32x2 lds_read_tr16_b64(unsigned addr) {
   i32x2 v;
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));

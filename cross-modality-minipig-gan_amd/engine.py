@@ -273,7 +273,7 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
     if v == 2:
         return "thin_cout1_kernel"
     if v == 18:
-        return f"gather_patch3d_c16_kernel<{'true' if has_pro else 'false'}>"
+        return f"gather_patch3d_c16_kernel<{'true' if has_pro else 'false'}, {'true' if g.mm_bf16 else 'false'}>"
     cin_eff = g.cout if backward_data else g.cin
     if v in (16, 17):
         cout_eff = g.cin if backward_data else g.cout
@@ -285,7 +285,7 @@ def gather_kernel_name(g: ConvGeom, backward_data: bool, has_pro: bool, per_samp
     if cin_eff % 32 == 0 or cin_eff == 16:      # software-pipelined main kernel <BN, TM, TN, WN, WRAPS, PRO>
         pro = 0 if not has_pro else (2 if per_sample_norm else (3 if fast_leaky else 1))
         return (f"gather_conv_pipe_kernel<{v}, {tm}, {tn}, {wn}, {1 if cin_eff % 32 == 0 else 2}, {pro}, "
-                f"{'true' if fast else 'false'}, {2 if ks2 else 1}>")
+                f"{'true' if fast else 'false'}, {2 if ks2 else 1}, {'true' if g.mm_bf16 else 'false'}>")
     return f"gather_conv_kernel<{v}, {tm}, {tn}, {wn}, {'false' if cin_eff % 4 == 0 else 'true'}>"
 
 

@@ -1,12 +1,13 @@
 #!/bin/bash
-# Round-3 evidence for profiles/ -- run on the GPU box as:  gpurun -- 'bash tools/collect_profiles.sh [part]'
-# (parts: a = bench + kernel stats, b = counters, c = C5 + variant B + tables; no argument = all; one gpurun call each
+# Round-4 evidence for profiles/ -- run on the GPU box as:  gpurun -- 'bash tools/collect_profiles.sh [part]'
+# (parts: b = counters FIRST -- tools/publish_profiles.sh turns them into profiles/traffic*.json, which the bench lines of
+#  parts a and c then carry --, a = bench + kernel stats, c = C5 + variant B + tables, d = inference; one gpurun call per part
 #  keeps a call inside its time limit).  Every rocprofv3 run has the program directly after `--`; counters are
 #  collected in passes of their own (--kernel-trace --pmc only).
 set -eo pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r03
-PART=${1:-abc}
+O=$R/gpurun_out/r04
+PART=${1:-bacd}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
@@ -37,6 +38,9 @@ echo "[b3] SQ counters: D's dense kernels, the generator's kernels (forward + ba
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/pmc_sq -- python3 $R/tools/bench_conv.py --layers D.conv2,D.conv3,D.conv4 --modes fwd,dgrad,wgrad --pro --reps 2 > $O/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/pmc_sq_g -- python3 $R/tools/gfwd_loop.py --reps 2 --backward > $O/pmc_sq_g.log 2>&1
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/pmc_sq_bf16 -- python3 $R/tools/bench_bf16.py --reps 2 > $O/pmc_sq_bf16.log 2>&1
+echo "[b4] PMC FETCH_SIZE / WRITE_SIZE, C5 bf16"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_c5_fetch -- python3 $R/bench.py --dims 3 --size 128 --batch 4 --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-gfwd --no-phases > $O/pmc_c5_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_c5_write -- python3 $R/bench.py --dims 3 --size 128 --batch 4 --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-gfwd --no-phases > $O/pmc_c5_write.log 2>&1
 fi
 if [[ $PART == *c* ]]; then
 echo "[c1] C5: bf16 storage 3-D line + kernel stats"
@@ -51,8 +55,9 @@ echo "[c3] variant B at the reference's scale: wall time, kernel stats, per-fami
 python3 $R/tools/bench_variant_b.py --batch 7 --steps 3 > $O/variant_b_bs7.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_vb -- python3 $R/tools/bench_variant_b.py --batch 7 --steps 3 > $O/stats_vb.log 2>&1
 python3 $R/tools/bench_variant_b.py --batch 7 --steps 2 --families > $O/variant_b_families.txt 2>&1
-echo "[c4] PMC FETCH_SIZE / WRITE_SIZE, C5 bf16"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_c5_fetch -- python3 $R/bench.py --dims 3 --size 128 --batch 4 --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-gfwd --no-phases > $O/pmc_c5_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_c5_write -- python3 $R/bench.py --dims 3 --size 128 --batch 4 --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-gfwd --no-phases > $O/pmc_c5_write.log 2>&1
+fi
+if [[ $PART == *d* ]]; then
+echo "[d1] N1: eval-mode generator forward (eager, HIP graph, train mode)"
+python3 $R/tools/bench_infer.py > $O/infer.txt 2>&1
 fi
 echo done

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Copy the summaries of the newest tools/collect_profiles.sh run (gpurun_out/r03/) into profiles/ (tracked).
+# Copy the summaries of the newest tools/collect_profiles.sh run (gpurun_out/r04/) into profiles/ (tracked).
 set -eo pipefail
 cd "$(dirname "$0")/.."
-P=gpurun_out/r03
-T=r03
+P=gpurun_out/r04
+T=r04
 newest() { ls -t $1 | head -1; }
 have() { ls $1 > /dev/null 2>&1; }
 if have "$P/bench_default.log"; then cp $P/bench_default.log profiles/${T}_bench_default.log; fi
@@ -16,7 +16,7 @@ for tag in default single gfwd gbwd c5_bf16 vb; do
     cp "$(newest "$P/stats_$tag/runc/*_kernel_stats.csv")" profiles/${T}_${name}_kernel_stats.csv
   fi
 done
-for f in phase_times phase_times_gbwd_calls kernel_phases_gfwd kernel_phases_gbwd layer_bench layer_bench_bf16 variant_b_bs7 variant_b_families c5_gfwd_calls c5_gbwd_calls; do
+for f in phase_times phase_times_gbwd_calls kernel_phases_gfwd kernel_phases_gbwd layer_bench layer_bench_bf16 variant_b_bs7 variant_b_families c5_gfwd_calls c5_gbwd_calls infer; do
   if have "$P/$f.txt"; then grep -v "amdgpu.ids\|RuntimeWarning\|mean = lambda" $P/$f.txt > profiles/${T}_$f.txt; fi
 done
 if have "$P/bench_c5_bf16.json"; then cat $P/bench_c5_bf16.err $P/bench_c5_bf16.json > profiles/${T}_bench_c5_bf16.log; fi

@@ -1727,25 +1727,28 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_bf16_kernel(const WgradHb p)
   const unsigned lds_base = lds_addr(lds);
   // (pipeline as in gather_conv_bf16_kernel: the K-step's barrier sits in front of its last k-sub's MFMAs)
   i32x2 fa[2][2 * TM], fb[2][2 * TN];                     // [set][2*tile + half]
-  auto read_frags = [&](int stage, int s, int set) {
+  // fragment addresses of the stage being read, formed once per K-step (the k-sub sits in the read's offset field)
+  unsigned pa[2 * TM], pb[2 * TN];
+  auto set_bases = [&](int stage) {
     const unsigned S = lds_base + stage * WH_STAGE;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      fa[set][2 * tm] = lds_read_tr16_b64(S + s * 16 * 256 + aoff[tm][0]);
-      fa[set][2 * tm + 1] = lds_read_tr16_b64(S + s * 16 * 256 + aoff[tm][1]);
-    }
+    for (int tm = 0; tm < TM; ++tm) { pa[2 * tm] = S + aoff[tm][0]; pa[2 * tm + 1] = S + aoff[tm][1]; }
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      fb[set][2 * tn] = lds_read_tr16_b64(S + s * 16 * 256 + boff[tn][0]);
-      fb[set][2 * tn + 1] = lds_read_tr16_b64(S + s * 16 * 256 + boff[tn][1]);
-    }
+    for (int tn = 0; tn < TN; ++tn) { pb[2 * tn] = S + boff[tn][0]; pb[2 * tn + 1] = S + boff[tn][1]; }
+  };
+  auto read_frags = [&](int s, int set) {
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i) fa[set][i] = lds_read_tr16_ksub(pa[i], s);
+#pragma unroll
+    for (int i = 0; i < 2 * TN; ++i) fb[set][i] = lds_read_tr16_ksub(pb[i], s);
   };
   if (nk > 0) issue();
   if (nk > 1) issue();
   if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
-  if (nk > 0) read_frags(0, 0, 0);
+  set_bases(0);
+  if (nk > 0) read_frags(0, 0);
   if (nk > 2) issue();
   int cstage = 0;
   for (int kt = 0; kt < nk; ++kt) {
@@ -1755,12 +1758,13 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_bf16_kernel(const WgradHb p)
       const int set = s & 1;
       lds_wait<2 * TM, 2 * TN>(fa[set], fb[set]);
       if (s < 3) {
-        read_frags(cstage, s + 1, set ^ 1);
+        read_frags(s + 1, set ^ 1);
       } else if (kt + 1 < nk) {
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) ; tail: the last tile" ::: "memory");      // (tools/check_isa.py)
         asm volatile("s_barrier" ::: "memory");
-        read_frags(nstage, 0, 0);
+        set_bases(nstage);
+        read_frags(0, 0);
         if (kt + 3 < nk) issue();
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1933,18 +1937,20 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_wide_kernel(const WgradHb p
   }
   const unsigned lds_base = lds_addr(lds);
   i32x2 fa[2][2 * TM], fb[2][2 * TN];                     // [set][2*tile + half]
-  auto read_frags = [&](int unitD, int unitG, int s, int set) {
-    const unsigned D = lds_base + unitD + s * 16 * 256, G = lds_base + unitG + s * 16 * 256;
+  // fragment addresses of the units being read, formed once per K-step (the k-sub sits in the read's offset field)
+  unsigned pa[2 * TM], pb[2 * TN];
+  auto set_bases = [&](int unitD, int unitG) {
+    const unsigned D = lds_base + unitD, G = lds_base + unitG;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      fa[set][2 * tm] = lds_read_tr16_b64(D + aoff[tm][0]);
-      fa[set][2 * tm + 1] = lds_read_tr16_b64(D + aoff[tm][1]);
-    }
+    for (int tm = 0; tm < TM; ++tm) { pa[2 * tm] = D + aoff[tm][0]; pa[2 * tm + 1] = D + aoff[tm][1]; }
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      fb[set][2 * tn] = lds_read_tr16_b64(G + boff[tn][0]);
-      fb[set][2 * tn + 1] = lds_read_tr16_b64(G + boff[tn][1]);
-    }
+    for (int tn = 0; tn < TN; ++tn) { pb[2 * tn] = G + boff[tn][0]; pb[2 * tn + 1] = G + boff[tn][1]; }
+  };
+  auto read_frags = [&](int s, int set) {
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i) fa[set][i] = lds_read_tr16_ksub(pa[i], s);
+#pragma unroll
+    for (int i = 0; i < 2 * TN; ++i) fb[set][i] = lds_read_tr16_ksub(pb[i], s);
   };
   // ring: units G_0 D_0 G_1 D_1 G_2 | D_2 G_3 D_3 ... in slots u % 5 (gather_conv_bf16_wide_kernel)
   constexpr int U = WW_UNIT;
@@ -1958,7 +1964,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_wide_kernel(const WgradHb p
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     int ug = 0, ud = U;
-    read_frags(ud, ug, 0, 0);
+    set_bases(ud, ug);
+    read_frags(0, 0);
     bool pend_d = false, pend_g = false;
     int unit_d = 0, unit_g = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -1970,7 +1977,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_wide_kernel(const WgradHb p
         const int set = s & 1;
         lds_wait<2 * TM, 2 * TN>(fa[set], fb[set]);
         if (s < 3) {
-          read_frags(ud, ug, s + 1, set ^ 1);
+          read_frags(s + 1, set ^ 1);
           if (s == 0 && pend_d) issueD(unit_d, HALF1);
           if (s == 1 && pend_g) issueG(unit_g, HALF0);
           if (s == 2 && pend_g) issueG(unit_g, HALF1);
@@ -1983,7 +1990,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_wide_kernel(const WgradHb p
           unit_d = ug;                                   // the dense tile of step kt+2 takes the slot G_kt leaves
           unit_g = ud;
           if (pend_d) issueD(unit_d, HALF0);
-          read_frags(nd, ng, 0, 0);
+          set_bases(nd, ng);
+          read_frags(0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

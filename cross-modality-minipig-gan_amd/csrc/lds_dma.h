@@ -38,6 +38,23 @@ __device__ __forceinline__ i32x2 lds_read_tr16_b64(unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
   return v;
 }
+// k-sub s (0..3) of a tile whose k-subs lie 16 rows of 256 B apart: the k-sub goes into the offset field (s is a
+// constant once the k-sub loop is unrolled; the dead cases fold away), so a tile's fragment addresses are formed once
+// per K-step instead of once per k-sub.
+template <int OFF>
+__device__ __forceinline__ i32x2 lds_read_tr16_b64_o(unsigned addr) {
+  i32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ i32x2 lds_read_tr16_ksub(unsigned addr, int s) {
+  switch (s) {
+    case 0: return lds_read_tr16_b64_o<0>(addr);
+    case 1: return lds_read_tr16_b64_o<16 * 256>(addr);
+    case 2: return lds_read_tr16_b64_o<2 * 16 * 256>(addr);
+    default: return lds_read_tr16_b64_o<3 * 16 * 256>(addr);
+  }
+}
 template <int NA, int NB, typename V>
 __device__ __forceinline__ void lds_wait(V (&a)[NA], V (&b)[NB]) {
   if constexpr (NA == 4 && NB == 2)

@@ -61,6 +61,8 @@ SIGNATURES = {
     "mpgan_norm_finalize_strided": (_I, [_P, _I, _I, _I, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mpgan_norm_from_running": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
     "mpgan_norm_from_running_multi": (_I, [_P, _I, _P]),
+    "mpgan_epi_vectors_multi": (_I, [_P, _I, _P]),
+    "mpgan_conv_forward_act": (_I, [_G, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P]),
     "mpgan_norm_act_add": (_I, [_P, _I, _PR, _P, _I, _PR, _I, _L, _I, _I, _P, _I, _P]),
     "mpgan_norm_bwd_reduce": (_I, [_P, _I, _P, _I, _PR, _P, _P, C.POINTER(PeerTapsC), _I, _L, _I, _P, _P]),
     "mpgan_tap_l1_partials": (_I, []),

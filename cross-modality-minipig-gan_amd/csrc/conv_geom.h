@@ -36,6 +36,21 @@ struct BwdStats {
   float slope;
 };
 
+// Epilogue activation (eval-mode inference): with running-statistics BatchNorm the layer's
+// affine is known before the launch, so the conv's epilogue emits the ACTIVATED tensor
+//   y = prelu(acc * scale[c] + shift[c], slope[c]) (+ resid) (tanh)
+// (the conv's own bias is folded into shift; slope[c] = 1 leaves a channel linear -- the residual half of a fused
+// unit0 || residual conv).  scale == nullptr: off.  Never combined with fused statistics or norm-backward sums.
+struct EpiAct {
+  const float* scale;
+  const float* shift;
+  const float* slope;
+};
+__device__ __forceinline__ float epi_act1(float v, float sc, float sh, float sl) {
+  v = fmaf(v, sc, sh);
+  return v > 0.f ? v : v * sl;
+}
+
 struct GatherConv {
   const float* in;
   const float* wp;
@@ -60,6 +75,7 @@ struct GatherConv {
   int in_bf16, out_bf16; // thin (VALU) kernels of the bf16 path: `in` / `out` point at bf16 data (weights stay fp32)
   int mm16;              // MPGAN_CONV_MM_BF16: matrix operands rounded to bf16 into LDS, bf16 MFMA, fp32 accumulation
   int min_blocks;        // the geometry's big-tile threshold (0: default), see mpgan_conv_geom
+  EpiAct epi;            // epilogue activation (eval-mode inference); epi.scale == nullptr: off
   int classes;           // the phases are border classes of unequal size (build_transposed): launchers pack the tile list
   int packed;            // set by set_tile_grid: the grid holds only real (phase, m-tile) pairs, tile_start[] delimits the phases
   MPGAN_STAMP_FIELD      // development builds only (mpgan_common.h)

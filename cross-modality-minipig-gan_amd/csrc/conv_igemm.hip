@@ -614,6 +614,7 @@ __global__ __launch_bounds__(256) void thin_cin1_kernel(const GatherConv p) {
   for (int e = 0; e < V; ++e) {
     if (co + e >= p.Cout) break;
     float v = acc[e];
+    if (p.epi.scale) v = epi_act1(v, p.epi.scale[co + e], p.epi.shift[co + e], p.epi.slope[co + e]);
     if (r) v += r[e];
     if (p.tanh_out) v = tanhf(v);
     acc[e] = v;
@@ -688,6 +689,12 @@ __global__ __launch_bounds__(256) void thin_cin1_full_kernel(const GatherConv p)
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
       float4 v = acc[q];
+      if (p.epi.scale) {                     // (wave-uniform addresses: scalar loads)
+        const float4 sc = *reinterpret_cast<const float4*>(p.epi.scale + 4 * q), sh = *reinterpret_cast<const float4*>(p.epi.shift + 4 * q),
+                     sl = *reinterpret_cast<const float4*>(p.epi.slope + 4 * q);
+        v.x = epi_act1(v.x, sc.x, sh.x, sl.x); v.y = epi_act1(v.y, sc.y, sh.y, sl.y);
+        v.z = epi_act1(v.z, sc.z, sh.z, sl.z); v.w = epi_act1(v.w, sc.w, sh.w, sl.w);
+      }
       if (r) {
         const float4 rv = *reinterpret_cast<const float4*>(r + 4 * q);
         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
@@ -781,6 +788,7 @@ __global__ __launch_bounds__(256) void thin_cout1_kernel(const GatherConv p) {
   for (int off = LANES / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if (live && d.opix >= 0 && l == 0) {
     float v = acc + (p.bias ? p.bias[0] : 0.f);
+    if (p.epi.scale) v = epi_act1(v, p.epi.scale[0], p.epi.shift[0], p.epi.slope[0]);
     if (p.resid) v += p.resid[(long)d.opix * p.ldr];
     if (p.tanh_out) v = tanhf(v);
     p.out[(long)d.opix * p.ldo] = v;
@@ -837,6 +845,7 @@ __global__ __launch_bounds__(256) void convt_quad_cout1_kernel(const GatherConv 
       const long pix = ((long)n * p.Ho + oy) * p.Wo + ox;
       float v = t + (p.bias ? p.bias[0] : 0.f);
       sv = v;
+      if (p.epi.scale) v = epi_act1(v, p.epi.scale[0], p.epi.shift[0], p.epi.slope[0]);
       if (p.resid) v += p.resid[pix * p.ldr];
       if (p.tanh_out) v = tanhf(v);
       p.out[pix * p.ldo] = v;
@@ -956,6 +965,7 @@ __global__ __launch_bounds__(256) void convt_oct_cout1_kernel(const GatherConv p
         if (oz < p.Do && oy < p.Ho && ox < p.Wo) {
           const long pix = (((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
           float vv = r2[c] + (p.bias ? p.bias[0] : 0.f);
+          if (p.epi.scale) vv = epi_act1(vv, p.epi.scale[0], p.epi.shift[0], p.epi.slope[0]);
           if (p.resid) vv += p.resid[pix * p.ldr];
           if (p.tanh_out) vv = tanhf(vv);
           p.out[pix * p.ldo] = vv;
@@ -972,6 +982,7 @@ __global__ __launch_bounds__(256) void convt_oct_cout1_kernel(const GatherConv p
     if (oz < p.Do && oy < p.Ho && ox < p.Wo) {
       const long pix = (((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox;
       float vv = t + (p.bias ? p.bias[0] : 0.f);
+      if (p.epi.scale) vv = epi_act1(vv, p.epi.scale[0], p.epi.shift[0], p.epi.slope[0]);
       if (p.resid) vv += p.resid[pix * p.ldr];
       if (p.tanh_out) vv = tanhf(vv);
       p.out[pix * p.ldo] = vv;
@@ -1065,7 +1076,7 @@ __global__ __launch_bounds__(256) void thin_c1c1_rows4_kernel(const GatherConv p
 static bool thin_c1c1_ok(const GatherConv& p) {
   static const bool off = dev_env("MPGAN_DBG_NO_THIN_ROWS") != nullptr;
   if (off || !(p.Cin == 1 && p.Cout == 1 && p.ldi == 1 && p.ldo == 1 && (!p.resid || p.ldr == 1) && p.nphase == 1 &&
-               !p.pro.scale && !p.stats && !p.stats_acc && !p.in_bf16 && !p.out_bf16 && p.Ky == 3 && p.Kx == 3 &&
+               !p.pro.scale && !p.stats && !p.stats_acc && !p.in_bf16 && !p.out_bf16 && !p.epi.scale && p.Ky == 3 && p.Kx == 3 &&
                (p.Kz == 3 || p.Kz == 1)))
     return false;
   const Phase& ph = p.ph[0];
@@ -1163,7 +1174,7 @@ static bool thin_cin1_rows_ok(const GatherConv& p) {
   const int T = p.Kz * p.Ky * p.Kx;
   const Phase& ph = p.ph[0];
   return !off && p.Cin == 1 && p.Cout == 64 && p.ldi == 1 && p.nphase == 1 && !p.pro.scale && !p.resid && !p.tanh_out &&
-         !p.stats_acc && !p.in_bf16 && (T == 9 || T == 27) && p.Kx == 3 && p.Ky == 3 && p.Kz == (T == 27 ? 3 : 1) &&
+         !p.stats_acc && !p.in_bf16 && !p.epi.scale && (T == 9 || T == 27) && p.Kx == 3 && p.Ky == 3 && p.Kz == (T == 27 ? 3 : 1) &&
          ph.nx == 3 && ph.ny == 3 && ph.nz == p.Kz && ph.dx0 == 0 && ph.dy0 == 0 && ph.dz0 == 0 && ph.kx0 == 0 &&
          ph.ky0 == 0 && ph.kz0 == 0 && p.dstep[0] == 1 && p.dstep[1] == 1 && p.dstep[2] == 1 && p.kstep[0] == 1 &&
          p.kstep[1] == 1 && p.kstep[2] == 1 && p.istride[0] == 1 && p.istride[1] == 1 && p.istride[2] == 1 &&
@@ -1521,6 +1532,8 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
     }
     const int co = li;
     const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+    const bool ea = p.epi.scale != nullptr && co < Cout;      // epilogue activation (eval-mode inference)
+    const float esc = ea ? p.epi.scale[co] : 1.f, esh = ea ? p.epi.shift[co] : 0.f, esl = ea ? p.epi.slope[co] : 1.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;      // row inside the wave's 32
@@ -1532,6 +1545,7 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
         float v = acc[r] + bv;
         sm += v;
         sq += v * v;
+        if (ea) v = epi_act1(v, esc, esh, esl);
         if (gres) v += gres[pix * ldr + co];
         if (tanh_out) v = tanhf(v);
         gout[pix * ldo + co] = v;
@@ -1576,6 +1590,8 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
     }
     const int co = l16;
     const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+    const bool ea = p.epi.scale != nullptr && co < Cout;      // epilogue activation (eval-mode inference)
+    const float esc = ea ? p.epi.scale[co] : 1.f, esh = ea ? p.epi.shift[co] : 0.f, esl = ea ? p.epi.slope[co] : 1.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1588,6 +1604,7 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const GatherConv p, c
           float v = (mt == 0 ? acc0[r] : acc1[r]) + bv;
           sm += v;
           sq += v * v;
+          if (ea) v = epi_act1(v, esc, esh, esl);
           if (gres) v += gres[pix * ldr + co];
           if (tanh_out) v = tanhf(v);
           gout[pix * ldo + co] = v;
@@ -1809,6 +1826,9 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
   // behind each tile's MFMA loops it was an exposed L2 round trip per tile)
   const int bias_co = NARROW ? (lane & 15) : (lane & 31);
   const float bias_v = (p.bias && bias_co < Cout) ? p.bias[bias_co] : 0.f;
+  const bool ea = p.epi.scale != nullptr;                      // epilogue activation (eval-mode inference): this lane's channel
+  const float esc = (ea && bias_co < Cout) ? p.epi.scale[bias_co] : 1.f, esh = (ea && bias_co < Cout) ? p.epi.shift[bias_co] : 0.f,
+              esl = (ea && bias_co < Cout) ? p.epi.slope[bias_co] : 1.f;
 
   // De-phase the blocks that share a CU (dispatch deals the first 256 blocks one per CU, then the next 256, ...):
   // identical blocks started together stay in lockstep -- all staging, then all contracting -- and leave the matrix
@@ -1911,6 +1931,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
                 sm += v;
                 sq += v * v;
               }
+              if (ea) v = epi_act1(v, esc, esh, esl);
               if (gres) v += rres[r];
               if (tanh_out) v = tanhf(v);
               if (pl.tw_off >= 0) tw[pxl * 40 + li] = v;       // vector path: through LDS, stored below
@@ -2001,6 +2022,7 @@ __global__ __launch_bounds__(256) void gather_patch_persist_kernel(const GatherC
                 sm += v;
                 sq += v * v;
               }
+              if (ea) v = epi_act1(v, esc, esh, esl);
               if (gres) v += rres[mt * 4 + r];
               if (tanh_out) v = tanhf(v);
               if (pl.tw_off >= 0) tw[pxl * 20 + l16] = v;
@@ -2696,6 +2718,8 @@ __global__ __launch_bounds__(256, 2) void gather_patch3d_c16_kernel(const Gather
       }
   // ---- epilogue: D[row = 4 g + i][col = ln] -> out[pixel][channel], bias / residual, statistics of z = acc + bias ----
   const float bv = p.bias ? p.bias[ln] : 0.f;
+  const bool ea = p.epi.scale != nullptr;                      // epilogue activation (eval-mode inference)
+  const float esc = ea ? p.epi.scale[ln] : 1.f, esh = ea ? p.epi.shift[ln] : 0.f, esl = ea ? p.epi.slope[ln] : 1.f;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
@@ -2709,6 +2733,7 @@ __global__ __launch_bounds__(256, 2) void gather_patch3d_c16_kernel(const Gather
         s1 += z;
         s2 = fmaf(z, z, s2);
         float v = z;
+        if (ea) v = epi_act1(v, esc, esh, esl);
         if (p.resid) v += p.resid[pix * p.ldr + ln];
         p.out[pix * p.ldo + ln] = v;
       }
@@ -2812,6 +2837,8 @@ static int launch_gather(const GatherConv& p, hipStream_t st) {
                   "gather_conv: more than 2^31 pixels");
   MPGAN_CHECK_ARG((long)p.Cout * p.Cin * p.Kz * p.Ky * p.Kx < (1L << 31), "gather_conv: weight larger than 2^31");
   const int variant = select_variant(p, maxM, thin_cin1_ok(p), thin_cout1_ok(p));
+  MPGAN_UNSUPPORTED(p.epi.scale && (p.stats || p.stats_acc || p.bwd.part || p.fold.acc || p.ksplit > 1 || p.in_bf16 || p.out_bf16),
+                    "gather_conv: the epilogue activation goes with a plain forward (no fused statistics, split-K or bf16 storage)");
   MPGAN_UNSUPPORTED(p.fold.acc && (p.pro.n_stride != 0 || p.fold.cstride < p.Cin),
                     "gather_conv: fold-on-load is per channel (BatchNorm) over >= Cin accumulator columns");
   if (variant <= 2) {
@@ -2991,6 +3018,28 @@ extern "C" int mpgan_conv_forward_fold(const mpgan_conv_geom* g, const float* x,
     p.stats_acc = reinterpret_cast<long long*>(stats_acc);
     p.acc_rep = acc_replicas;
   }
+  return launch_gather(p, (hipStream_t)stream);
+}
+
+// Forward conv of eval-mode inference: y = prelu(conv(x) * scale[c] + shift[c], slope[c]) (+ resid) (tanh) -- the layer's
+// running-statistics BatchNorm, its PReLU and the conv's own bias (folded into `shift`) applied in the epilogue, so the
+// ACTIVATED tensor is what reaches HBM and no norm_act_add launch follows (EpiAct, conv_geom.h).
+extern "C" int mpgan_conv_forward_act(const mpgan_conv_geom* g, const float* x, int32_t ldx, const float* w_packed,
+                                      const float* scale, const float* shift, const float* slope, const float* resid,
+                                      int32_t ldr, int32_t tanh_out, float* y, int32_t ldy, void* stream) {
+  int rc = check_geom(g);
+  if (rc) return rc;
+  MPGAN_CHECK_ARG(x && w_packed && y && scale && shift && slope, "conv_forward_act: null pointer");
+  MPGAN_CHECK_ARG(ldx >= g->cin && ldy >= g->cout && (!resid || ldr >= g->cout), "conv_forward_act: bad pitch");
+  MPGAN_CHECK_ARG(((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(slope)) & 15) == 0,
+                  "conv_forward_act: scale / shift / slope must be 16-byte aligned");
+  GatherConv p{};
+  p.in = x; p.wp = w_packed; p.out = y; p.bias = nullptr; p.resid = resid;
+  p.pro = make_pro(nullptr);
+  p.fold = make_fold(nullptr);
+  p.epi.scale = scale; p.epi.shift = shift; p.epi.slope = slope;
+  p.ldi = ldx; p.ldo = ldy; p.ldr = ldr; p.tanh_out = tanh_out;
+  build_for_forward(p, g);
   return launch_gather(p, (hipStream_t)stream);
 }
 

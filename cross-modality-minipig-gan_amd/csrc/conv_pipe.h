@@ -74,6 +74,16 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
     cov[tn] = n0 + (wn * TN + tn) * 32 + li;
     bv[tn] = bias_pre ? bias_pre[tn] : ((p.bias && cov[tn] < Cout) ? p.bias[cov[tn]] : 0.f);   // bias_pre: fetched before the K loop
   }
+  // epilogue activation (eval-mode inference): this lane's columns' affine and slope
+  const bool ea = p.epi.scale != nullptr;
+  float esc[TN], esh[TN], esl[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const bool okc = ea && cov[tn] < Cout;
+    esc[tn] = okc ? p.epi.scale[cov[tn]] : 1.f;
+    esh[tn] = okc ? p.epi.shift[cov[tn]] : 0.f;
+    esl[tn] = okc ? p.epi.slope[cov[tn]] : 1.f;
+  }
   // fused norm-backward sums of the produced gradient (BwdStats): per-column vectors and running sums
   const bool bw = p.bwd.part != nullptr;
   // Output path A (the usual one): every 32 x 32 accumulator tile goes through a wave-private LDS transpose and leaves
@@ -92,7 +102,11 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) wt[((r & 3) + 8 * (r >> 2) + 4 * lh) * TP + li] = acc[tm][tn][r] + bv[tn];
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[tm][tn][r] + bv[tn];
+            if (ea) v = epi_act1(v, esc[tn], esh[tn], esl[tn]);
+            wt[((r & 3) + 8 * (r >> 2) + 4 * lh) * TP + li] = v;
+          }
           const int c4 = lane & 7, co = n0 + (wn * TN + tn) * 32 + 4 * c4;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -152,6 +166,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherConv& p, const Phase& 
       for (int tn = 0; tn < TN; ++tn) {
         if (cov[tn] >= Cout) continue;
         float v = acc[tm][tn][r] + bv[tn];
+        if (ea) v = epi_act1(v, esc[tn], esh[tn], esl[tn]);
         if (rrow) v += rrow[cov[tn]];
         if (tanh_out) v = tanhf(v);
         orow[cov[tn]] = v;

@@ -966,6 +966,48 @@ extern "C" int mpgan_norm_from_running_multi(const int64_t* table, int32_t n_lay
   return check_launch("norm_from_running_multi");
 }
 
+// Epilogue-activation vectors of every conv of an eval-mode plan in ONE launch (mpgan_conv_forward_act): block b serves
+// table row b = {gamma, beta, running_mean, running_var, conv bias, PReLU weight (one element), scale, shift, slope
+// (device addresses), c_norm, c_total, eps bits}.  Channels < c_norm carry the running-statistics BatchNorm + PReLU of
+// the layer: scale = gamma / sqrt(var + eps), shift = beta - mean * scale + bias * scale, slope = the PReLU weight
+// (1 when the layer has none); channels c_norm .. c_total - 1 (the residual half of a fused unit0 || residual conv, or a
+// conv without a norm layer) stay linear: scale 1, shift = bias, slope 1.
+__global__ __launch_bounds__(256) void epi_vectors_multi_kernel(const long long* __restrict__ table) {
+  const long long* e = table + 12 * (long)blockIdx.x;
+  const float* gamma = reinterpret_cast<const float*>(e[0]);
+  const float* beta = reinterpret_cast<const float*>(e[1]);
+  const float* rm = reinterpret_cast<const float*>(e[2]);
+  const float* rv = reinterpret_cast<const float*>(e[3]);
+  const float* bias = reinterpret_cast<const float*>(e[4]);
+  const float* alpha = reinterpret_cast<const float*>(e[5]);
+  float* scale = reinterpret_cast<float*>(e[6]);
+  float* shift = reinterpret_cast<float*>(e[7]);
+  float* slope = reinterpret_cast<float*>(e[8]);
+  const int c_norm = (int)e[9], c_total = (int)e[10];
+  const float eps = __uint_as_float((unsigned)e[11]);
+  const float a = alpha ? alpha[0] : 1.f;
+  for (int i = threadIdx.x; i < c_total; i += 256) {
+    const float b = bias ? bias[i] : 0.f;
+    if (i < c_norm) {
+      const float sc = (gamma ? gamma[i] : 1.f) / sqrtf(rv[i] + eps);
+      scale[i] = sc;
+      shift[i] = fmaf(b - rm[i], sc, beta ? beta[i] : 0.f);
+      slope[i] = a;
+    } else {
+      scale[i] = 1.f;
+      shift[i] = b;
+      slope[i] = 1.f;
+    }
+  }
+}
+
+extern "C" int mpgan_epi_vectors_multi(const int64_t* table, int32_t n_layers, void* stream) {
+  MPGAN_CHECK_ARG(table && n_layers > 0, "epi_vectors_multi: bad argument");
+  hipLaunchKernelGGL(epi_vectors_multi_kernel, dim3((unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(table));
+  return check_launch("epi_vectors_multi");
+}
+
 extern "C" int32_t mpgan_tap_l1_partials(void) { return 3 * 1024; }
 
 extern "C" int mpgan_tap_l1(const float* za, int32_t lda, const mpgan_prologue* pa, const float* zb, int32_t ldb,

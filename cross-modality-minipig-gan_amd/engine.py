@@ -732,6 +732,45 @@ def emit_eval_norms(prog, eval_norms, dev):
              keep=(table, eval_norms))
 
 
+def emit_conv_fwd_act(prog, rows, g: ConvGeom, x, wp, bias, y, norm_mod=None, act_mod=None, c_norm=None, resid=None,
+                      tanh=False):
+    """Eval-mode inference conv (code/GAN/inferrence.py:97-110,169-170): running-statistics BatchNorm, PReLU, the conv's
+    bias and the residual add all in the conv's epilogue (mpgan_conv_forward_act); `rows` collects the plan's table rows
+    for the one up-front mpgan_epi_vectors_multi launch that fills this conv's scale / shift / slope vectors.
+    c_norm: the norm + activation cover only the first c_norm output channels (a conv fused with its unit's residual conv)."""
+    import struct
+    ops._check_in_out(g, x, y, "plan conv_forward_act")
+    c = g.cout if c_norm is None else c_norm
+    if norm_mod is None:
+        c = 0
+    else:
+        assert hasattr(norm_mod, "running_mean") and norm_mod.running_mean is not None, "eval plan: BatchNorm layers only"
+    if act_mod is not None:
+        assert act_mod.weight.numel() == 1, "eval plan: PReLU with one parameter (MONAI 0.4.0's default)"
+    cpad = (g.cout + 3) // 4 * 4
+    vec = torch.empty(3, cpad, device=x.device)              # scale / shift / slope, each row 16-byte aligned
+    eps_bits = struct.unpack("<I", struct.pack("<f", float(norm_mod.eps if norm_mod is not None else 0.0)))[0]
+    nm = norm_mod
+    rows.append([_p(nm.weight) or 0 if nm is not None else 0, _p(nm.bias) or 0 if nm is not None else 0,
+                 nm.running_mean.data_ptr() if nm is not None else 0, nm.running_var.data_ptr() if nm is not None else 0,
+                 _p(bias) or 0, _p(act_mod.weight) if act_mod is not None else 0,
+                 vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), c, g.cout, eps_bits])
+    gc = g.c()
+    tag = (gather_kernel_name(g, False, False), 2.0 * conv_macs(g), conv_bytes(g))
+    prog.add("conv_forward", lib().mpgan_conv_forward_act, C.byref(gc), x.data_ptr(), _ld(x), wp.data_ptr(),
+             vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), _p(resid), _ld(resid), int(tanh), y.data_ptr(), _ld(y),
+             keep=(gc, x, wp, bias, y, resid, vec, norm_mod, act_mod), desc=_gdesc(g), tag=tag)
+
+
+def emit_epi_vectors(prog, rows, dev):
+    """One launch filling the epilogue-activation vectors of every conv of an eval-mode plan (they depend on parameters
+    and running statistics only, not on the input)."""
+    if not rows:
+        return
+    table = torch.tensor(rows, dtype=torch.int64, device=dev)
+    prog.add("epi_vectors_multi", lib().mpgan_epi_vectors_multi, table.data_ptr(), len(rows), keep=(table,))
+
+
 def emit_norm_act_add(prog, z, pz, r, pr, out, tanh=False, fold=None):
     """fold: mpgan_norm_fold of z's producer (this launch finalises its statistics)."""
     n, P, ldz = ops._cl(z, "norm_act_add z")
@@ -1014,12 +1053,53 @@ class UNetPlan:
         self.scratch = scratch
         self._marks = (own_mark, wait_mark)
         self.eval_norms = [] if not training else None   # eval mode: (norm module, NormBuf, C) of every layer
+        self.epi_rows = []                                # eval mode, BatchNorm: table rows of emit_conv_fwd_act
+        self.eval_fused = (not training) and (not instance) and (not want_backward)
         self._build_args = dict(x_in=x_in, y_out=y_out, tanh_out=tanh_out, want_backward=want_backward, gbufs=gbufs,
                                 chans=chans, L=L, sizes=sizes, in_ch=in_ch, sub_out=sub_out, cats=cats, R=R,
                                 bottom=dict(bc0=bc0, BN0=BN0, BA0=BA0, bc1=bc1, BN1=BN1, BA1=BA1, res=bottom.res,
                                             gb0=gb0, gb1=gb1, gbr=gbr, zb0=zb0, zb1=zb1, rb=rb, nbb0=nbb0, nbb1=nbb1,
                                             cb=cb, cb_in=cb_in),
                                 prelu_pro=prelu_pro, instance=instance)
+
+    def _emit_eval(self, a, down_state, up_state):
+        """Eval-mode inference program of one U-Net (code/GAN/inferrence.py:97-110): every
+        conv emits its ACTIVATED output -- running-statistics BatchNorm, PReLU, bias and the unit's residual add in its
+        epilogue -- so no norm_act_add launch and no normalise-on-load prologue remain: 15 launches per U-Net instead of
+        22, all of them convs.  Same buffers as the training plan (a raw-output buffer now holds the activation)."""
+        f, store, rows = self.fwd, self.store, self.epi_rows
+        R = a["R"]
+        chans, L, cats = a["chans"], a["L"], a["cats"]
+        y_out = a["y_out"]
+        bt = a["bottom"]
+        wp = store.wp
+        for l in range(L - 1):
+            s = down_state[l]
+            (cv0, N0, A0), (cv1, N1, A1) = s["ru"].units
+            if s["gf"] is not None:       # unit0 || residual in one conv: the first c channels are normed + activated
+                fr = s["fr"]
+                emit_conv_fwd_act(f, rows, s["gf"], s["xin"], store.wp_fused(fr), store.bias_fused(fr), s["zr"], N0, A0,
+                                  c_norm=s["c"])
+            else:
+                emit_conv_fwd_act(f, rows, s["g0"], s["xin"], wp(R(cv0)), cv0.bias, s["z0"], N0, A0)
+                emit_conv_fwd(f, s["gr"], s["xin"], wp(R(s["ru"].res)), s["ru"].res.bias, s["r"])
+            emit_conv_fwd_act(f, rows, s["g1"], s["z0"], wp(R(cv1)), cv1.bias, cats[l][..., :s["c"]], N1, A1, resid=s["r"])
+        d_last = cats[L - 2][..., :bt["cb_in"]]
+        emit_conv_fwd_act(f, rows, bt["gb0"], d_last, wp(R(bt["bc0"])), bt["bc0"].bias, bt["zb0"], bt["BN0"], bt["BA0"])
+        if bt["res"] is not None:
+            emit_conv_fwd(f, bt["gbr"], d_last, wp(R(bt["res"])), bt["res"].bias, bt["rb"])
+        emit_conv_fwd_act(f, rows, bt["gb1"], bt["zb0"], wp(R(bt["bc1"])), bt["bc1"].bias, cats[L - 2][..., bt["cb_in"]:],
+                          bt["BN1"], bt["BA1"], resid=bt["rb"] if bt["res"] is not None else d_last)
+        for l in range(L - 2, -1, -1):
+            u = up_state[l]
+            if "zu" in u:
+                emit_conv_fwd_act(f, rows, u["gt"], cats[l], wp(R(u["ct"])), u["ct"].bias, u["zt"], u["NT"], u["AT"])
+                dst = cats[l - 1][..., chans[l - 1]:] if l > 0 else y_out
+                emit_conv_fwd_act(f, rows, u["gu"], u["zt"], wp(R(u["cu"])), u["cu"].bias, dst, u["NU"], u["AU"],
+                                  resid=u["zt"], tanh=(a["tanh_out"] and l == 0))
+            else:                          # top level: the transposed conv leaves act(bn(.)) itself, then the conv-only unit
+                emit_conv_fwd_act(f, rows, u["gt"], cats[l], wp(R(u["ct"])), u["ct"].bias, u["ua"], u["NT"], u["AT"])
+                emit_conv_fwd(f, u["gu"], u["ua"], wp(R(u["cu"])), u["cu"].bias, y_out, resid=u["ua"], tanh=a["tanh_out"])
 
     # programs are emitted after the shared scratch has been sized and allocated
     def emit(self):
@@ -1034,6 +1114,9 @@ class UNetPlan:
         tr = self.training
         bt = a["bottom"]
         wp, wpb = store.wp, store.wp_bwd
+        if self.eval_fused:
+            self._emit_eval(a, down_state, up_state)
+            return
 
         # ================= forward =================
         for l in range(L - 1):
@@ -1243,6 +1326,7 @@ class GeneratorPlan:
                          keep=(self.acc_all,))
         if not training:
             emit_eval_norms(self.fwd, [e for p in self.unet_plans for e in p.eval_norms], dev)
+            emit_epi_vectors(self.fwd, [r for p in self.unet_plans for r in p.epi_rows], dev)
         for p in self.unet_plans:
             self.fwd.extend(p.fwd)
         self.bwd = Program()

@@ -212,6 +212,29 @@ def conv_forward(g: ConvGeom, x, w_packed, bias, y, *, pro: Optional[Prologue] =
     return y
 
 
+def conv_forward_act(g: ConvGeom, x, w_packed, scale, shift, slope, y, *, resid=None, tanh_out: bool = False):
+    """Eval-mode inference conv (code/GAN/inferrence.py:97-110): y = prelu(conv(x) * scale + shift, slope) (+ resid) (tanh),
+    everything behind the matrix product applied in the conv's epilogue (include/mpgan_hip.h: mpgan_conv_forward_act)."""
+    _check_in_out(g, x, y, "conv_forward_act")
+    _, _, ldx = _cl(x, "conv_forward_act x")
+    _, _, ldy = _cl(y, "conv_forward_act y")
+    ldr = 0
+    if resid is not None:
+        if resid.shape != y.shape:
+            raise ValueError("conv_forward_act: resid shape mismatch")
+        _, _, ldr = _cl(resid, "conv_forward_act resid")
+    if w_packed.numel() < g.cout * g.cin * g.taps:
+        raise ValueError("conv_forward_act: packed weight too small")
+    for v in (scale, shift, slope):
+        if v.numel() < g.cout or v.dtype != torch.float32 or not v.is_contiguous():
+            raise ValueError("conv_forward_act: scale / shift / slope must be contiguous fp32 vectors of cout elements")
+    gc = g.c()
+    check(lib().mpgan_conv_forward_act(C.byref(gc), x.data_ptr(), ldx, w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                       slope.data_ptr(), _ptr(resid), ldr, int(tanh_out), y.data_ptr(), ldy, _stream()),
+          "conv_forward_act")
+    return y
+
+
 def conv_backward_data(g: ConvGeom, dy, w_packed_bwd, dx, *, resid=None):
     _check_in_out(g, dx, dy, "conv_backward_data")
     _, _, lddy = _cl(dy, "conv_backward_data dy")

@@ -231,6 +231,23 @@ int mpgan_norm_from_running(const float* gamma, const float* beta, const float* 
  * may be 0), C, eps (the float's bit pattern in the low 32 bits)}. */
 int mpgan_norm_from_running_multi(const int64_t* table, int32_t n_layers, void* stream);
 
+/* Eval-mode inference (code/GAN/inferrence.py:97-110,169-170: generator.eval(); generator(x)): with running-statistics
+ * BatchNorm a layer's affine is known before its conv runs, so the conv's epilogue applies it, the PReLU and the residual
+ * add, and the ACTIVATED tensor is what reaches memory -- no norm_act_add launch, no prologue in the consumer:
+ *     y = prelu(conv(x) * scale[c] + shift[c], slope[c]) (+ resid) (tanh)
+ * The conv's own bias is folded into `shift` by the caller (mpgan_epi_vectors_multi does it); slope[c] = 1 leaves a
+ * channel linear.  scale / shift / slope: [cout] floats, 16-byte aligned.  Not combinable with fused statistics. */
+int mpgan_conv_forward_act(const mpgan_conv_geom* g, const float* x, int32_t ldx, const float* w_packed,
+                           const float* scale, const float* shift, const float* slope, const float* resid,
+                           int32_t ldr, int32_t tanh_out, float* y, int32_t ldy, void* stream);
+
+/* The three vectors of every conv of an eval-mode plan in one launch.  table: device int64[n_layers][12] = {gamma, beta,
+ * running_mean, running_var, conv bias, PReLU weight (one element) (device addresses; gamma / beta / bias / PReLU may be
+ * 0), scale, shift, slope (outputs), c_norm, c_total, eps (the float's bit pattern in the low 32 bits)}: channels
+ * < c_norm get scale = gamma / sqrt(var + eps), shift = beta + (bias - mean) * scale, slope = the PReLU weight (1 without
+ * one); channels c_norm .. c_total - 1 (no norm layer: the residual half of a fused conv) get 1, bias, 1. */
+int mpgan_epi_vectors_multi(const int64_t* table, int32_t n_layers, void* stream);
+
 /* out = act(z*scale+shift) [+ r]   where r is either a plain tensor or itself
  * act(zr*scale_r+shift_r); optional tanh on the sum.  (ResidualUnit.forward's
  * "cx + res" and the generator's final Tanh, GAN_final.py:117.) */

@@ -777,3 +777,86 @@ def test_small_map_valid_conv_backward_data_runs_as_border_class_phases(case, dm
         test_conv_forward_dgrad_wgrad(case)
     finally:
         _MIN_BLOCKS[0] = saved
+
+
+# ---- eval-mode inference convs (mpgan_conv_forward_act): BatchNorm affine + PReLU + residual in the epilogue ----
+# (dims, cin, cout, k, stride, pad, spatial, batch, transposed): one case per kernel class of the generator's eval program
+ACT_CASES = [
+    (2, 1, 32, 3, 2, 1, (20, 24), 2, False),       # thin_cin1_full: the fused unit0 || residual conv of level 0 (c_norm = 16)
+    (2, 16, 16, 3, 1, 1, (40, 24), 2, False),      # persistent 2-D patch kernel, 16-wide MFMA form
+    (2, 32, 32, 3, 1, 1, (24, 20), 2, False),      # ... 32-wide form
+    (2, 16, 64, 3, 2, 1, (20, 24), 2, False),      # K-stepped, 16 gathered channels (fused 16 -> 32 || 32: c_norm = 32)
+    (2, 64, 64, 3, 1, 1, (16, 16), 2, False),      # K-stepped, in-block split-K form
+    (2, 128, 128, 3, 1, 1, (8, 8), 2, False),
+    (2, 64, 128, 1, 1, 0, (8, 8), 2, False),       # 1 x 1 residual conv (linear epilogue: c_norm = 0)
+    (2, 192, 32, 3, 2, 1, (6, 5), 2, True),        # transposed conv, four phases, K-stepped
+    (2, 64, 16, 3, 2, 1, (10, 12), 2, True),       # transposed conv on the phase-merged patch kernel
+    (2, 32, 1, 3, 2, 1, (12, 10), 3, True),        # quad kernel (C -> 1)
+    (2, 1, 1, 3, 1, 1, (16, 20), 2, False),        # 1 -> 1 (generic thin kernel: the rows kernel has no activation)
+    (3, 1, 32, 3, 2, 1, (8, 10, 12), 2, False),
+    (3, 16, 16, 3, 1, 1, (5, 12, 11), 2, False),   # 3-D patch kernel
+    (3, 32, 32, 3, 1, 1, (6, 5, 7), 2, False),
+    (3, 192, 32, 3, 2, 1, (3, 4, 5), 1, True),
+    (3, 32, 1, 3, 2, 1, (5, 4, 6), 2, True),       # octet kernel (C -> 1)
+    (3, 16, 1, 3, 2, 1, (5, 4, 6), 1, True),       # ... four lanes per voxel
+]
+
+
+@pytest.mark.parametrize("case", ACT_CASES, ids=lambda c: "d{}_{}to{}_k{}s{}p{}{}".format(*c[:6], "T" if c[8] else ""))
+@pytest.mark.parametrize("with_resid,tanh", [(False, False), (True, False), (True, True)], ids=["plain", "resid", "resid_tanh"])
+def test_conv_forward_act_epilogue(case, with_resid, tanh):
+    """y = prelu(conv(x) * scale + shift, slope) (+ resid) (tanh) against torch, the vectors produced by
+    mpgan_epi_vectors_multi from a BatchNorm's running statistics, the conv's bias and a PReLU weight (channels beyond
+    c_norm stay linear); input, output and residual as channel slices of wider buffers."""
+    import ctypes as C
+    import struct
+    from mpgan_amd import ops
+    from mpgan_amd._lib import lib
+    dims, cin, cout, k, s, p, spatial, n, transposed = case
+    gen = torch.Generator().manual_seed(3000 + cin * 5 + cout + dims)
+    x = torch.rand(n, cin, *spatial, generator=gen) * 2 - 1
+    wshape = (cin, cout) if transposed else (cout, cin)
+    w = (torch.rand(*wshape, *([k] * dims), generator=gen) * 2 - 1) / (cin * k ** dims) ** 0.5
+    b = torch.rand(cout, generator=gen) - 0.5
+    c_norm = 0 if (k == 1) else (cout // 2 if cout in (32, 64) and not transposed and s == 2 else cout)
+    gamma, beta = torch.rand(cout, generator=gen) + 0.5, torch.rand(cout, generator=gen) - 0.5
+    rm, rv = torch.rand(cout, generator=gen) - 0.5, torch.rand(cout, generator=gen) + 0.25
+    alpha, eps = torch.tensor([0.3]), 1e-5
+    if transposed:
+        z = _convt(dims)(x, w, b, stride=s, padding=p, output_padding=s - 1)
+    else:
+        z = _conv(dims)(x, w, b, stride=s, padding=p)
+    shp = [1, -1] + [1] * dims
+    zn = (z - rm.view(shp)) / torch.sqrt(rv.view(shp) + eps) * gamma.view(shp) + beta.view(shp)
+    a = torch.where(zn > 0, zn, alpha * zn)
+    ref = torch.cat([a[:, :c_norm], z[:, c_norm:]], 1)
+    res = torch.rand(ref.shape, generator=gen) - 0.5
+    if with_resid:
+        ref = ref + res
+    if tanh:
+        ref = torch.tanh(ref)
+
+    g = _geom(dims, n, cin, cout, k, s, p, spatial, transposed=transposed)
+    dev = "cuda"
+    vec = torch.full((3, (cout + 3) // 4 * 4), float("nan"), device=dev)
+    keep = [t.to(dev) for t in (gamma, beta, rm, rv, b, alpha)]
+    eps_bits = struct.unpack("<I", struct.pack("<f", eps))[0]
+    row = [keep[0].data_ptr() if c_norm else 0, keep[1].data_ptr() if c_norm else 0, keep[2].data_ptr() if c_norm else 0,
+           keep[3].data_ptr() if c_norm else 0, keep[4].data_ptr(), keep[5].data_ptr() if c_norm else 0,
+           vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), c_norm, cout, eps_bits]
+    table = torch.tensor([row], dtype=torch.int64, device=dev)
+    assert lib().mpgan_epi_vectors_multi(table.data_ptr(), 1, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    # channel slices of wider buffers (multiples of four channels aside, as the U-Net's concatenation buffers are)
+    xw = torch.zeros(n, *g.in_dhw, cin + (4 if cin > 1 else 0), device=dev)
+    xs = xw[..., :cin] if cin > 1 else xw
+    xs.copy_(to_cl(x))
+    yw = torch.full((n, *g.out_dhw, cout + (8 if cout > 1 else 0)), float("nan"), device=dev)
+    ys = yw[..., 4:4 + cout] if cout > 1 else yw
+    rw = torch.zeros(n, *g.out_dhw, 2 * cout, device=dev) if cout > 1 else torch.zeros(n, *g.out_dhw, 1, device=dev)
+    rs = rw[..., cout:] if cout > 1 else rw
+    rs.copy_(to_cl(res))
+    wp = ops.pack_weight(w.to(dev), transposed=transposed)
+    ops.conv_forward_act(g, xs, wp, vec[0], vec[1], vec[2], ys, resid=rs if with_resid else None, tanh_out=tanh)
+    assert_close(from_cl(ys.contiguous(), dims), ref, what="conv + BatchNorm(eval) + PReLU + residual epilogue")
+    if cout > 1:
+        assert torch.isnan(yw[..., :4]).all() and torch.isnan(yw[..., 4 + cout:]).all()      # nothing outside the slice

@@ -80,7 +80,8 @@ struct GatherConv {
   int packed;            // set by set_tile_grid: the grid holds only real (phase, m-tile) pairs, tile_start[] delimits the phases
   MPGAN_STAMP_FIELD      // development builds only (mpgan_common.h)
   Phase ph[MAX_PHASES];
-  int tile_start[MAX_PHASES + 1];   // packed: first work item of phase i (in m-tiles); entries past nphase = INT_MAX
+  int tile_start[MAX_PHASES + 1];   // packed: first (phase, m-tile) pair = statistics row of phase i; past nphase = INT_MAX
+  int group_start[9];               // packed: first tile of work group k (one eighth of EVERY phase), see decode_block
 };
 
 // `row`: index of the block's (phase, m-tile) pair = its row of fused statistics / norm-backward partial sums.
@@ -88,21 +89,34 @@ struct BlockId { int mt, nt, phase, split, row; };
 __host__ __device__ __forceinline__ BlockId decode_block(const GatherConv& p, const unsigned w) {   // w: position in the work order
   BlockId b;
   if (p.packed) {
-    // Border-class phases differ in size by up to 27 x: a grid of nphase x max-tiles blocks would leave most of them
-    // empty AND (phases being contiguous ranges of the work order, which xcd_remap hands out in eighths) put a third
-    // of the work -- the interior class -- on one XCD (measured: variant B's 256 -> 512 backward-data 47.7 -> 79 ms).
-    // The work list therefore holds real tiles only, phase after phase; every XCD gets an equal contiguous share.
+    // Border-class phases differ in size by up to 27 x and in K length (taps) by up to 3.4 x.  A grid of nphase x
+    // max-tiles blocks would leave most of them empty; a list of the real tiles phase after phase would put all
+    // 27-tap interior tiles on the one or two XCDs whose contiguous share of the work order (xcd_remap hands out
+    // eighths) they fall into -- measured on variant B's 256 -> 512 backward-data: every class launched alone sums to
+    // 34.4 ms, the phase-major list took 44.9 (and the nphase x max-tiles grid 79).  The list therefore runs through
+    // eight GROUPS, group k holding the k-th eighth of every phase: each XCD's share has the same mix of tap counts,
+    // tiles of a phase stay contiguous inside a group (same weights, neighbouring pixels in one L2).
     b.nt = (int)(w % (unsigned)p.ntiles);
     unsigned q = w / (unsigned)p.ntiles;
     const unsigned tot = (unsigned)p.mtiles;            // (packed: mtiles = all phases' tiles)
     b.split = (int)(q / tot);
     q -= (unsigned)b.split * tot;
-    int ph = 0;
+    int k = 0;
 #pragma unroll
-    for (int i = 1; i < MAX_PHASES; ++i) ph += q >= (unsigned)p.tile_start[i] ? 1 : 0;
+    for (int i = 1; i < 8; ++i) k += q >= (unsigned)p.group_start[i] ? 1 : 0;
+    unsigned r = q - (unsigned)p.group_start[k];        // position inside group k
+    int ph = 0, mt = 0;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < MAX_PHASES; ++i) {
+      const unsigned tp = i < p.nphase ? (unsigned)(p.tile_start[i + 1] - p.tile_start[i]) : 0u;   // tiles of phase i
+      const unsigned lo = (tp * (unsigned)k) >> 3, sz = ((tp * (unsigned)(k + 1)) >> 3) - lo;      // its k-th eighth
+      if (!found && r < sz) { ph = i; mt = (int)(lo + r); found = true; }
+      if (!found) r -= sz;
+    }
     b.phase = ph;
-    b.mt = (int)(q - (unsigned)p.tile_start[ph]);
-    b.row = (int)q;
+    b.mt = mt;
+    b.row = p.tile_start[ph] + mt;
     return b;
   }
   // n-tile fastest, then phase, then m-tile: the phases of a strided backward-data gather read the
@@ -155,12 +169,23 @@ inline long set_tile_grid(GatherConv& q, int bm) {
     q.mtiles = (int)((max_phase_pixels(q) + bm - 1) / bm);
     return (long)q.mtiles * q.nphase;
   }
+  const char* only_s = dev_env("MPGAN_DBG_ONLY_PHASE");          // (make DEV=1: time one class at a time; read per call)
+  const int only = only_s ? atoi(only_s) : -1;
   long t = 0;
   for (int i = 0; i <= MAX_PHASES; ++i) {
     q.tile_start[i] = i <= q.nphase ? (int)t : 0x7FFFFFFF;
-    if (i < q.nphase) t += ((long)q.N * q.ph[i].Mz * q.ph[i].My * q.ph[i].Mx + bm - 1) / bm;
+    if (i < q.nphase && (only < 0 || only == i)) t += ((long)q.N * q.ph[i].Mz * q.ph[i].My * q.ph[i].Mx + bm - 1) / bm;
   }
   for (int i = q.nphase + 1; i <= MAX_PHASES; ++i) q.tile_start[i] = 0x7FFFFFFF;
+  long gs = 0;                                            // group k = the k-th eighth of every phase (decode_block)
+  for (int k = 0; k <= 8; ++k) {
+    q.group_start[k] = (int)gs;
+    if (k < 8)
+      for (int i = 0; i < q.nphase; ++i) {
+        const long tp = q.tile_start[i + 1] - q.tile_start[i];
+        gs += ((tp * (k + 1)) >> 3) - ((tp * k) >> 3);
+      }
+  }
   q.packed = 1;
   q.mtiles = (int)t;
   return t;
@@ -237,7 +262,7 @@ inline void build_transposed(GatherConv& p, int n, const int32_t* gath_dhw, int 
   // Only where the K-stepped kernels serve the gather (>= 64 channels on both sides): the patch kernels stage the
   // padding as zeros once per tile and need one phase.
   p.classes = 0;
-  if (classes_ok && s[0] == 1 && s[1] == 1 && s[2] == 1 && cg >= 64 && cp >= 64) {
+  if (classes_ok && !dev_env("MPGAN_DBG_NO_CLASSES") && s[0] == 1 && s[1] == 1 && s[2] == 1 && cg >= 64 && cp >= 64) {
     int nc[3], lo[3][3], hi[3][3], k0c[3][3], njc[3][3];
     double real = 1.0, issued = 1.0, issued_cls = 1.0;
     for (int d = 0; d < 3; ++d) {

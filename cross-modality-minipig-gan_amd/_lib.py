@@ -51,6 +51,8 @@ SIGNATURES = {
     "mpgan_conv_variant": (_I, [_G, _I, _I]),
     "mpgan_conv_bwd_stats_rows": (_I, [_G]),
     "mpgan_conv_variant_bf16": (_I, [_G, _I]),
+    "mpgan_conv_bwd_stats_rows_bf16": (_I, [_G]),
+    "mpgan_conv_backward_data_stats_bf16": (_I, [_G, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _P]),
     "mpgan_conv_backward_data_stats": (_I, [_G, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "mpgan_conv_wgrad_workspace": (_L, [_G]),
     "mpgan_conv_backward_weight": (_I, [_G, _P, _I, _PR, _P, _I, _P, _P, _F, _P, _L, _P]),

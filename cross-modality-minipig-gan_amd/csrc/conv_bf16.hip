@@ -56,10 +56,17 @@ template <int TN> struct HbSlab {
   static constexpr int PITCH = TN * 32 + 8;               // floats; rows r and r+4 land half a bank sweep apart
   static constexpr int WAVE = 32 * PITCH * 4;
 };
+// bw (BwdStats with part != null; backward-data launches): the launch also leaves the norm-backward sums of the gradient
+// it produces against z, the raw output of the layer in front (bf16, BatchNorm + LeakyReLU(slope)) -- per tile and
+// column sum(gy) and sum(gy * zhat), gy = g * act'(y), from the gradient AS STORED (rounded to bf16) -- as one row
+// [3][Cout] of bw.part (the third part, a PReLU slope's gradient, is zero here): what norm_bwd_reduce_bf16 would re-read
+// g and z for.  z is fetched 16 bytes per lane beside the store of the same 8 channels.  pair_cols: the tile's columns
+// c and c + BNT / 2 are the same produced channel (two phases of a pair share the tile).
 template <int TM, int TN, int WMW, int BNT>
 __device__ __forceinline__ void hb_epilogue(const f32x16 (&acc)[TM][TN], float* slab, const int* rowpix, float* part,
                                             int rowbase, int colw, int cbase, int wmw, const float* bias, float* stats_row,
-                                            int n0, int Cout, char* goutb, int ldo, int tid, int lane) {
+                                            int n0, int Cout, char* goutb, int ldo, int tid, int lane,
+                                            const BwdStats* bw = nullptr, float* bwd_row = nullptr, bool pair_cols = false) {
   constexpr int PITCH = HbSlab<TN>::PITCH;
   const int li = lane & 31, lh = lane >> 5;
   float bv[TN];
@@ -109,6 +116,22 @@ __device__ __forceinline__ void hb_epilogue(const f32x16 (&acc)[TM][TN], float* 
     }
   }
   constexpr int CH = TN * 4;                              // 16-byte output chunks per row
+  // norm-backward sums: this lane stores chunk lane % CH of every row it handles, i.e. always the same 8 channels
+  const bool bws = bw != nullptr && bwd_row != nullptr;
+  const int bch = cbase + (lane % CH) * 8;
+  float bsc[8], bsh[8], bmu[8], bis[8], bs1[8], bs2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool okc = bws && bch + e < Cout;
+    bsc[e] = okc ? bw->scale[bch + e] : 0.f;
+    bsh[e] = okc ? bw->shift[bch + e] : 0.f;
+    bmu[e] = okc ? bw->mean[bch + e] : 0.f;
+    bis[e] = okc ? bw->invstd[bch + e] : 0.f;
+    bs1[e] = bs2[e] = 0.f;
+  }
+  const float bslope = bws ? bw->slope : 0.f;
+  const __bf16* bz = bws ? reinterpret_cast<const __bf16*>(bw->z) : nullptr;
+  const int bldz = bws ? bw->ldz : 0;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     __builtin_amdgcn_wave_barrier();
@@ -129,6 +152,53 @@ __device__ __forceinline__ void hb_epilogue(const f32x16 (&acc)[TM][TN], float* 
       o[0] = (__bf16)v0.x; o[1] = (__bf16)v0.y; o[2] = (__bf16)v0.z; o[3] = (__bf16)v0.w;
       o[4] = (__bf16)v1.x; o[5] = (__bf16)v1.y; o[6] = (__bf16)v1.z; o[7] = (__bf16)v1.w;
       *reinterpret_cast<bf16x8*>(goutb + ((long)pix * ldo + cbase + ch * 8) * 2) = o;
+      if (bws) {
+        const bf16x8 zz = *reinterpret_cast<const bf16x8*>(bz + (long)pix * bldz + cbase + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float zf = (float)zz[e], g = (float)o[e];
+          const float y = zf * bsc[e] + bsh[e];
+          const float gy = y < 0.f ? g * bslope : g;
+          bs1[e] += gy;
+          bs2[e] = fmaf(gy, (zf - bmu[e]) * bis[e], bs2[e]);
+        }
+      }
+    }
+  }
+  if (bws) {
+    // lanes that share a chunk (lane % CH), then the WMW waves that share the columns (fixed order: no atomics)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int off = CH; off < 64; off <<= 1) {
+        bs1[e] += __shfl_xor(bs1[e], off, 64);
+        bs2[e] += __shfl_xor(bs2[e], off, 64);
+      }
+    }
+    __syncthreads();                                      // (`part` may still hold the forward statistics' partials)
+    if (lane < CH) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        part[(wmw * 2 + 0) * BNT + colw + lane * 8 + e] = bs1[e];
+        part[(wmw * 2 + 1) * BNT + colw + lane * 8 + e] = bs2[e];
+      }
+    }
+    __syncthreads();
+    const int ncol = pair_cols ? BNT / 2 : BNT;
+    if (tid < ncol && n0 + tid < Cout) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WMW; ++w) {
+        a1 += part[(w * 2 + 0) * BNT + tid];
+        a2 += part[(w * 2 + 1) * BNT + tid];
+        if (pair_cols) {
+          a1 += part[(w * 2 + 0) * BNT + tid + BNT / 2];
+          a2 += part[(w * 2 + 1) * BNT + tid + BNT / 2];
+        }
+      }
+      bwd_row[n0 + tid] = a1;
+      bwd_row[Cout + n0 + tid] = a2;
+      bwd_row[2 * Cout + n0 + tid] = 0.f;
     }
   }
 }
@@ -813,11 +883,13 @@ __global__ __launch_bounds__(512, 1) void gather_conv_bf16_wide_kernel(const Gat
     rowpix[tid] = pix;
   }
   const int cbase = PAIR ? (wn & 1) * 64 : n0 + wn * 64;             // first produced channel of this wave's columns
+  const BwdStats bwl = p.bwd;                                        // (a local copy: no pointer into the kernel arguments)
   __syncthreads();
   hb_epilogue<TM, TN, WM, BN>(acc, reinterpret_cast<float*>(lds + wid * T::EP_WAVE),
                               rowpix + (PAIR ? (wn >> 1) * BM : 0), reinterpret_cast<float*>(lds + T::EP_PART), wm * 128,
                               wn * 64, cbase, wm, p.bias, (!PAIR && p.stats) ? p.stats + (long)stats_row * 2 * Cout : nullptr,
-                              n0, Cout, reinterpret_cast<char*>(p.out), p.ldo, tid, lane);
+                              n0, Cout, reinterpret_cast<char*>(p.out), p.ldo, tid, lane, &bwl,
+                              bwl.part ? bwl.part + (long)stats_row * 3 * Cout : nullptr, PAIR);
 }
 
 // Which K-stepped form serves a gather: 0 = 256 x 128/64 tile (gather_conv_bf16_kernel), 1 = 256 x 256, 2 = 512 x 128,
@@ -1160,11 +1232,13 @@ __global__ __launch_bounds__(512, 1) void gather_patch_bf16_kernel(const GatherC
     const int oz = oz0 + z, oy = oy0 + y, ox = ox0 + x;
     rowpix[tid] = (oz < ph.Mz && oy < ph.My && ox < ph.Mx) ? ((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox : -1;
   }
+  const BwdStats bwl = p.bwd;                          // (a local copy: no pointer into the kernel arguments)
   __syncthreads();
   hb_epilogue<TM, TN, T::WM, BN>(acc, reinterpret_cast<float*>(lds + wid * HbSlab<TN>::WAVE), rowpix,
                                  reinterpret_cast<float*>(lds + T::EP_PART), wm * TM * 32, wn * (BN / WN), n0 + wn * (BN / WN), wm,
                                  p.bias, p.stats ? p.stats + (long)stats_row * 2 * Cout : nullptr, n0, Cout,
-                                 reinterpret_cast<char*>(p.out), p.ldo, tid, lane);
+                                 reinterpret_cast<char*>(p.out), p.ldo, tid, lane, &bwl,
+                                 bwl.part ? bwl.part + (long)stats_row * 3 * Cout : nullptr, false);
 }
 
 static bool hp_ok(const GatherConv& p) {
@@ -1472,11 +1546,13 @@ __global__ __launch_bounds__(512, 1) void gather_patch8_bf16_kernel(const Gather
     const int oz = oz0 + z, oy = oy0 + y, ox = ox0 + x;
     rowpix[tid] = (oz < ph.Mz && oy < ph.My && ox < ph.Mx) ? ((n * p.Do + oz) * p.Ho + oy) * p.Wo + ox : -1;
   }
+  const BwdStats bwl = p.bwd;                          // (a local copy: no pointer into the kernel arguments)
   __syncthreads();
   hb_epilogue<TM, TN, T::WM, BN>(acc, reinterpret_cast<float*>(lds + wid * HbSlab<TN>::WAVE), rowpix,
                                  reinterpret_cast<float*>(lds + T::EP_PART), wm * TM * 32, wn * (BN / WN), n0 + wn * (BN / WN), wm,
                                  p.bias, p.stats ? p.stats + (long)stats_row * 2 * Cout : nullptr, n0, Cout,
-                                 reinterpret_cast<char*>(p.out), p.ldo, tid, lane);
+                                 reinterpret_cast<char*>(p.out), p.ldo, tid, lane, &bwl,
+                                 bwl.part ? bwl.part + (long)stats_row * 3 * Cout : nullptr, false);
 }
 
 // 8 x 8 x 8 tiles pay on maps of at least 16 pixels per dimension whose extent wastes little in the last tile
@@ -1566,6 +1642,8 @@ static int hb_dispatch(const GatherConv& p, hipStream_t st, const char* what) {
   if (wide == 1 && no_ring) return mask ? hw_launch<2, 4, true, false>(p, maxM, st) : hw_launch<2, 4, false, false>(p, maxM, st);
   if (wide == 1) return mask ? hw_launch<2, 4, true>(p, maxM, st) : hw_launch<2, 4, false>(p, maxM, st);
   if (wide == 2) return mask ? hw_launch<4, 2, true>(p, maxM, st) : hw_launch<4, 2, false>(p, maxM, st);
+  MPGAN_UNSUPPORTED(p.bwd.part != nullptr, "%s: no fused norm-backward sums on the narrow K-stepped kernel "
+                                            "(mpgan_conv_bwd_stats_rows_bf16() == 0)", what);
   static int nw = 0;
   if (!nw) {
     const char* e = dev_env("MPGAN_DBG_HB_NW");      // development: force four or eight waves per block
@@ -2459,6 +2537,66 @@ extern "C" int mpgan_conv_backward_data_bf16(const mpgan_conv_geom* g, const voi
   set_geom_flags(p, g);
   build_gather_bf16(p, g, true);
   return hb_dispatch(p, (hipStream_t)stream, "conv_backward_data_bf16");
+}
+
+// Rows of norm-backward partial sums mpgan_conv_backward_data_stats_bf16 leaves for this geometry: one per (phase or
+// phase pair, m-tile) of the patch / wide form that serves it; 0 = served by the narrow K-stepped kernel, which has no
+// fused sums (run mpgan_norm_bwd_reduce_bf16).
+extern "C" int32_t mpgan_conv_bwd_stats_rows_bf16(const mpgan_conv_geom* g) {
+  if (check_geom(g)) return -1;
+  GatherConv p{};
+  set_geom_flags(p, g);
+  build_gather_bf16(p, g, true);
+  if (p.Cin % HB_BK != 0 || p.Cout % 8 != 0) return 0;
+  p.ldi = p.Cin;
+  if (hp8_use(p, false)) {
+    const HpGrid tg = hp8_grid(p);
+    return p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x;
+  }
+  if (hp_use(p, false)) {
+    const HpGrid tg = hp_grid(p);
+    return p.N * tg.tiles_z * tg.tiles_y * tg.tiles_x;
+  }
+  const int wide = hw_choice(p, false);
+  if (wide == 0) return 0;
+  if (wide == 3) return (int32_t)((max_phase_pixels(p) + 255) / 256) * (p.nphase / 2);
+  return (int32_t)phase_tile_rows(p, hw_bm(wide));
+}
+
+// mpgan_conv_backward_data_bf16 + the reduce pass of the BatchNorm + LeakyReLU(slope) in front of this conv's input, in
+// one launch: dx (bf16) is the gradient w.r.t. a = act(scale * z + shift); partials[rows][3][cin] receive the sums
+// mpgan_norm_bwd_reduce_bf16 would form from the stored dx and z (feed mpgan_norm_bwd_finalize with n = 1, chunks = rows).
+extern "C" int mpgan_conv_backward_data_stats_bf16(const mpgan_conv_geom* g, const void* dy, int32_t lddy,
+                                                   const void* w_packed_bwd, void* dx, int32_t lddx, const void* z,
+                                                   int32_t ldz, const float* scale, const float* shift, const float* mean,
+                                                   const float* invstd, float slope, float* partials, void* stream) {
+  int rc = check_geom(g);
+  if (rc) return rc;
+  MPGAN_CHECK_ARG(dy && w_packed_bwd && dx && z && scale && shift && mean && invstd && partials,
+                  "conv_backward_data_stats_bf16: null pointer");
+  MPGAN_CHECK_ARG(lddy >= g->cout && lddx >= g->cin && ldz >= g->cin, "conv_backward_data_stats_bf16: bad pitch");
+  MPGAN_UNSUPPORTED(ldz % 8 != 0 || (reinterpret_cast<uintptr_t>(z) & 15) != 0, "conv_backward_data_stats_bf16: z pitch %% 8, 16-byte aligned");
+  MPGAN_UNSUPPORTED(mpgan_conv_bwd_stats_rows_bf16(g) <= 0, "conv_backward_data_stats_bf16: this geometry has no fused sums "
+                                                            "(mpgan_conv_bwd_stats_rows_bf16() == 0)");
+  GatherConv p{};
+  p.in = static_cast<const float*>(dy); p.wp = static_cast<const float*>(w_packed_bwd); p.out = static_cast<float*>(dx);
+  p.pro = make_pro(nullptr);
+  p.ldi = lddy; p.ldo = lddx;
+  p.bwd.z = static_cast<const float*>(z); p.bwd.ldz = ldz;
+  p.bwd.scale = scale; p.bwd.shift = shift; p.bwd.mean = mean; p.bwd.invstd = invstd;
+  p.bwd.part = partials; p.bwd.leaky = 1; p.bwd.slope = slope;
+  set_geom_flags(p, g);
+  build_gather_bf16(p, g, true);
+  {   // the rows were sized on the compact geometry: a pitched operand must not change the form
+    GatherConv c = p;
+    c.ldi = c.Cin;
+    const bool a8 = hp8_use(c, false), a4 = !a8 && hp_use(c, false);
+    const bool b8 = hp8_use(p, false), b4 = !b8 && hp_use(p, false);
+    MPGAN_UNSUPPORTED(a8 != b8 || a4 != b4 || (!a8 && !a4 && hw_choice(c, false) != hw_choice(p, false)),
+                      "conv_backward_data_stats_bf16: the channel pitch of dy changes the kernel form the partial rows were "
+                      "sized for: pass a compact tensor");
+  }
+  return hb_dispatch(p, (hipStream_t)stream, "conv_backward_data_stats_bf16");
 }
 
 static void wgrad_hb_dims(const mpgan_conv_geom* g, int& Cd, int& Cg, int& T, long& M) {

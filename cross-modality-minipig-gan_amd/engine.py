@@ -582,6 +582,11 @@ def emit_conv_dgrad(prog, g: ConvGeom, dy, wp_bwd, dx, resid=None):
 
 
 _FUSE_BWD_STATS = not os.environ.get("MPGAN_DBG_NO_FUSE_BWD_STATS")
+# The bf16 path's counterpart (mpgan_conv_backward_data_stats_bf16) is OFF by default: measured at config C5 on one box
+# (tools/phase_times.py, round 4), D's backward passes take 57.9 ms per step with the sums fused into the backward-data
+# epilogues and 57.2 ms with the separate norm_bwd_reduce_bf16 launches -- the bf16 kernels run one block per CU, so the
+# epilogue's extra 16-byte z loads are exposed, while the separate pass streams g and z with the whole chip at the HBM rate.
+_FUSE_BWD_STATS_BF16 = bool(os.environ.get("MPGAN_FUSE_BWD_STATS_BF16"))
 
 
 def emit_conv_dgrad_stats(prog, g: ConvGeom, dy, wp_bwd, dx, z, nb: "NormBuf", slope: float, partials) -> int:
@@ -1524,6 +1529,7 @@ class DiscPlanBF16:
         size = dhw
         L = lib()
         part_need, ws_need = 4, 4
+        fused_rows, prev_bwd_rows = [], 0
         for i, cv in enumerate(convs):
             g = conv_geom_of(cv, n, size, dims)
             geoms.append(g)
@@ -1540,6 +1546,12 @@ class DiscPlanBF16:
             rows_total = n * size[0] * size[1] * size[2]
             fwd_rows = (rows_total + 255) // 256 if i == 0 else ops.conv_stats_rows_bf16(g)
             bwd_rows = ops.norm_bwd_rows_bf16(rows_total, cv.out_channels)
+            # (rows of the fused norm-backward sums the NEXT layer's backward-data launch leaves for this layer's norm)
+            fused_rows.append(0)
+            if i > 0 and _FUSE_BWD_STATS_BF16:
+                fused_rows[i - 1] = max(0, int(lib().mpgan_conv_bwd_stats_rows_bf16(C.byref(g.c()))))
+                part_need = max(part_need, (max(fused_rows[i - 1], prev_bwd_rows) * 4 + 1) * cv.in_channels)
+            prev_bwd_rows = bwd_rows
             part_need = max(part_need, (fwd_rows + 32) * 2 * cv.out_channels, bwd_rows * 4 * cv.out_channels + cv.out_channels)
             ws_need = max(ws_need, (ops.conv_wgrad_workspace_bf16dy(g) if i == 0 else ops.conv_wgrad_workspace_bf16(g)) // 4)
         P_last = size[0] * size[1] * size[2]
@@ -1630,11 +1642,14 @@ class DiscPlanBF16:
             gin = gas[i]
             dz = self.dzs[i]
             g32 = int(gin.dtype == torch.float32)
-            bias_part = part[brow * 3 * c + c:brow * 4 * c + c] if (want_param_grads and i > 0) else None
-            b.add("norm_bwd_reduce_bf16", L.mpgan_norm_bwd_reduce_bf16, gin.data_ptr(), g32, c, z.data_ptr(), c,
-                  nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(), 0.2, rows_total,
-                  c, part.data_ptr(), keep=(gin, z, nb, part))
-            b.add("norm_bwd_finalize", L.mpgan_norm_bwd_finalize, part.data_ptr(), 1, brow, c, rows_total, 0,
+            frow = fused_rows[i] if i < 3 else 0          # > 0: the backward-data launch that produced `gin` left the sums
+            base = max(brow, frow) * 3 * c + c            # the apply pass's bias partials sit behind the rows finalize reads
+            bias_part = part[base:base + brow * c] if (want_param_grads and i > 0) else None
+            if not frow:
+                b.add("norm_bwd_reduce_bf16", L.mpgan_norm_bwd_reduce_bf16, gin.data_ptr(), g32, c, z.data_ptr(), c,
+                      nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(), 0.2, rows_total,
+                      c, part.data_ptr(), keep=(gin, z, nb, part))
+            b.add("norm_bwd_finalize", L.mpgan_norm_bwd_finalize, part.data_ptr(), 1, frow or brow, c, rows_total, 0,
                   _p(gv(bn.weight)), _p(gv(bn.bias)), None, nb.c1.data_ptr(), nb.c2.data_ptr(), keep=(bn,))
             b.add("norm_bwd_apply_bf16", L.mpgan_norm_bwd_apply_bf16, gin.data_ptr(), g32, c, z.data_ptr(), c,
                   nb.scale.data_ptr(), nb.shift.data_ptr(), nb.mean.data_ptr(), nb.invstd.data_ptr(),
@@ -1652,7 +1667,15 @@ class DiscPlanBF16:
                           self.x_in.data_ptr(), 1, dz.data_ptr(), c, gv(cv.weight).data_ptr(), gv(cv.bias).data_ptr(),
                           1.0, ws.data_ptr(), ws.numel() * 4, keep=(gc, ws), desc=_gdesc(g),
                           tag=("wgrad_thin_kernel", 2.0 * conv_macs(g), conv_bytes(g, 2) + 2 * self.x_in.numel()))
-            if i > 0:
+            if i > 0 and fused_rows[i - 1]:
+                # ... and the reduce pass of the layer in front (its norm-backward sums against z_{i-1}) in the same launch
+                zp, nbp = zs[i - 1], nbs[i - 1]
+                b.add("conv_backward_data_bf16", L.mpgan_conv_backward_data_stats_bf16, C.byref(gc), dz.data_ptr(), c,
+                      w16b(i).data_ptr(), gas[i - 1].data_ptr(), g.cin, zp.data_ptr(), g.cin, nbp.scale.data_ptr(),
+                      nbp.shift.data_ptr(), nbp.mean.data_ptr(), nbp.invstd.data_ptr(), 0.2, part.data_ptr(),
+                      keep=(gc, zp, nbp), desc=_gdesc(g),
+                      tag=("dgrad:" + _bf16_kernel_name(g, True), 2.0 * conv_macs(g), conv_bytes(g, 2)))
+            elif i > 0:
                 b.add("conv_backward_data_bf16", L.mpgan_conv_backward_data_bf16, C.byref(gc), dz.data_ptr(), c,
                       w16b(i).data_ptr(), gas[i - 1].data_ptr(), g.cin, keep=(gc,), desc=_gdesc(g),
                       tag=("dgrad:" + _bf16_kernel_name(g, True), 2.0 * conv_macs(g), conv_bytes(g, 2)))

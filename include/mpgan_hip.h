@@ -498,6 +498,16 @@ int mpgan_norm_act_bf16(const void* z, int32_t ldz, const float* scale, const fl
  *   reduce: partial rows [mpgan_norm_bwd_rows_bf16()][3][C] for mpgan_norm_bwd_finalize(n=1, chunks=rows, P=rows_total);
  *   apply : dz (bf16) = scale*(gy - c1 - zhat*c2); bias_partials (nullable) receives per-block column sums
  *           [mpgan_norm_bwd_rows_bf16()][C] of the stored dz (the conv's bias gradient, reduce with mpgan_reduce_partials). */
+/* Backward-data of the bf16 path + the reduce pass of the BatchNorm + LeakyReLU(slope) in front of the conv's input in one
+ * launch (as mpgan_conv_backward_data_stats does for fp32): dx (bf16) is the gradient w.r.t. a = act(scale * z + shift);
+ * partials[mpgan_conv_bwd_stats_rows_bf16(g)][3][cin] receive what mpgan_norm_bwd_reduce_bf16 would form from the STORED
+ * dx and z.  rows == 0: this geometry runs on the narrow K-stepped kernel, which has no fused sums.
+ * (nn.BatchNorm3d + nn.LeakyReLU(0.2) backward, GAN_final.py:170-171 under autograd.) */
+int32_t mpgan_conv_bwd_stats_rows_bf16(const mpgan_conv_geom* g);
+int mpgan_conv_backward_data_stats_bf16(const mpgan_conv_geom* g, const void* dy, int32_t lddy, const void* w_packed_bwd,
+                                        void* dx, int32_t lddx, const void* z, int32_t ldz, const float* scale,
+                                        const float* shift, const float* mean, const float* invstd, float slope,
+                                        float* partials, void* stream);
 int32_t mpgan_norm_bwd_rows_bf16(int64_t rows, int32_t c);
 int mpgan_norm_bwd_reduce_bf16(const void* g, int32_t g_f32, int32_t ldg, const void* z, int32_t ldz, const float* scale,
                                const float* shift, const float* mean, const float* invstd, float slope, int64_t rows,

@@ -206,6 +206,49 @@ def test_big_patch_form_128_columns_bf16():
     test_conv_forward_bf16_exact_and_random(*case)
 
 
+BWD_STATS_CASES = [WIDE_CASES[0], WIDE_CASES[1], WIDE_CASES[4], WIDE_CASES[5], PATCH8_CASES[0], PATCH8_CASES[1], CASES[6]]
+
+
+@pytest.mark.parametrize("n,spatial,cin,cout,k,s,p", BWD_STATS_CASES, ids=lambda v: str(v))
+def test_backward_data_with_fused_norm_backward_sums_bf16(wide_forms, n, spatial, cin, cout, k, s, p):
+    """mpgan_conv_backward_data_stats_bf16 on every kernel form that has the sums (256 x 256 over phase pairs, 256 x 256,
+    512 x 128 per phase, both patch forms): dx is bit-identical to the plain launch, and the partial rows add up to what
+    norm_bwd_reduce computes from the STORED gradient and z -- sum(gy), sum(gy * zhat) with gy = g * LeakyReLU'(y)."""
+    import ctypes as C
+    from mpgan_amd import ops
+    from mpgan_amd._lib import check, lib
+    g = _geom(n, spatial, cin, cout, k, s, p)
+    gc = g.c()
+    rows = lib().mpgan_conv_bwd_stats_rows_bf16(C.byref(gc))
+    assert rows > 0, "this case is meant to run on a form with fused sums"
+    dims = len(spatial)
+    gen = torch.Generator().manual_seed(21)
+    w = ((torch.rand(cout, cin, *([k] * dims), generator=gen) - 0.5) * 0.2).to(BF).float()
+    dy = (torch.rand(n, cout, *g.out_dhw[3 - dims:], generator=gen) - 0.5).to(BF)
+    z = (torch.rand(n, *g.in_dhw, cin, generator=gen) * 2 - 1).to(BF).cuda()          # the layer in front's raw output
+    scale, shift = torch.rand(cin, generator=gen) + 0.5, torch.rand(cin, generator=gen) - 0.5
+    mean, invstd = torch.rand(cin, generator=gen) - 0.5, torch.rand(cin, generator=gen) + 0.5
+    wpb = ops.pack_weight_bf16(w.cuda(), for_dgrad=True)
+    dyc = to_cl(dy.float()).to(BF)
+    dx0 = torch.empty(n, *g.in_dhw, cin, device="cuda", dtype=BF)
+    ops.conv_backward_data_bf16(g, dyc, wpb, dx0)
+    dx1 = torch.full_like(dx0, float("nan"))
+    part = torch.full((rows * 3 * cin,), float("nan"), device="cuda")
+    vec = [v.cuda() for v in (scale, shift, mean, invstd)]
+    check(lib().mpgan_conv_backward_data_stats_bf16(C.byref(gc), dyc.data_ptr(), cout, wpb.data_ptr(), dx1.data_ptr(), cin,
+                                                    z.data_ptr(), cin, vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
+                                                    vec[3].data_ptr(), 0.2, part.data_ptr(),
+                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "backward_data_stats_bf16")
+    assert torch.equal(dx0, dx1)
+    got = part.view(rows, 3, cin).double().sum(0).cpu()
+    gd, zd = dx1.double().cpu().reshape(-1, cin), z.double().cpu().reshape(-1, cin)
+    y = zd * scale.double() + shift.double()
+    gy = torch.where(y < 0, gd * 0.2, gd)
+    want = torch.stack([gy.sum(0), (gy * (zd - mean.double()) * invstd.double()).sum(0), torch.zeros(cin, dtype=torch.float64)])
+    tol = 2e-5 * gy.abs().sum(0).max().item()
+    assert (got - want).abs().max().item() <= tol, ((got - want).abs().max().item(), tol)
+
+
 def test_wide_forms_serve_config_c5_by_default():
     """D.conv3 / D.conv4 at 128^3 bs 4: forward of conv3 and backward-data of conv4 on 256 x 256 tiles, backward-data of
     conv3 (128 produced channels, eight congruent phases) on 256 x 256 tiles over phase pairs."""

@@ -628,6 +628,8 @@ __global__ __launch_bounds__(256) void thin_cin1_kernel(const GatherConv p) {
 // Cin == 1, Cout = 4*CQ <= 64: one thread = one output pixel x ALL output channels.  The input
 // sample of a tap is loaded once and meets the tap's whole weight row, read from LDS at a
 // wave-uniform address (broadcast); a thread stores 16*CQ contiguous bytes, a wave a contiguous run.
+// (A fully unrolled 27-tap instance was tried in round 4: hipcc hoists every tap's weight row out of LDS at once and
+//  spills -- 96 -> 881 us at 128^3; the run-time tap loops stay.)
 template <int CQ, bool OUT_BF16 = false>
 __global__ __launch_bounds__(256) void thin_cin1_full_kernel(const GatherConv p) {
   extern __shared__ __attribute__((aligned(16))) float wl[];   // [T][4*CQ]
@@ -1015,6 +1017,10 @@ static bool convt_oct_ok(const GatherConv& p) {
 // vector path, the two border threads of a row read element by element.
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+// REVX: the x taps run backwards (backward-data: window position 2 - jx of tap jx; forward: jx) -- a template
+// parameter, so that the window index of every product is a compile-time constant (as a runtime value it cost two
+// selects per FMA: 216 beside the 108 FMAs of a thread).
+template <bool REVX>
 __global__ __launch_bounds__(256) void thin_c1c1_rows4_kernel(const GatherConv p) {
   const Phase& ph = p.ph[0];
   const int Mx = ph.Mx, groups = (Mx + 3) >> 2;
@@ -1055,14 +1061,24 @@ __global__ __launch_bounds__(256) void thin_c1c1_rows4_kernel(const GatherConv p
       const float* __restrict__ wr = p.wp + (kz * 3 + ky) * 3;      // packed [1][tap][1]
 #pragma unroll
       for (int jx = 0; jx < 3; ++jx) {
-        const int off = ph.dx0 + p.dstep[2] * jx + 1;                // 0 .. 2: window position of output 0's sample
+        const int off = REVX ? 2 - jx : jx;                          // window position of output 0's sample (thin_c1c1_ok)
         const float w = wr[ph.kx0 + p.kstep[2] * jx];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = fmaf(w, off == 0 ? win[j] : (off == 1 ? win[j + 1] : win[j + 2]), o[j]);
+        for (int j = 0; j < 4; ++j) o[j] = fmaf(w, win[j + off], o[j]);
       }
     }
   }
   const long obase = (((long)n * p.Do + z) * p.Ho + y) * p.Wo + x0;
+  if (x0 + 3 < Mx && (p.Wo & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.resid)) & 15) == 0) {
+    float4 v = make_float4(o[0], o[1], o[2], o[3]);                // whole quad, 16-byte aligned rows: one load, one store
+    if (p.resid) {
+      const float4 rr = *reinterpret_cast<const float4*>(p.resid + obase);
+      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+    }
+    if (p.tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+    *reinterpret_cast<float4*>(p.out + obase) = v;
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     if (x0 + j >= Mx) break;
@@ -1230,7 +1246,8 @@ static int launch_thin(const GatherConv& p, long maxM, hipStream_t st) {
   if (thin_c1c1_ok(p)) {
     const Phase& ph0 = p.ph[0];
     const long threads4 = (long)p.N * ph0.Mz * ph0.My * ((ph0.Mx + 3) / 4);
-    hipLaunchKernelGGL(thin_c1c1_rows4_kernel, dim3((unsigned)((threads4 + 255) / 256)), dim3(256), 0, st, p);
+    if (p.dstep[2] < 0) hipLaunchKernelGGL(thin_c1c1_rows4_kernel<true>, dim3((unsigned)((threads4 + 255) / 256)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(thin_c1c1_rows4_kernel<false>, dim3((unsigned)((threads4 + 255) / 256)), dim3(256), 0, st, p);
     return check_launch("thin_c1c1_rows4");
   }
   if (thin_cin1_ok(p)) {

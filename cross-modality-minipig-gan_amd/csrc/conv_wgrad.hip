@@ -443,16 +443,26 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int e = 0; e < V; ++e) bsum[e] += d[e];
       const int bz = mz * p.sz - p.pz, by = my * p.sy - p.py, bx = mx * p.sx - p.px;
+      // ONE 64-bit address per pixel (its tap (0, 0, 0); it may lie in front of the tensor and is then never read) and a
+      // wave-uniform 32-bit offset per (kz, ky) row of taps: the per-tap 64-bit pixel index cost more than the FMAs
+      const float* __restrict__ g0 = p.gath + ((((long)n * p.Gz + bz) * p.Gy + by) * p.Gx + bx) * p.ldg;
+      constexpr int KX = T == 1 ? 1 : 3, KY = KX, KZ = T / (KX * KY);       // host admits only 1, 3x3 and 3x3x3 kernels here
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        constexpr int KX = T == 1 ? 1 : 3, KY = KX;       // host admits only 1, 3x3 and 3x3x3 kernels here
-        const int kx = t % KX, ky = (t / KX) % KY, kz = t / (KX * KY);   // constants after unrolling
-        const int iz = bz + kz, iy = by + ky, ix = bx + kx;
-        const bool ok = (unsigned)iz < (unsigned)p.Gz && (unsigned)iy < (unsigned)p.Gy && (unsigned)ix < (unsigned)p.Gx;
-        const long pix = (((long)n * p.Gz + iz) * p.Gy + iy) * p.Gx + ix;
-        const float g = ok ? p.gath[pix * p.ldg] : 0.f;
+      for (int kz = 0; kz < KZ; ++kz) {
+        const bool okz = (unsigned)(bz + kz) < (unsigned)p.Gz;
 #pragma unroll
-        for (int e = 0; e < V; ++e) acc[t][e] = fmaf(d[e], g, acc[t][e]);
+        for (int ky = 0; ky < KY; ++ky) {
+          const bool oky = okz && (unsigned)(by + ky) < (unsigned)p.Gy;
+          const int ro = (kz * p.Gy + ky) * p.Gx * p.ldg;
+#pragma unroll
+          for (int kx = 0; kx < KX; ++kx) {
+            const int t = (kz * KY + ky) * KX + kx;
+            const bool ok = oky && (unsigned)(bx + kx) < (unsigned)p.Gx;
+            const float g = ok ? g0[ro + kx * p.ldg] : 0.f;
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[t][e] = fmaf(d[e], g, acc[t][e]);
+          }
+        }
       }
     }
   }
